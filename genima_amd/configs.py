@@ -1,0 +1,154 @@
+"""Architecture configs for the Genima hot path (diffusers-style ``config.json`` dictionaries).
+
+The reference loads these architectures from checkpoints:
+  * ``stabilityai/sd-turbo`` UNet/VAE/text-encoder  (controller/cfgs/eval_genima.yaml:4,
+    diffusion/train_controlnet_genima.py:1042-1064)
+  * ``ControlNetModel.from_unet(unet)``             (diffusion/train_controlnet_genima.py:1066-1071)
+Key names follow the published diffusers/transformers ``config.json`` schema so a real checkpoint's
+config can be dropped in unchanged.  ``*_tiny`` configs keep the topology (4 levels, 2 layers per
+block, cross-attention at levels 0-2, head_dim 64, GroupNorm(32)) at reduced width for parity tests.
+"""
+from __future__ import annotations
+
+import copy
+
+# ----------------------------------------------------------------------------- UNet (SD-2.1 family)
+SD_TURBO_UNET = {
+    "_class_name": "UNet2DConditionModel",
+    "in_channels": 4,
+    "out_channels": 4,
+    "sample_size": 64,
+    "block_out_channels": [320, 640, 1280, 1280],
+    "layers_per_block": 2,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D", "DownBlock2D"],
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D"],
+    "attention_head_dim": [5, 10, 20, 20],  # == number of heads in the SD-2.x family (head dim 64)
+    "cross_attention_dim": 1024,
+    "use_linear_projection": True,
+    "norm_num_groups": 32,
+    "norm_eps": 1e-5,
+    "act_fn": "silu",
+    "flip_sin_to_cos": True,
+    "freq_shift": 0,
+    "transformer_layers_per_block": 1,
+    "resnet_time_scale_shift": "default",
+}
+
+TINY_UNET = dict(
+    SD_TURBO_UNET,
+    block_out_channels=[64, 128, 256, 256],
+    attention_head_dim=[1, 2, 4, 4],
+    cross_attention_dim=128,
+    sample_size=16,
+)
+
+# ----------------------------------------------------------------------------- ControlNet
+SD_TURBO_CONTROLNET = dict(
+    {k: v for k, v in SD_TURBO_UNET.items() if k not in ("out_channels", "up_block_types")},
+    _class_name="ControlNetModel",
+    conditioning_channels=3,
+    conditioning_embedding_out_channels=[16, 32, 96, 256],
+    global_pool_conditions=False,
+)
+TINY_CONTROLNET = dict(
+    {k: v for k, v in TINY_UNET.items() if k not in ("out_channels", "up_block_types")},
+    _class_name="ControlNetModel",
+    conditioning_channels=3,
+    conditioning_embedding_out_channels=[16, 32, 96, 256],
+    global_pool_conditions=False,
+)
+
+# ----------------------------------------------------------------------------- AutoencoderKL
+SD_TURBO_VAE = {
+    "_class_name": "AutoencoderKL",
+    "in_channels": 3,
+    "out_channels": 3,
+    "latent_channels": 4,
+    "block_out_channels": [128, 256, 512, 512],
+    "layers_per_block": 2,
+    "norm_num_groups": 32,
+    "act_fn": "silu",
+    "scaling_factor": 0.18215,
+    "sample_size": 768,
+}
+TINY_VAE = dict(SD_TURBO_VAE, block_out_channels=[32, 64, 64, 64], sample_size=128)
+
+# ----------------------------------------------------------------------------- CLIP text towers
+SD_TURBO_TEXT = {  # OpenCLIP ViT-H/14 text tower truncated to 23 layers
+    "_class_name": "CLIPTextModel",
+    "vocab_size": 49408,
+    "hidden_size": 1024,
+    "intermediate_size": 4096,
+    "num_hidden_layers": 23,
+    "num_attention_heads": 16,
+    "max_position_embeddings": 77,
+    "hidden_act": "gelu",
+    "layer_norm_eps": 1e-5,
+    "projection_dim": 0,
+}
+TINY_TEXT = dict(SD_TURBO_TEXT, vocab_size=1024, hidden_size=128, intermediate_size=512,
+                 num_hidden_layers=2, num_attention_heads=2)
+
+ACT_CLIP_TEXT = {  # openai CLIP ViT-B/32 text tower (controller/method/genima_act.py:314-346)
+    "_class_name": "CLIPTextModel",
+    "vocab_size": 49408,
+    "hidden_size": 512,
+    "intermediate_size": 2048,
+    "num_hidden_layers": 12,
+    "num_attention_heads": 8,
+    "max_position_embeddings": 77,
+    "hidden_act": "quick_gelu",
+    "layer_norm_eps": 1e-5,
+    "projection_dim": 512,
+}
+TINY_ACT_CLIP_TEXT = dict(ACT_CLIP_TEXT, vocab_size=1024, hidden_size=128, intermediate_size=512,
+                          num_hidden_layers=2, num_attention_heads=2, projection_dim=64)
+
+# ----------------------------------------------------------------------------- scheduler (SD-Turbo scheduler_config.json)
+SD_TURBO_SCHEDULER = {
+    "_class_name": "EulerDiscreteScheduler",
+    "num_train_timesteps": 1000,
+    "beta_start": 0.00085,
+    "beta_end": 0.012,
+    "beta_schedule": "scaled_linear",
+    "prediction_type": "epsilon",
+    "timestep_spacing": "trailing",
+    "steps_offset": 1,
+    "use_karras_sigmas": False,
+    "interpolation_type": "linear",
+    "timestep_type": "discrete",
+}
+
+# ----------------------------------------------------------------------------- ACT controller
+ACT_POLICY = {  # controller/cfgs/method/genima_act.yaml:13-39
+    "hidden_dim": 256,
+    "enc_layers": 4,
+    "dec_layers": 6,
+    "dim_feedforward": 2048,
+    "nheads": 8,
+    "num_queries": 20,
+    "state_dim": 8,
+    "action_dim": 8,
+    "latent_dim": 32,
+    "num_views": 4,
+    "image_size": 256,
+    "backbone": "resnet18",
+    "use_lang_cond": True,
+    "lang_dim": 512,
+    "pre_norm": False,
+}
+TINY_ACT_POLICY = dict(ACT_POLICY, hidden_dim=64, enc_layers=1, dec_layers=2, dim_feedforward=128, nheads=2,
+                       image_size=64, lang_dim=64)
+
+
+def family(name: str) -> dict:
+    """Return the dict of component configs for a model family ("sd-turbo" or "tiny")."""
+    if name == "sd-turbo":
+        fam = dict(unet=SD_TURBO_UNET, controlnet=SD_TURBO_CONTROLNET, vae=SD_TURBO_VAE, text=SD_TURBO_TEXT,
+                   scheduler=SD_TURBO_SCHEDULER, act=ACT_POLICY, act_text=ACT_CLIP_TEXT)
+    elif name == "tiny":
+        fam = dict(unet=TINY_UNET, controlnet=TINY_CONTROLNET, vae=TINY_VAE, text=TINY_TEXT,
+                   scheduler=SD_TURBO_SCHEDULER, act=TINY_ACT_POLICY, act_text=TINY_ACT_CLIP_TEXT)
+    else:
+        raise KeyError(f"unknown model family {name!r}")
+    return copy.deepcopy(fam)

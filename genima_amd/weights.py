@@ -1,0 +1,140 @@
+"""Seeded synthetic weights + checkpoint IO for the Genima hot path.
+
+No checkpoints exist on the build or GPU boxes (no network), so benchmarks and parity tests use weights
+drawn from an in-repo *counter-based* PRNG: element ``i`` of tensor ``name`` depends only on
+``(seed, name, i)``, never on numpy/torch generator state or version, so the CPU oracle and the HIP
+path see bit-identical fp32 master weights on every box.  Scales follow SURVEY.md §8(d): conv/linear
+~ U(-a, a) with std 1/sqrt(fan_in), norm gamma = 1 +- 0.1, beta = +-0.1, non-zero ControlNet
+"zero convs" (std 0.02) so the residual path is exercised.
+
+Real checkpoints: ``load_diffusers_dir`` reads the layout the reference loads
+(``config.json`` + ``diffusion_pytorch_model[.fp16].safetensors`` /``model[.fp16].safetensors``;
+controller/agent/sd_controlnet_agent.py:21-42) and ``save_diffusers_dir`` writes it
+(diffusion/train_controlnet_genima.py:1077-1105, :1486).
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """Vectorised splitmix64 finaliser over uint64 (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def counter_uniform(seed: int, name: str, n: int) -> np.ndarray:
+    """``n`` float32 values uniform in [-1, 1), a pure function of (seed, name, index)."""
+    base = _splitmix64(np.array([(seed * 0x9E3779B97F4A7C15 + _fnv1a64(name)) & 0xFFFFFFFFFFFFFFFF],
+                                dtype=np.uint64))[0]
+    out = np.empty(n, dtype=np.float32)
+    chunk = 1 << 22
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        with np.errstate(over="ignore"):
+            idx = (np.arange(s, e, dtype=np.uint64) + base) & _M64
+        z = _splitmix64(idx)
+        u = (z >> np.uint64(40)).astype(np.float32) * np.float32(1.0 / (1 << 24))  # [0,1), 24 bits
+        out[s:e] = u * np.float32(2.0) - np.float32(1.0)
+    return out
+
+
+def counter_bytes(seed: int, name: str, n: int) -> np.ndarray:
+    """``n`` uint8 values (synthetic images)."""
+    u = counter_uniform(seed, name, n)
+    return np.clip(np.floor((u * 0.5 + 0.5) * 256.0), 0, 255).astype(np.uint8)
+
+
+_SQRT3 = 3.0 ** 0.5
+
+
+def _init_rule(name: str, shape):
+    """Return (kind, scale) for a parameter."""
+    leaf = name.rsplit(".", 1)[-1]
+    is_norm = any(t in name for t in (".norm", "norm_out", "layer_norm", "group_norm", "ln_", ".bn"))
+    if is_norm and len(shape) == 1:
+        return ("gamma", 0.1) if leaf == "weight" else ("beta", 0.1)
+    if leaf == "bias":
+        return ("uniform", 0.02 * _SQRT3)
+    if "token_embedding" in name or "position_embedding" in name or name.endswith("embed.weight"):
+        return ("uniform", 0.02 * _SQRT3)
+    if name.startswith("controlnet_down_blocks") or name.startswith("controlnet_mid_block") \
+            or name.startswith("controlnet_cond_embedding.conv_out"):
+        return ("uniform", 0.02 * _SQRT3)
+    fan_in = 1
+    for d in shape[1:]:
+        fan_in *= d
+    return ("uniform", _SQRT3 / max(fan_in, 1) ** 0.5)
+
+
+def synth_state_dict(schema: "OrderedDict[str, tuple]", seed: int, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
+    """fp32 master state dict for ``schema`` (see module docstring)."""
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in schema.items():
+        n = int(np.prod(shape)) if len(shape) else 1
+        kind, scale = _init_rule(name, shape)
+        u = counter_uniform(seed, prefix + name, n)
+        if kind == "gamma":
+            v = 1.0 + scale * u
+        else:
+            v = scale * u
+        sd[name] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)).reshape(shape))
+    return sd
+
+
+def round_to(sd: Dict[str, torch.Tensor], dtype: torch.dtype) -> "OrderedDict[str, torch.Tensor]":
+    """Round master weights through ``dtype`` and back to fp32 (what an fp16 checkpoint holds)."""
+    return OrderedDict((k, v.to(dtype).to(torch.float32)) for k, v in sd.items())
+
+
+# ----------------------------------------------------------------------------- diffusers-style directories
+_WEIGHT_FILES = (
+    "diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors",
+    "model.fp16.safetensors", "model.safetensors",
+)
+
+
+def load_diffusers_dir(path: str, subfolder: Optional[str] = None):
+    """Return (config dict, fp32 state dict) from a diffusers/transformers component directory."""
+    from safetensors.torch import load_file
+
+    d = os.path.join(path, subfolder) if subfolder else path
+    with open(os.path.join(d, "config.json")) as f:
+        cfg = json.load(f)
+    for fn in _WEIGHT_FILES:
+        p = os.path.join(d, fn)
+        if os.path.exists(p):
+            sd = load_file(p)
+            return cfg, OrderedDict((k, v.to(torch.float32)) for k, v in sd.items())
+    raise FileNotFoundError(f"no safetensors weight file under {d} (looked for {_WEIGHT_FILES})")
+
+
+def save_diffusers_dir(path: str, cfg: dict, sd: Dict[str, torch.Tensor], dtype=torch.float32,
+                       weight_name: str = "diffusion_pytorch_model.safetensors"):
+    from safetensors.torch import save_file
+
+    os.makedirs(path, exist_ok=True)
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg, f, indent=2, sort_keys=True)
+    save_file({k: v.detach().to(dtype).contiguous().cpu() for k, v in sd.items()}, os.path.join(path, weight_name))
