@@ -1,0 +1,269 @@
+// C-ABI plumbing of libgenima_hip.so: context, thread-local error string, op programs (record / replay / hipGraph), events.
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[1024] = "";
+
+void gn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+
+enum OpType {
+  OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
+  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL
+};
+
+struct GenericArgs {  // argument block of the small ops
+  const void* p0; const void* p1; const void* p2; void* p3;
+  int64_t n0, n1;
+  int32_t i0, i1, i2, i3;
+  float f0, f1;
+};
+
+struct Op {
+  int type;
+  union {
+    gn_gemm_desc gemm;
+    gn_attn_desc attn;
+    gn_groupnorm_desc gnorm;
+    GenericArgs g;
+  };
+};
+
+}  // namespace
+
+struct gn_program {
+  gn_ctx* ctx;
+  std::vector<Op> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+static int32_t run_op(gn_ctx* ctx, const Op& op) {
+  const GenericArgs& g = op.g;
+  switch (op.type) {
+    case OP_GEMM: return gn_launch_gemm(ctx, &op.gemm);
+    case OP_ATTN: return gn_launch_attention(ctx, &op.attn);
+    case OP_GROUPNORM: return gn_launch_groupnorm(ctx, &op.gnorm);
+    case OP_LAYERNORM: return gn_layernorm_fwd(ctx, g.p0, g.p1, g.p2, g.p3, g.n0, g.i0, g.f0);
+    case OP_TEMB: return gn_timestep_embedding(ctx, (const float*)g.p0, g.p3, g.i0, g.i1, g.i2, g.f0);
+    case OP_SCALE_PAD: return gn_scale_pad(ctx, g.p0, g.p3, g.n0, g.i0, g.i1, g.f0);
+    case OP_EULER: return gn_euler_step(ctx, g.p3, g.p0, g.n0, g.i0, g.i1, g.f0, g.f1);
+    case OP_F16_TO_U8: return gn_image_f16_to_u8(ctx, g.p0, (uint8_t*)g.p3, g.n0, g.i0);
+    case OP_U8_TO_F16: return gn_image_u8_to_f16(ctx, (const uint8_t*)g.p0, g.p3, g.n0, g.i0, g.f0, g.f1);
+    case OP_ADD: return gn_add(ctx, g.p0, g.p1, g.p3, g.n0);
+    case OP_ACT: return gn_act(ctx, g.p0, g.p3, g.n0, g.i0);
+    case OP_EMBED: return gn_embedding(ctx, (const int32_t*)g.p0, g.p1, g.p2, g.p3, g.i0, g.i1, g.i2);
+    case OP_SOFTMAX: return gn_softmax_rows(ctx, g.p3, g.n0, g.i0, g.i1, g.f0);
+    case OP_MAXPOOL: return gn_maxpool3x3s2(ctx, g.p0, g.p3, g.i0, g.i1, g.i2, g.i3);
+    default: gn_set_error("gn_program: unknown op type %d", op.type); return GN_ERR_INVALID;
+  }
+}
+
+static int32_t push_generic(gn_program* p, int type, const void* p0, const void* p1, const void* p2, void* p3, int64_t n0,
+                            int64_t n1, int32_t i0, int32_t i1, int32_t i2, int32_t i3, float f0, float f1) {
+  GN_REQUIRE(p, "gn_program_add_*: null program");
+  Op op;
+  memset(&op, 0, sizeof(op));
+  op.type = type;
+  op.g = GenericArgs{p0, p1, p2, p3, n0, n1, i0, i1, i2, i3, f0, f1};
+  p->ops.push_back(op);
+  return GN_OK;
+}
+
+extern "C" {
+
+int32_t gn_version(void) { return 100; }
+const char* gn_last_error(void) { return g_err; }
+
+int32_t gn_ctx_create(int32_t device, void* stream, gn_ctx** out) {
+  GN_REQUIRE(out, "gn_ctx_create: null out");
+  int n = 0;
+  GN_HIP(hipGetDeviceCount(&n));
+  GN_REQUIRE(device >= 0 && device < n, "gn_ctx_create: device %d out of range (%d visible)", device, n);
+  GN_HIP(hipSetDevice(device));
+  gn_ctx* c = new gn_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  *out = c;
+  return GN_OK;
+}
+int32_t gn_ctx_destroy(gn_ctx* ctx) {
+  delete ctx;
+  return GN_OK;
+}
+int32_t gn_ctx_set_stream(gn_ctx* ctx, void* stream) {
+  GN_REQUIRE(ctx, "gn_ctx_set_stream: null ctx");
+  ctx->stream = (hipStream_t)stream;
+  return GN_OK;
+}
+
+int32_t gn_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
+  GN_REQUIRE(ctx, "gn_gemm: null ctx");
+  return gn_launch_gemm(ctx, d);
+}
+int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d) {
+  GN_REQUIRE(ctx, "gn_attention_fwd: null ctx");
+  return gn_launch_attention(ctx, d);
+}
+int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d) {
+  GN_REQUIRE(ctx, "gn_groupnorm_fwd: null ctx");
+  return gn_launch_groupnorm(ctx, d);
+}
+
+// ---- programs ---------------------------------------------------------------------------------------------------------
+int32_t gn_program_create(gn_ctx* ctx, gn_program** out) {
+  GN_REQUIRE(ctx && out, "gn_program_create: null argument");
+  gn_program* p = new gn_program();
+  p->ctx = ctx;
+  *out = p;
+  return GN_OK;
+}
+int32_t gn_program_destroy(gn_program* p) {
+  if (p) {
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    delete p;
+  }
+  return GN_OK;
+}
+int32_t gn_program_add_gemm(gn_program* p, const gn_gemm_desc* d) {
+  GN_REQUIRE(p && d, "gn_program_add_gemm: null argument");
+  Op op;
+  memset(&op, 0, sizeof(op));
+  op.type = OP_GEMM;
+  op.gemm = *d;
+  p->ops.push_back(op);
+  return GN_OK;
+}
+int32_t gn_program_add_attention(gn_program* p, const gn_attn_desc* d) {
+  GN_REQUIRE(p && d, "gn_program_add_attention: null argument");
+  Op op;
+  memset(&op, 0, sizeof(op));
+  op.type = OP_ATTN;
+  op.attn = *d;
+  p->ops.push_back(op);
+  return GN_OK;
+}
+int32_t gn_program_add_groupnorm(gn_program* p, const gn_groupnorm_desc* d) {
+  GN_REQUIRE(p && d, "gn_program_add_groupnorm: null argument");
+  Op op;
+  memset(&op, 0, sizeof(op));
+  op.type = OP_GROUPNORM;
+  op.gnorm = *d;
+  p->ops.push_back(op);
+  return GN_OK;
+}
+int32_t gn_program_add_layernorm(gn_program* p, const void* x, const void* gamma, const void* beta, void* y, int64_t M, int32_t C, float eps) {
+  return push_generic(p, OP_LAYERNORM, x, gamma, beta, y, M, 0, C, 0, 0, 0, eps, 0.f);
+}
+int32_t gn_program_add_timestep_embedding(gn_program* p, const float* t, void* out, int32_t B, int32_t dim, int32_t flip, float freq_shift) {
+  return push_generic(p, OP_TEMB, t, nullptr, nullptr, out, 0, 0, B, dim, flip, 0, freq_shift, 0.f);
+}
+int32_t gn_program_add_scale_pad(gn_program* p, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad, float scale) {
+  return push_generic(p, OP_SCALE_PAD, x, nullptr, nullptr, out, pixels, 0, C, Cpad, 0, 0, scale, 0.f);
+}
+int32_t gn_program_add_euler_step(gn_program* p, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps, float sigma, float sigma_next) {
+  return push_generic(p, OP_EULER, eps, nullptr, nullptr, x, pixels, 0, C, ld_eps, 0, 0, sigma, sigma_next);
+}
+int32_t gn_program_add_image_f16_to_u8(gn_program* p, const void* in, uint8_t* out, int64_t pixels, int32_t ld) {
+  return push_generic(p, OP_F16_TO_U8, in, nullptr, nullptr, out, pixels, 0, ld, 0, 0, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float mul, float add) {
+  return push_generic(p, OP_U8_TO_F16, in, nullptr, nullptr, out, pixels, 0, Cpad, 0, 0, 0, mul, add);
+}
+int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n) {
+  return push_generic(p, OP_ADD, a, b, nullptr, out, n, 0, 0, 0, 0, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_act(gn_program* p, const void* x, void* out, int64_t n, int32_t act) {
+  return push_generic(p, OP_ACT, x, nullptr, nullptr, out, n, 0, act, 0, 0, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_embedding(gn_program* p, const int32_t* ids, const void* tok, const void* pos, void* out, int32_t B, int32_t L, int32_t D) {
+  return push_generic(p, OP_EMBED, ids, tok, pos, out, 0, 0, B, L, D, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_softmax_rows(gn_program* p, void* x, int64_t rows, int32_t cols, int32_t ld, float scale) {
+  return push_generic(p, OP_SOFTMAX, nullptr, nullptr, nullptr, x, rows, 0, cols, ld, 0, 0, scale, 0.f);
+}
+int32_t gn_program_add_maxpool3x3s2(gn_program* p, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C) {
+  return push_generic(p, OP_MAXPOOL, x, nullptr, nullptr, y, 0, 0, B, H, W, C, 0.f, 0.f);
+}
+int64_t gn_program_num_ops(const gn_program* p) { return p ? (int64_t)p->ops.size() : 0; }
+
+int32_t gn_program_run(gn_program* p, int64_t first, int64_t last) {
+  GN_REQUIRE(p, "gn_program_run: null program");
+  const int64_t n = (int64_t)p->ops.size();
+  if (last < 0 || last > n) last = n;
+  GN_REQUIRE(first >= 0 && first <= last, "gn_program_run: bad range [%ld, %ld)", (long)first, (long)last);
+  for (int64_t i = first; i < last; ++i) {
+    int32_t rc = run_op(p->ctx, p->ops[(size_t)i]);
+    if (rc != GN_OK) {
+      char tmp[900];
+      snprintf(tmp, sizeof(tmp), "%s", g_err);
+      gn_set_error("op %ld (type %d): %s", (long)i, p->ops[(size_t)i].type, tmp);
+      return rc;
+    }
+  }
+  return GN_OK;
+}
+
+int32_t gn_program_capture(gn_program* p) {
+  GN_REQUIRE(p, "gn_program_capture: null program");
+  GN_REQUIRE(p->ctx->stream != nullptr, "gn_program_capture: needs a non-default stream");
+  if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+  if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+  GN_HIP(hipStreamBeginCapture(p->ctx->stream, hipStreamCaptureModeThreadLocal));
+  int32_t rc = gn_program_run(p, 0, -1);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(p->ctx->stream, &g);
+  if (rc != GN_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) { gn_set_error("hipStreamEndCapture failed: %s", hipGetErrorString(e)); return GN_ERR_HIP; }
+  p->graph = g;
+  GN_HIP(hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0));
+  return GN_OK;
+}
+
+int32_t gn_program_launch(gn_program* p) {
+  GN_REQUIRE(p && p->exec, "gn_program_launch: program not captured");
+  GN_HIP(hipGraphLaunch(p->exec, p->ctx->stream));
+  return GN_OK;
+}
+
+// ---- events ----------------------------------------------------------------------------------------------------------
+int32_t gn_event_create(void** ev) {
+  GN_REQUIRE(ev, "gn_event_create: null");
+  hipEvent_t e;
+  GN_HIP(hipEventCreate(&e));
+  *ev = (void*)e;
+  return GN_OK;
+}
+int32_t gn_event_destroy(void* ev) {
+  if (ev) GN_HIP(hipEventDestroy((hipEvent_t)ev));
+  return GN_OK;
+}
+int32_t gn_event_record(gn_ctx* ctx, void* ev) {
+  GN_REQUIRE(ctx && ev, "gn_event_record: null");
+  GN_HIP(hipEventRecord((hipEvent_t)ev, ctx->stream));
+  return GN_OK;
+}
+int32_t gn_event_elapsed_ms(void* start, void* stop, float* ms) {
+  GN_REQUIRE(start && stop && ms, "gn_event_elapsed_ms: null");
+  GN_HIP(hipEventSynchronize((hipEvent_t)stop));
+  GN_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+  return GN_OK;
+}
+int32_t gn_stream_synchronize(gn_ctx* ctx) {
+  GN_REQUIRE(ctx, "gn_stream_synchronize: null ctx");
+  GN_HIP(hipStreamSynchronize(ctx->stream));
+  return GN_OK;
+}
+
+}  // extern "C"

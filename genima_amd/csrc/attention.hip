@@ -1,0 +1,224 @@
+// Flash-style attention forward on MFMA for gfx950 (self-, cross- and causal CLIP attention).
+//
+// Everything is computed transposed so the softmax row statistics are lane-local:
+//   S^T[key, q] = K_tile . Q^T        (A operand = K rows from LDS, B operand = Q held in registers)
+//   O^T[d,  q]  = V^T_tile . P^T      (A operand = V^T rows from LDS, B operand = P^T straight from the S^T accumulators)
+// With v_mfma_f32_32x32x16_f16 the D layout puts column (= query) lane&31 in each lane, so the running max / sum of a query
+// row live in the two lanes {l, l+32}; the only cross-lane traffic per key tile is one exchange with lane^32.
+// The K tile is written to LDS with key bits 2 and 3 swapped so that the 8 S^T accumulators a lane holds per 16-key step are
+// 8 *consecutive* keys: converting them to f16 gives the PV B-operand directly and the V^T fragment is one ds_read_b128.
+// V arrives already transposed ([b][h*D+d][key]) from the V projection's epilogue, so both tiles use the same 16-byte-chunk
+// XOR-swizzled LDS image as the GEMM kernel (conflict-free ds_read_b128).
+// Block = 4 waves x 32 query rows; key tile = 64; global -> register -> LDS staging with the next tile's loads in flight
+// under the current tile's MFMAs.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 64;  // keys per tile
+
+struct AttnParams {
+  const f16* q; const f16* k; const f16* vt; f16* o;
+  long q_bs, k_bs, vt_bs, o_bs;
+  int q_rs, k_rs, vt_rs, o_rs;
+  int heads, Nq, Nk, causal;
+  float scale_log2;  // scale * log2(e)
+};
+
+__device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int ROWB = D * 2;        // K tile row bytes
+  constexpr int KCH = D / 8;         // 16-byte chunks per K row
+  constexpr int KS = D / 16;         // k16 steps of QK^T
+  constexpr int DT = D / 32;         // 32-row d tiles of O^T
+  constexpr int K_BYTES = KT * ROWB; // K tile: [64 keys][D]
+  constexpr int V_BYTES = D * 128;   // V^T tile: [D rows][64 keys]
+  constexpr int KLD = (KT * KCH) / 256;  // chunks per thread (K)
+  constexpr int VLD = (D * 8) / 256;     // chunks per thread (V^T)
+  static_assert(KLD >= 1 && VLD >= 1, "tile too small for 256 threads");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + V_BYTES];
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + K_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * 128;
+  const int qrow = q0 + wave * 32 + l31;
+
+  const f16* qp = p.q + (long)b * p.q_bs + (long)h * D;
+  const f16* kp = p.k + (long)b * p.k_bs + (long)h * D;
+  const f16* vp = p.vt + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
+
+  // Q fragments (B operand): lane holds Q[qrow][16*ks + 8*hi .. +8]
+  f16x8 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qrow < p.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)qrow * p.q_rs + ks * 16 + hi * 8);
+    qf[ks] = *reinterpret_cast<f16x8*>(&v);
+  }
+
+  f32x16 oacc[DT];
+#pragma unroll
+  for (int t = 0; t < DT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
+  float m_run = -1e30f, l_run = 0.0f;
+
+  // key range: causal rows never look past their own index
+  int nk_eff = p.Nk;
+  if (p.causal) nk_eff = min(p.Nk, q0 + 128);
+  const int ntiles = (nk_eff + KT - 1) / KT;
+
+  uint4 rk[KLD], rv[VLD];
+  auto load_tile = [&](int t) {
+    const int j0 = t * KT;
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int id = tid + 256 * i;
+      const int key = id / KCH, ch = id % KCH;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (j0 + key < p.Nk) v = *reinterpret_cast<const uint4*>(kp + (long)(j0 + key) * p.k_rs + ch * 8);
+      rk[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int id = tid + 256 * i;
+      const int drow = id >> 3, ch = id & 7;
+      uint4 v = *reinterpret_cast<const uint4*>(vp + (long)drow * p.vt_rs + j0 + ch * 8);
+      const int kb = j0 + ch * 8;
+      if (kb + 8 > p.Nk) {  // chunk straddles / lies beyond Nk: zero the dead keys (P is 0 there; 0 * garbage must stay 0)
+        f16x8 e = *reinterpret_cast<f16x8*>(&v);
+#pragma unroll
+        for (int x = 0; x < 8; ++x)
+          if (kb + x >= p.Nk) e[x] = (f16)0.0f;
+        v = *reinterpret_cast<uint4*>(&e);
+      }
+      rv[i] = v;
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int id = tid + 256 * i;
+      const int key = id / KCH, ch = id % KCH;
+      const int row = (key & 32) | swap23(key & 31);
+      *reinterpret_cast<uint4*>(Ks + lds_swz<ROWB>(row, ch)) = rk[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int id = tid + 256 * i;
+      const int drow = id >> 3, ch = id & 7;
+      *reinterpret_cast<uint4*>(Vs + lds_swz<128>(drow, ch)) = rv[i];
+    }
+  };
+
+  if (ntiles > 0) load_tile(0);
+  for (int t = 0; t < ntiles; ++t) {
+    __syncthreads();  // everyone finished reading the previous tile
+    store_tile();
+    __syncthreads();
+    if (t + 1 < ntiles) load_tile(t + 1);
+
+    const int j0 = t * KT;
+    // ---- S^T = K . Q^T for the two 32-key sub-tiles --------------------------------------------------------------------
+    f32x16 s[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = 0.0f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<ROWB>(u * 32 + l31, ks * 2 + hi));
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+      }
+    }
+    // accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7)   (K rows were stored bit-2/3 swapped)
+    float mx = -1e30f;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
+        float v = s[u][r] * p.scale_log2;
+        const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
+        v = dead ? -INFINITY : v;
+        s[u][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.0f;
+    f16x8 pf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f(s[u][r] - m_new);
+        psum += pv;
+        pf[u][r >> 3][r & 7] = (f16)pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int sstep = 0; sstep < 2; ++sstep) {
+          f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(dt * 32 + l31, u * 4 + sstep * 2 + hi));
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][sstep], oacc[dt], 0, 0, 0);
+        }
+  }
+
+  // ---- finalize: O[q][d] = O^T[d][q] / l ----------------------------------------------------------------------------------
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+  if (qrow < p.Nq) {
+    f16* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_rs + (long)h * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (f16)(oacc[dt][4 * g + i] * inv);
+        *reinterpret_cast<f16x4*>(op + dt * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+}  // namespace
+
+int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
+  GN_REQUIRE(d && d->q && d->k && d->vt && d->o, "gn_attention_fwd: null pointer");
+  GN_REQUIRE(d->D == 64 || d->D == 32, "gn_attention_fwd: head dim %d unsupported (32 or 64)", d->D);
+  GN_REQUIRE(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0, "gn_attention_fwd: empty problem");
+  GN_REQUIRE(d->q_rs % 8 == 0 && d->k_rs % 8 == 0 && d->vt_rs % 8 == 0 && d->o_rs % 4 == 0, "gn_attention_fwd: row strides must be multiples of 8 (o: 4)");
+  GN_REQUIRE(d->vt_rs >= ((d->Nk + 63) / 64) * 64, "gn_attention_fwd: vt row stride %d must cover round_up(Nk=%d, 64)", d->vt_rs, d->Nk);
+  GN_REQUIRE(((uintptr_t)d->q & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->vt & 15) == 0 && ((uintptr_t)d->o & 7) == 0, "gn_attention_fwd: pointer alignment");
+  GN_REQUIRE(d->q_bs % 8 == 0 && d->k_bs % 8 == 0 && d->vt_bs % 8 == 0 && d->o_bs % 4 == 0, "gn_attention_fwd: batch strides alignment");
+  AttnParams p;
+  p.q = (const f16*)d->q; p.k = (const f16*)d->k; p.vt = (const f16*)d->vt; p.o = (f16*)d->o;
+  p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.vt_bs = d->vt_bs; p.o_bs = d->o_bs;
+  p.q_rs = d->q_rs; p.k_rs = d->k_rs; p.vt_rs = d->vt_rs; p.o_rs = d->o_rs;
+  p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.causal = d->causal;
+  p.scale_log2 = d->scale * 1.4426950408889634f;
+  dim3 grid((d->Nq + 127) / 128, d->heads, d->B);
+  if (d->D == 64)
+    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(256), 0, ctx->stream, p);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), 0, ctx->stream, p);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}

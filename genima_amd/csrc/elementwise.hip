@@ -1,0 +1,272 @@
+// Small HBM-bound kernels of the Genima hot path (SURVEY.md K9, K10, K14 + gathers): timestep embedding, scheduler
+// elementwise ops, image pre/post-processing, residual adds, CLIP embedding gather, row softmax (VAE attention), max-pool.
+// All f16 storage / f32 math, 16-byte accesses where the layout allows.
+#include "common.h"
+
+namespace {
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, f16* __restrict__ out, int B, int dim, int flip,
+                                          float freq_shift) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * dim) return;
+  const int b = idx / dim, j = idx - b * dim;
+  const int half = dim >> 1;
+  const int k = j < half ? j : j - half;
+  const float freq = expf(-9.210340371976184f * (float)k / ((float)half - freq_shift));  // ln(10000)
+  const float arg = t[b] * freq;
+  // diffusers: cat[sin, cos], then flip_sin_to_cos swaps the halves -> [cos, sin]
+  const bool is_sin = flip ? (j >= half) : (j < half);
+  out[idx] = (f16)(is_sin ? sinf(arg) : cosf(arg));
+}
+
+__global__ void scale_pad_kernel(const f16* __restrict__ x, f16* __restrict__ out, long pixels, int C, int Cpad, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pixels * Cpad) return;
+  const long p = idx / Cpad;
+  const int c = (int)(idx - p * Cpad);
+  out[idx] = c < C ? (f16)((float)x[p * C + c] * scale) : (f16)0.0f;
+}
+
+__global__ void euler_step_kernel(f16* __restrict__ x, const f16* __restrict__ eps, long pixels, int C, int ld, float sigma,
+                                  float sigma_next) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pixels * C) return;
+  const long p = idx / C;
+  const int c = (int)(idx - p * C);
+  // diffusers EulerDiscreteScheduler.step, epsilon prediction, gamma = 0, in f32 then cast back
+  const float xf = (float)x[idx];
+  const float e = (float)eps[p * ld + c];
+  // explicit round-to-nearest intrinsics: no FMA contraction, so the f32 op order matches the reference bit for bit
+  const float x0 = __fsub_rn(xf, __fmul_rn(sigma, e));
+  const float d = __fdiv_rn(__fsub_rn(xf, x0), sigma);
+  x[idx] = (f16)__fadd_rn(xf, __fmul_rn(d, __fsub_rn(sigma_next, sigma)));
+}
+
+__global__ void add_noise_kernel(const f16* __restrict__ x0, const f16* __restrict__ noise, const float* __restrict__ a,
+                                 const float* __restrict__ c, f16* __restrict__ out, long per_sample) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (i >= per_sample) return;
+  const long idx = (long)b * per_sample + i;
+  out[idx] = (f16)(a[b] * (float)x0[idx] + c[b] * (float)noise[idx]);
+}
+
+__global__ void image_u8_to_f16_kernel(const uint8_t* __restrict__ in, f16* __restrict__ out, long pixels, int Cpad, float mul,
+                                       float add) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  f16 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = (f16)0.0f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) v[c] = (f16)((float)in[p * 3 + c] / 255.0f * mul + add);
+  for (int c = 0; c < Cpad; ++c) out[p * Cpad + c] = v[c < 8 ? c : 7];
+}
+
+__global__ void image_f16_to_u8_kernel(const f16* __restrict__ in, uint8_t* __restrict__ out, long pixels, int ld) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    // the reference does (x / 2 + 0.5).clamp(0, 1) on the f16 tensor, then float -> *255 -> round (half to even)
+    f16 h = (f16)((float)in[p * ld + c] * 0.5f + 0.5f);
+    float f = fminf(fmaxf((float)h, 0.0f), 1.0f);
+    out[p * 3 + c] = (uint8_t)rintf(f * 255.0f);
+  }
+}
+
+__global__ void add_kernel(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ out, long n8) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 ra = a[i], rb = b[i];
+  const f16x8 va = *reinterpret_cast<const f16x8*>(&ra), vb = *reinterpret_cast<const f16x8*>(&rb);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)((float)va[e] + (float)vb[e]);
+  out[i] = *reinterpret_cast<uint4*>(&o);
+}
+
+__global__ void act_kernel(const uint4* __restrict__ a, uint4* __restrict__ out, long n8, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 ra = a[i];
+  const f16x8 va = *reinterpret_cast<const f16x8*>(&ra);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)apply_act((float)va[e], act);
+  out[i] = *reinterpret_cast<uint4*>(&o);
+}
+
+__global__ void embedding_kernel(const int32_t* __restrict__ ids, const f16* __restrict__ tok, const f16* __restrict__ pos,
+                                 f16* __restrict__ out, int B, int L, int D) {
+  const int DC = D >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * L * DC) return;
+  const long row = idx / DC;
+  const int c0 = (int)(idx - row * DC) * 8;
+  const int i = (int)(row % L);
+  const long id = ids[row];
+  const uint4 rt = *reinterpret_cast<const uint4*>(tok + id * D + c0);
+  const uint4 rp = *reinterpret_cast<const uint4*>(pos + (long)i * D + c0);
+  const f16x8 vt = *reinterpret_cast<const f16x8*>(&rt), vp = *reinterpret_cast<const f16x8*>(&rp);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)((float)vt[e] + (float)vp[e]);
+  *reinterpret_cast<uint4*>(out + row * D + c0) = *reinterpret_cast<uint4*>(&o);
+}
+
+constexpr int SM_MAXCH = 8;  // cols <= 4096
+__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ x, long rows, int cols, int ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  f16* xr = x + row * ld;
+  const int CC = cols >> 3;
+  float v[SM_MAXCH][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < SM_MAXCH; ++i) {
+    const int cx = lane + 64 * i;
+    if (cx < CC) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(xr + cx * 8);
+      const f16x8 h = *reinterpret_cast<const f16x8*>(&raw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = (float)h[e] * scale; mx = fmaxf(mx, v[i][e]); }
+    }
+  }
+  mx = wave_max(mx);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < SM_MAXCH; ++i) {
+    const int cx = lane + 64 * i;
+    if (cx < CC) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { v[i][e] = __expf(v[i][e] - mx); s += v[i][e]; }
+    }
+  }
+  const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+  for (int i = 0; i < SM_MAXCH; ++i) {
+    const int cx = lane + 64 * i;
+    if (cx < CC) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)(v[i][e] * inv);
+      *reinterpret_cast<uint4*>(xr + cx * 8) = *reinterpret_cast<uint4*>(&o);
+    }
+  }
+}
+
+__global__ void maxpool3x3s2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int B, int H, int W, int C, int Ho, int Wo) {
+  const int CC = C >> 3;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * Ho * Wo * CC) return;
+  const long pix = idx / CC;
+  const int c0 = (int)(idx - pix * CC) * 8;
+  const int ox = (int)(pix % Wo);
+  const int oy = (int)((pix / Wo) % Ho);
+  const int b = (int)(pix / ((long)Wo * Ho));
+  float m[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+  for (int dy = 0; dy < 3; ++dy)
+    for (int dx = 0; dx < 3; ++dx) {
+      const int iy = oy * 2 - 1 + dy, ix = ox * 2 - 1 + dx;
+      if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + (((long)b * H + iy) * W + ix) * C + c0);
+        const f16x8 v = *reinterpret_cast<const f16x8*>(&raw);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], (float)v[e]);
+      }
+    }
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)m[e];
+  *reinterpret_cast<uint4*>(y + pix * C + c0) = *reinterpret_cast<uint4*>(&o);
+}
+
+inline unsigned nblk(long n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+extern "C" {
+
+int32_t gn_timestep_embedding(gn_ctx* ctx, const float* t, void* out, int32_t B, int32_t dim, int32_t flip, float freq_shift) {
+  GN_REQUIRE(ctx && t && out && B > 0 && dim > 0 && dim % 2 == 0, "gn_timestep_embedding: bad arguments");
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3(nblk((long)B * dim)), dim3(256), 0, ctx->stream, t, (f16*)out, B, dim, flip, freq_shift);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_scale_pad(gn_ctx* ctx, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad, float scale) {
+  GN_REQUIRE(ctx && x && out && pixels > 0 && C > 0 && Cpad >= C, "gn_scale_pad: bad arguments");
+  hipLaunchKernelGGL(scale_pad_kernel, dim3(nblk(pixels * Cpad)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)out, (long)pixels, C, Cpad, scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_euler_step(gn_ctx* ctx, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps, float sigma, float sigma_next) {
+  GN_REQUIRE(ctx && x && eps && pixels > 0 && C > 0 && ld_eps >= C && sigma > 0.0f, "gn_euler_step: bad arguments");
+  hipLaunchKernelGGL(euler_step_kernel, dim3(nblk(pixels * C)), dim3(256), 0, ctx->stream, (f16*)x, (const f16*)eps, (long)pixels, C, ld_eps, sigma, sigma_next);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_add_noise(gn_ctx* ctx, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac, void* out, int32_t B, int64_t per_sample) {
+  GN_REQUIRE(ctx && x0 && noise && sqrt_ac && sqrt_1mac && out && B > 0 && per_sample > 0, "gn_add_noise: bad arguments");
+  hipLaunchKernelGGL(add_noise_kernel, dim3(nblk(per_sample), B), dim3(256), 0, ctx->stream, (const f16*)x0, (const f16*)noise, sqrt_ac, sqrt_1mac, (f16*)out, (long)per_sample);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_image_u8_to_f16(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float mul, float add) {
+  GN_REQUIRE(ctx && in && out && pixels > 0 && Cpad >= 3 && Cpad <= 8, "gn_image_u8_to_f16: bad arguments");
+  hipLaunchKernelGGL(image_u8_to_f16_kernel, dim3(nblk(pixels)), dim3(256), 0, ctx->stream, in, (f16*)out, (long)pixels, Cpad, mul, add);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_image_f16_to_u8(gn_ctx* ctx, const void* in, uint8_t* out, int64_t pixels, int32_t ld) {
+  GN_REQUIRE(ctx && in && out && pixels > 0 && ld >= 3, "gn_image_f16_to_u8: bad arguments");
+  hipLaunchKernelGGL(image_f16_to_u8_kernel, dim3(nblk(pixels)), dim3(256), 0, ctx->stream, (const f16*)in, out, (long)pixels, ld);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n) {
+  GN_REQUIRE(ctx && a && b && out && n > 0 && n % 8 == 0, "gn_add: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(add_kernel, dim3(nblk(n / 8)), dim3(256), 0, ctx->stream, (const uint4*)a, (const uint4*)b, (uint4*)out, (long)(n / 8));
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_act(gn_ctx* ctx, const void* x, void* out, int64_t n, int32_t act) {
+  GN_REQUIRE(ctx && x && out && n > 0 && n % 8 == 0, "gn_act: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(act_kernel, dim3(nblk(n / 8)), dim3(256), 0, ctx->stream, (const uint4*)x, (uint4*)out, (long)(n / 8), act);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_embedding(gn_ctx* ctx, const int32_t* ids, const void* tok, const void* pos, void* out, int32_t B, int32_t L, int32_t D) {
+  GN_REQUIRE(ctx && ids && tok && pos && out && B > 0 && L > 0 && D > 0 && D % 8 == 0, "gn_embedding: bad arguments");
+  hipLaunchKernelGGL(embedding_kernel, dim3(nblk((long)B * L * (D / 8))), dim3(256), 0, ctx->stream, ids, (const f16*)tok, (const f16*)pos, (f16*)out, B, L, D);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_softmax_rows(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale) {
+  GN_REQUIRE(ctx && x && rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_MAXCH && ld % 8 == 0 && ld >= cols, "gn_softmax_rows: cols must be a multiple of 8, <= %d", 64 * 8 * SM_MAXCH);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, ctx->stream, (f16*)x, (long)rows, cols, ld, scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_maxpool3x3s2(gn_ctx* ctx, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C) {
+  GN_REQUIRE(ctx && x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gn_maxpool3x3s2: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(nblk((long)B * Ho * Wo * (C / 8))), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)y, B, H, W, C, Ho, Wo);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,432 @@
+// MFMA implicit-GEMM convolution + Linear for gfx950 (CDNA4).
+//
+//   out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )
+//
+// One kernel family serves every Conv2d (3x3/1x1/7x7, stride 1/2, fused nearest-2x upsample, virtual channel concat)
+// and every Linear on the Genima hot path:
+//   * activations are NHWC f16, so a conv's A operand is an on-the-fly gather of 16-byte channel chunks
+//     (tap-major K = KH*KW*Cin) and a Linear's A operand is the same loader with a dense row stride;
+//   * weights are [N][K] f16 (K contiguous) for both;
+//   * BMxBNx64 block tile, 4 waves, v_mfma_f32_32x32x16_f16 with f32 accumulation;
+//   * global -> registers -> LDS staging, double-buffered, next tile's loads in flight under the current tile's MFMAs
+//     (one barrier per K tile); LDS rows are 128 B with the XOR swizzle of common.h (conflict-free ds_read_b128);
+//   * operands are swapped (D = W_tile * A_tile^T) so each lane ends up with 4 consecutive output channels of one output
+//     row: 8-byte bias / residual loads and 8-byte stores in the epilogue;
+//   * epilogue fuses bias, per-batch time-embedding shift, SiLU/GELU/QuickGELU/ReLU/GEGLU, scale and residual add;
+//   * optional split-K over gridDim.y with an f32 workspace and a fused reduce+epilogue kernel (small-M layers);
+//   * blockIdx -> tile mapping is XCD-aware (each XCD walks a contiguous run of tiles, N fastest, so the A rows an XCD's L2
+//     holds are reused across the N tiles).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;          // K tile (f16 elements) = 128-byte LDS rows
+constexpr int NTHREADS = 256;   // 4 waves
+
+struct GemmParams {
+  const f16* a;
+  const f16* a2;
+  const f16* w;
+  const f16* bias;
+  const f16* shift;
+  const f16* res;
+  f16* out;
+  float* ws;
+  int M, N, K;
+  long lda, ldw, ldr, ldo, ldshift;
+  int H, W, C1, C2, KH, KW, stride, pad_t, pad_l, Ho, Wo, ups;
+  int act, out_mode, rpb;
+  float out_scale;
+  int splitk, kper;
+  int tiles_m, tiles_n;
+};
+
+// ---- epilogue for 4 consecutive output channels [nb, nb+4) of row m -------------------------------------------------
+__device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int nb, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  if (p.bias) {
+    f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + nb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)b[i];
+  }
+  int bidx = 0;
+  if (p.shift || p.out_mode == GN_OUT_BATCH_TRANSPOSED) bidx = m / p.rpb;
+  if (p.shift) {
+    f16x4 s = *reinterpret_cast<const f16x4*>(p.shift + (long)bidx * p.ldshift + nb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)s[i];
+  }
+  if (p.act != GN_ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act);
+  }
+  if (p.out_scale != 1.0f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= p.out_scale;
+  }
+  if (p.res) {
+    f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (long)m * p.ldr + nb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
+  }
+  if (p.out_mode == GN_OUT_BATCH_TRANSPOSED) {
+    const int ml = m - bidx * p.rpb;
+    f16* o = p.out + ((long)bidx * p.N + nb) * p.ldo + ml;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[(long)i * p.ldo] = (f16)v[i];
+  } else {
+    f16x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o[i] = (f16)v[i];
+    *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + nb) = o;
+  }
+}
+
+// GEGLU: hidden block hb (4 consecutive packed rows) and the matching gate block -> 4 output columns at oc.
+__device__ __forceinline__ void epilogue_geglu4(const GemmParams& p, int m, int nh, int ng, int oc, const float* h,
+                                                const float* g) {
+  float hv[4], gv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { hv[i] = h[i]; gv[i] = g[i]; }
+  if (p.bias) {
+    f16x4 bh = *reinterpret_cast<const f16x4*>(p.bias + nh);
+    f16x4 bg = *reinterpret_cast<const f16x4*>(p.bias + ng);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { hv[i] += (float)bh[i]; gv[i] += (float)bg[i]; }
+  }
+  f16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (f16)(hv[i] * act_gelu(gv[i]));
+  *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + oc) = o;
+}
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile >= 32x32");
+  constexpr int RA = BM / 32, RB = BN / 32;  // 16-byte chunks per thread per tile
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  // XCD-aware, bijective block -> tile remap (block b runs on XCD b % 8; give each XCD a contiguous run of tiles)
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.kper;
+  const int kend = min(p.K, kbeg + p.kper);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // ---- loader state -------------------------------------------------------------------------------------------------
+  const int chunk = tid & 7;
+  const int row0 = tid >> 3;  // 0..31
+  int kcur = kbeg + chunk * 8;
+
+  // conv gather state
+  const int Cin = p.C1 + p.C2;
+  int iy0[RA], ix0[RA];
+  long boff[RA];
+  int cc = 0, dy = 0, dx = 0;
+  const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
+  if constexpr (CONV) {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + row0 + 32 * i;
+      if (m < p.M) {
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        iy0[i] = oy * p.stride - p.pad_t;
+        ix0[i] = ox * p.stride - p.pad_l;
+        boff[i] = (long)b * p.H * p.W;
+      } else {
+        iy0[i] = -(1 << 28);
+        ix0[i] = -(1 << 28);
+        boff[i] = 0;
+      }
+    }
+    const int tap = kcur / Cin;
+    cc = kcur - tap * Cin;
+    dy = tap / p.KW;
+    dx = tap - dy * p.KW;
+  }
+
+  uint4 ra[RA], rb[RB];
+
+  auto load_tile = [&]() {
+    const bool kok = kcur < kend;
+    if constexpr (CONV) {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+        const bool ok = kok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (ok) {
+          const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+          const long pix = boff[i] + (long)sy * p.W + sx;
+          const f16* src = (cc < p.C1) ? (p.a + pix * p.C1 + cc) : (p.a2 + pix * p.C2 + (cc - p.C1));
+          v = *reinterpret_cast<const uint4*>(src);
+        }
+        ra[i] = v;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (kok && m < p.M) v = *reinterpret_cast<const uint4*>(p.a + (long)m * p.lda + kcur);
+        ra[i] = v;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      const int n = n0 + row0 + 32 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (kok && n < p.N) v = *reinterpret_cast<const uint4*>(p.w + (long)n * p.ldw + kcur);
+      rb[i] = v;
+    }
+    // advance to the next K tile
+    kcur += BK;
+    if constexpr (CONV) {
+      cc += BK;
+      while (cc >= Cin) {
+        cc -= Cin;
+        if (++dx == p.KW) { dx = 0; ++dy; }
+      }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+    unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(As + lds_swz<128>(row0 + 32 * i, chunk)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(Bs + lds_swz<128>(row0 + 32 * i, chunk)) = rb[i];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  load_tile();
+  store_tile(0);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const bool more = (kt + 1 < nk);
+    if (more) load_tile();
+    const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      f16x8 fa[TM], fw[TN];
+      const int c = kk * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f16x8*>(As + lds_swz<128>(wm * WTM + i * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fw[j] = *reinterpret_cast<const f16x8*>(Bs + lds_swz<128>(wn * WTN + j * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane holds D[n = 8g + 4hi + (r&3)][m = lane&31] per 32x32 tile ----------------------------------------
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + l31;
+    if (m >= p.M) continue;
+    if (p.splitk > 1) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N) {
+            f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(p.ws + ((long)z * p.M + m) * p.N + nb) = v;
+          }
+        }
+    } else if (p.act == GN_ACT_GEGLU) {
+      if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; j += 2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nh = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+            if (nh + 32 < p.N) {
+              const int oc = ((n0 + wn * WTN + j * 32) >> 1) + 8 * g + 4 * hi;
+              float h[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+              float gg[4] = {acc[j + 1][i][4 * g], acc[j + 1][i][4 * g + 1], acc[j + 1][i][4 * g + 2],
+                             acc[j + 1][i][4 * g + 3]};
+              epilogue_geglu4(p, m, nh, nh + 32, oc, h, gg);
+            }
+          }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N)
+            epilogue_store4(p, m, nb, acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+        }
+    }
+  }
+}
+
+// split-K: sum the f32 partial slabs in a fixed order and apply the fused epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
+  const long n4 = p.N >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)p.M * n4) return;
+  const int m = (int)(idx / n4);
+  const int nb = (int)(idx - (long)m * n4) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int z = 0; z < p.splitk; ++z) s += *reinterpret_cast<const f32x4*>(p.ws + ((long)z * p.M + m) * p.N + nb);
+  epilogue_store4(p, m, nb, s[0], s[1], s[2], s[3]);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
+  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, 1);
+  if (conv)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(NTHREADS), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(NTHREADS), 0, st, p);
+}
+
+struct Plan {
+  int bm, bn, splitk, kper;
+};
+
+// Tile / split-K heuristic: the largest tile that still gives >= ~1 block per CU without much padded-N waste; split K when
+// the grid would leave most of the 256 CUs idle (8x8 / 16x16 latent levels, batch-1 inference).
+Plan plan_gemm(const gn_gemm_desc* d) {
+  const int64_t M = d->M, N = d->N, K = d->K;
+  Plan pl;
+  if (d->act == GN_ACT_GEGLU) {
+    pl.bm = 128; pl.bn = 128;
+  } else {
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    int best = 2;
+    for (int c = 0; c < 3; ++c) {
+      const int64_t tm = cdiv64(M, cand[c][0]), tn = cdiv64(N, cand[c][1]);
+      const double waste = (double)(tm * cand[c][0] * tn * cand[c][1]) / (double)(M * N);
+      if (tm * tn >= 256 && waste <= 1.13) { best = c; break; }
+    }
+    pl.bm = cand[best][0]; pl.bn = cand[best][1];
+  }
+  const int64_t blocks = cdiv64(M, pl.bm) * cdiv64(N, pl.bn);
+  int sk = d->splitk;
+  if (sk <= 0) {
+    sk = 1;
+    if (d->act != GN_ACT_GEGLU && d->out_mode == GN_OUT_ROWMAJOR && blocks < 192 && K >= 1024) {
+      sk = (int)cdiv64(384, blocks);
+      const int maxsk = (int)(K / 512);
+      if (sk > maxsk) sk = maxsk;
+      if (sk > 16) sk = 16;
+      if (sk < 1) sk = 1;
+    }
+  }
+  if (d->act == GN_ACT_GEGLU || d->out_mode != GN_OUT_ROWMAJOR) sk = 1;
+  int kper = (int)(cdiv64(cdiv64(K, sk), BK) * BK);
+  sk = (int)cdiv64(K, kper);
+  pl.splitk = sk;
+  pl.kper = kper;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d) {
+  if (!d) return 0;
+  Plan pl = plan_gemm(d);
+  if (pl.splitk <= 1) return 0;
+  return (int64_t)pl.splitk * d->M * d->N * (int64_t)sizeof(float);
+}
+
+int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
+  GN_REQUIRE(d && d->a && d->w && d->out, "gn_gemm: null a/w/out");
+  GN_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "gn_gemm: empty problem M=%ld N=%ld K=%ld", (long)d->M, (long)d->N, (long)d->K);
+  GN_REQUIRE(d->K % 8 == 0 && d->ldw % 8 == 0, "gn_gemm: K (%ld) and ldw (%ld) must be multiples of 8", (long)d->K, (long)d->ldw);
+  GN_REQUIRE(d->N % 4 == 0, "gn_gemm: N (%ld) must be a multiple of 4 (pad the weight rows)", (long)d->N);
+  GN_REQUIRE(d->M < (1ll << 31) && d->N < (1 << 24) && d->K < (1 << 24), "gn_gemm: problem too large");
+  GN_REQUIRE(((uintptr_t)d->a & 15) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->out & 7) == 0,
+             "gn_gemm: a/w must be 16-byte aligned, out 8-byte aligned");
+  const bool geglu = d->act == GN_ACT_GEGLU;
+  if (geglu) {
+    GN_REQUIRE(d->N % 64 == 0 && !d->shift && !d->residual && d->out_mode == GN_OUT_ROWMAJOR,
+               "gn_gemm: GEGLU needs N %% 64 == 0 and no shift/residual/transposed output");
+  }
+  GemmParams p;
+  p.a = (const f16*)d->a; p.a2 = (const f16*)d->a2; p.w = (const f16*)d->w;
+  p.bias = (const f16*)d->bias; p.shift = (const f16*)d->shift; p.res = (const f16*)d->residual;
+  p.out = (f16*)d->out; p.ws = (float*)d->workspace;
+  p.M = (int)d->M; p.N = (int)d->N; p.K = (int)d->K;
+  p.lda = d->lda; p.ldw = d->ldw; p.ldr = d->ldr; p.ldo = d->ldo;
+  p.ldshift = d->ldshift > 0 ? d->ldshift : d->N;
+  p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride;
+  p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Ho = d->Ho; p.Wo = d->Wo; p.ups = d->upsample2x;
+  p.act = d->act; p.out_mode = d->out_mode;
+  p.rpb = d->rows_per_batch > 0 ? d->rows_per_batch : (int)d->M;
+  p.out_scale = d->out_scale;
+  if (d->conv) {
+    GN_REQUIRE(d->C1 % 8 == 0 && d->C2 % 8 == 0 && d->C1 > 0, "gn_gemm(conv): C1/C2 (%d/%d) must be multiples of 8", d->C1, d->C2);
+    GN_REQUIRE((d->C2 == 0) == (d->a2 == nullptr), "gn_gemm(conv): a2 and C2 must be given together");
+    GN_REQUIRE(d->K == (int64_t)d->KH * d->KW * (d->C1 + d->C2), "gn_gemm(conv): K != KH*KW*(C1+C2)");
+    GN_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "gn_gemm(conv): M != B*Ho*Wo");
+    GN_REQUIRE(d->stride >= 1 && d->KH >= 1 && d->KW >= 1 && d->H > 0 && d->W > 0, "gn_gemm(conv): bad geometry");
+  } else {
+    GN_REQUIRE(d->lda % 8 == 0 && d->lda >= d->K, "gn_gemm: lda (%ld) must be a multiple of 8 and >= K", (long)d->lda);
+  }
+  if (d->residual) GN_REQUIRE(d->ldr % 4 == 0 && ((uintptr_t)d->residual & 7) == 0, "gn_gemm: residual stride/alignment");
+  if (d->out_mode == GN_OUT_ROWMAJOR) GN_REQUIRE(d->ldo % 4 == 0, "gn_gemm: ldo (%ld) must be a multiple of 4", (long)d->ldo);
+  if (d->out_mode == GN_OUT_BATCH_TRANSPOSED) GN_REQUIRE(d->rows_per_batch > 0 && d->M % d->rows_per_batch == 0, "gn_gemm: transposed output needs rows_per_batch | M");
+  if (d->shift) GN_REQUIRE(d->rows_per_batch > 0 && p.ldshift % 4 == 0 && ((uintptr_t)d->shift & 7) == 0, "gn_gemm: shift needs rows_per_batch and 8-byte aligned rows");
+
+  Plan pl = plan_gemm(d);
+  p.splitk = pl.splitk; p.kper = pl.kper;
+  p.tiles_m = (int)cdiv64(d->M, pl.bm); p.tiles_n = (int)cdiv64(d->N, pl.bn);
+  if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
+
+  const bool conv = d->conv != 0;
+  if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 2>(p, conv, ctx->stream);
+  else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2, 2>(p, conv, ctx->stream);
+  else launch_cfg<64, 64, 2, 2>(p, conv, ctx->stream);
+  GN_LAUNCH_CHECK();
+  if (pl.splitk > 1) {
+    const long total = (long)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, p);
+    GN_LAUNCH_CHECK();
+  }
+  return GN_OK;
+}

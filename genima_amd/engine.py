@@ -1,0 +1,354 @@
+"""Engine: the host-side launcher over the C ABI (include/genima_hip.h).
+
+PyTorch-ROCm is used for device memory, streams and interop only: every op takes torch CUDA tensors, passes their
+``data_ptr()`` + shapes to libgenima_hip.so and never touches a torch compute kernel.  Two modes:
+
+  * eager  (``Engine(device)``):   each call enqueues the kernel immediately on the current stream (kernel parity tests);
+  * record (``Engine(device, record=True)``): ops are appended to a ``gn_program`` with all buffers pre-allocated and
+    name-keyed (so the unrolled denoise steps reuse one set of activation buffers); ``run()`` replays the whole program from
+    C++ without returning to Python, ``capture()`` + ``launch()`` replay it as one hipGraph.
+
+Layout conventions: activations NHWC f16 ``[B, H, W, C]`` == token-major ``[B, H*W, C]``; conv weights packed
+``[Cout, KH*KW*Cin]`` (packing.py); Linear weights ``[out, in]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR,
+                   AttnDesc, GemmDesc, GenimaHipError, GroupNormDesc, check)
+
+F16 = torch.float16
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+class Engine:
+    def __init__(self, device="cuda:0", record: bool = False):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise GenimaHipError("the Genima HIP engine needs a ROCm device (torch device 'cuda:N'); there is no CPU path")
+        if not torch.cuda.is_available():
+            raise GenimaHipError("no ROCm device visible to torch; the Genima HIP path has no CPU fallback")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.stream = torch.cuda.current_stream(self.device)
+        self._ctx = C.c_void_p()
+        check(self.lib.gn_ctx_create(idx, C.c_void_p(self.stream.cuda_stream), C.byref(self._ctx)), "gn_ctx_create")
+        self.record = record
+        self._prog = C.c_void_p()
+        if record:
+            check(self.lib.gn_program_create(self._ctx, C.byref(self._prog)), "gn_program_create")
+        self.buffers: Dict[str, torch.Tensor] = {}
+        self._keep = []  # tensors referenced by recorded ops
+        self._scope = []
+        self.captured = False
+
+    # ------------------------------------------------------------------------------------------------ housekeeping
+    def __del__(self):
+        try:
+            if self._prog:
+                self.lib.gn_program_destroy(self._prog)
+            if self._ctx:
+                self.lib.gn_ctx_destroy(self._ctx)
+        except Exception:
+            pass
+
+    def use_stream(self, stream: torch.cuda.Stream):
+        self.stream = stream
+        check(self.lib.gn_ctx_set_stream(self._ctx, C.c_void_p(stream.cuda_stream)), "gn_ctx_set_stream")
+
+    class _Scope:
+        def __init__(self, eng, name):
+            self.eng, self.name = eng, name
+
+        def __enter__(self):
+            self.eng._scope.append(self.name)
+
+        def __exit__(self, *a):
+            self.eng._scope.pop()
+
+    def scope(self, name: str):
+        return Engine._Scope(self, name)
+
+    def buf(self, name: Optional[str], shape, dtype=F16, zero: bool = False) -> torch.Tensor:
+        """Output buffer.  Eager: a fresh tensor.  Record: a persistent tensor keyed by the scoped name."""
+        shape = tuple(int(s) for s in shape)
+        if not self.record or name is None:
+            return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+        key = "/".join(self._scope + [name])
+        t = self.buffers.get(key)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.buffers[key] = t
+        return t
+
+    def _keepalive(self, *ts):
+        if self.record:
+            self._keep.extend(t for t in ts if t is not None)
+
+    @property
+    def num_ops(self) -> int:
+        return int(self.lib.gn_program_num_ops(self._prog)) if self.record else 0
+
+    def run(self, first: int = 0, last: int = -1):
+        check(self.lib.gn_program_run(self._prog, first, last), "gn_program_run")
+
+    def capture(self):
+        check(self.lib.gn_program_capture(self._prog), "gn_program_capture")
+        self.captured = True
+
+    def launch(self):
+        check(self.lib.gn_program_launch(self._prog), "gn_program_launch")
+
+    def synchronize(self):
+        check(self.lib.gn_stream_synchronize(self._ctx), "gn_stream_synchronize")
+
+    # ------------------------------------------------------------------------------------------------ events
+    def event(self):
+        ev = C.c_void_p()
+        check(self.lib.gn_event_create(C.byref(ev)), "gn_event_create")
+        return ev
+
+    def event_record(self, ev):
+        check(self.lib.gn_event_record(self._ctx, ev), "gn_event_record")
+
+    def event_elapsed_ms(self, a, b) -> float:
+        ms = C.c_float()
+        check(self.lib.gn_event_elapsed_ms(a, b, C.byref(ms)), "gn_event_elapsed_ms")
+        return float(ms.value)
+
+    # ------------------------------------------------------------------------------------------------ GEMM family
+    def _gemm(self, d: GemmDesc, keep):
+        ws_bytes = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
+        ws = None
+        if ws_bytes > 0:
+            ws = self._workspace(ws_bytes)
+            d.workspace = ws.data_ptr()
+        if self.record:
+            check(self.lib.gn_program_add_gemm(self._prog, C.byref(d)), "gn_program_add_gemm")
+            self._keepalive(*keep, ws)
+        else:
+            check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm")
+
+    def _workspace(self, nbytes: int) -> torch.Tensor:
+        """f32 split-K / GroupNorm scratch: one shared grow-only buffer (ops on one stream run in order)."""
+        n = _round_up(nbytes, 256) // 4
+        cur = self.buffers.get("__workspace__")
+        if cur is None or cur.numel() < n:
+            if self.record and cur is not None:
+                self._keep.append(cur)  # earlier recorded ops still point at the old buffer
+            cur = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
+            self.buffers["__workspace__"] = cur
+        return cur
+
+    def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
+               transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0) -> torch.Tensor:
+        """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
+        transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel)."""
+        K = x.shape[-1]
+        M = x.numel() // K
+        N = w.shape[0]
+        assert w.shape[1] == K, (w.shape, x.shape)
+        n_out = N // 2 if act == ACT_GEGLU else N
+        d = GemmDesc()
+        if transposed_out:
+            assert rows_per_batch > 0 and M % rows_per_batch == 0
+            nb = M // rows_per_batch
+            ld = pad_cols if pad_cols else _round_up(rows_per_batch, 64)
+            if out is None:
+                out = self.buf(name, (nb, N, ld), zero=True)
+            d.out_mode, d.ldo, d.rows_per_batch = OUT_BATCH_TRANSPOSED, ld, rows_per_batch
+        else:
+            if out is None:
+                out = self.buf(name, tuple(x.shape[:-1]) + (n_out,))
+            d.out_mode, d.ldo = OUT_ROWMAJOR, out.stride(-2) if out.dim() > 1 else n_out
+        d.a, d.w, d.bias, d.residual, d.out = _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out)
+        d.M, d.N, d.K = M, N, K
+        d.lda, d.ldw = x.stride(-2) if x.dim() > 1 else K, w.stride(0)
+        d.ldr = residual.stride(-2) if residual is not None else 0
+        d.act, d.splitk, d.out_scale = act, splitk, 1.0
+        self._gemm(d, (x, w, bias, residual, out))
+        return out
+
+    def conv2d(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ksize: int = 3,
+               stride: int = 1, pad: Tuple[int, int, int, int] = None, x2: Optional[torch.Tensor] = None,
+               shift: Optional[torch.Tensor] = None, ldshift: int = 0, residual: Optional[torch.Tensor] = None,
+               act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
+               name: Optional[str] = None, splitk: int = 0) -> torch.Tensor:
+        """NHWC conv.  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
+        pad = (top, left, bottom, right); default k//2 all round.  shift: [B, ldshift or Cout] per-batch channel shift."""
+        B, H, W, C1 = x.shape
+        C2 = x2.shape[-1] if x2 is not None else 0
+        N = w.shape[0]
+        k = ksize
+        if pad is None:
+            pad = (k // 2,) * 4
+        Hin, Win = (2 * H, 2 * W) if upsample2x else (H, W)
+        Ho = (Hin + pad[0] + pad[2] - k) // stride + 1
+        Wo = (Win + pad[1] + pad[3] - k) // stride + 1
+        if out is None:
+            out = self.buf(name, (B, Ho, Wo, N))
+        d = GemmDesc()
+        d.a, d.a2, d.w, d.bias, d.shift, d.residual, d.out = (_ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(shift),
+                                                              _ptr(residual), _ptr(out))
+        d.M, d.N, d.K = B * Ho * Wo, N, k * k * (C1 + C2)
+        assert w.shape[1] == d.K, (tuple(w.shape), d.K)
+        d.ldw, d.ldo, d.ldshift = w.stride(0), out.stride(-2), ldshift
+        d.ldr = residual.stride(-2) if residual is not None else 0
+        d.conv, d.B, d.H, d.W, d.C1, d.C2 = 1, B, H, W, C1, C2
+        d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = k, k, stride, pad[0], pad[1], Ho, Wo
+        d.upsample2x, d.act, d.out_mode, d.rows_per_batch, d.splitk, d.out_scale = (int(upsample2x), act, OUT_ROWMAJOR,
+                                                                                     Ho * Wo, splitk, out_scale)
+        self._gemm(d, (x, x2, w, bias, shift, residual, out))
+        return out
+
+    # ------------------------------------------------------------------------------------------------ attention
+    def attention(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, Nk: Optional[int] = None,
+                  causal: bool = False, out: Optional[torch.Tensor] = None, name: Optional[str] = None) -> torch.Tensor:
+        """q: [B, Nq, heads*D] view (last dim contiguous, may be a column slice), k: [B, Nk, heads*D] view,
+        vt: [B, heads*D, Nk_pad] (V transposed).  Returns o [B, Nq, heads*D]."""
+        B, Nq, Cq = q.shape
+        D = Cq // heads
+        Nk = k.shape[1] if Nk is None else Nk
+        if out is None:
+            out = self.buf(name, (B, Nq, Cq))
+        d = AttnDesc()
+        d.q, d.k, d.vt, d.o = _ptr(q), _ptr(k), _ptr(vt), _ptr(out)
+        d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q.stride(0), k.stride(0), vt.stride(0), out.stride(0)
+        d.q_rs, d.k_rs, d.vt_rs, d.o_rs = q.stride(1), k.stride(1), vt.stride(1), out.stride(1)
+        d.B, d.heads, d.Nq, d.Nk, d.D, d.causal, d.scale = B, heads, Nq, Nk, D, int(causal), float(D) ** -0.5
+        if self.record:
+            check(self.lib.gn_program_add_attention(self._prog, C.byref(d)), "gn_program_add_attention")
+            self._keepalive(q, k, vt, out)
+        else:
+            check(self.lib.gn_attention_fwd(self._ctx, C.byref(d)), "gn_attention_fwd")
+        return out
+
+    # ------------------------------------------------------------------------------------------------ norms
+    def groupnorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
+                  act: int = ACT_NONE, x2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  name: Optional[str] = None) -> torch.Tensor:
+        """x: [B, H, W, C1] or [B, HW, C1] (x2 optional concat source).  Returns act(GN(cat)) [.., C1+C2]."""
+        B, C1 = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * C1)
+        C2 = x2.shape[-1] if x2 is not None else 0
+        if out is None:
+            out = self.buf(name, tuple(x.shape[:-1]) + (C1 + C2,))
+        d = GroupNormDesc()
+        d.x, d.x2, d.gamma, d.beta, d.y = _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out)
+        d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, C1, C2, groups, act, eps
+        ws = self._workspace(int(self.lib.gn_groupnorm_workspace_bytes(C.byref(d))))
+        d.workspace = ws.data_ptr()
+        if self.record:
+            check(self.lib.gn_program_add_groupnorm(self._prog, C.byref(d)), "gn_program_add_groupnorm")
+            self._keepalive(x, x2, gamma, beta, out, ws)
+        else:
+            check(self.lib.gn_groupnorm_fwd(self._ctx, C.byref(d)), "gn_groupnorm_fwd")
+        return out
+
+    def layernorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, *,
+                  out: Optional[torch.Tensor] = None, name: Optional[str] = None) -> torch.Tensor:
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        if out is None:
+            out = self.buf(name, x.shape)
+        args = (_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), M, Cc, eps)
+        if self.record:
+            check(self.lib.gn_program_add_layernorm(self._prog, *args), "gn_program_add_layernorm")
+            self._keepalive(x, gamma, beta, out)
+        else:
+            check(self.lib.gn_layernorm_fwd(self._ctx, *args), "gn_layernorm_fwd")
+        return out
+
+    # ------------------------------------------------------------------------------------------------ small ops
+    def _small(self, fn_name: str, keep, *args):
+        if self.record:
+            check(getattr(self.lib, "gn_program_add_" + fn_name)(self._prog, *args), "gn_program_add_" + fn_name)
+            self._keepalive(*keep)
+        else:
+            check(getattr(self.lib, "gn_" + fn_name)(self._ctx, *args), "gn_" + fn_name)
+
+    def timestep_embedding(self, t: torch.Tensor, dim: int, flip_sin_to_cos=True, freq_shift=0.0, *, name=None):
+        """t: f32 [B] device tensor -> f16 [B, dim]."""
+        out = self.buf(name, (t.numel(), dim))
+        self._small("timestep_embedding", (t, out), _ptr(t), _ptr(out), t.numel(), dim, int(flip_sin_to_cos), float(freq_shift))
+        return out
+
+    def scale_pad(self, x: torch.Tensor, scale: float, cpad: int, *, out=None, name=None):
+        """x: [..., C] -> [..., cpad] = x*scale zero-padded on channels."""
+        Cc = x.shape[-1]
+        if out is None:
+            out = self.buf(name, tuple(x.shape[:-1]) + (cpad,))
+        self._small("scale_pad", (x, out), _ptr(x), _ptr(out), x.numel() // Cc, Cc, cpad, float(scale))
+        return out
+
+    def euler_step(self, x: torch.Tensor, eps: torch.Tensor, sigma: float, sigma_next: float):
+        """In place: x[..., C] <- x + eps[..., :C] * (sigma_next - sigma)."""
+        Cc = x.shape[-1]
+        self._small("euler_step", (x, eps), _ptr(x), _ptr(eps), x.numel() // Cc, Cc, eps.stride(-2), float(sigma), float(sigma_next))
+        return x
+
+    def add_noise(self, x0, noise, sqrt_ac, sqrt_1mac, *, name=None):
+        out = self.buf(name, x0.shape)
+        B = x0.shape[0]
+        check(self.lib.gn_add_noise(self._ctx, _ptr(x0), _ptr(noise), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), B, x0.numel() // B), "gn_add_noise")
+        return out
+
+    def image_u8_to_f16(self, img: torch.Tensor, cpad: int = 8, mul: float = 1.0, add: float = 0.0, *, out=None, name=None):
+        """uint8 [B, H, W, 3] -> f16 [B, H, W, cpad] = v/255*mul + add (channels >= 3 zero)."""
+        if out is None:
+            out = self.buf(name, tuple(img.shape[:-1]) + (cpad,))
+        self._small("image_u8_to_f16", (img, out), _ptr(img), _ptr(out), img.numel() // 3, cpad, float(mul), float(add))
+        return out
+
+    def image_f16_to_u8(self, x: torch.Tensor, *, out=None, name=None):
+        """f16 [B, H, W, ld>=3] -> uint8 [B, H, W, 3] (VaeImageProcessor.postprocess numerics)."""
+        if out is None:
+            out = self.buf(name, tuple(x.shape[:-1]) + (3,), dtype=torch.uint8)
+        self._small("image_f16_to_u8", (x, out), _ptr(x), _ptr(out), x.numel() // x.shape[-1], x.stride(-2))
+        return out
+
+    def add(self, a: torch.Tensor, b: torch.Tensor, *, out=None, name=None):
+        if out is None:
+            out = self.buf(name, a.shape)
+        self._small("add", (a, b, out), _ptr(a), _ptr(b), _ptr(out), a.numel())
+        return out
+
+    def act(self, x: torch.Tensor, act: int, *, out=None, name=None):
+        if out is None:
+            out = self.buf(name, x.shape)
+        self._small("act", (x, out), _ptr(x), _ptr(out), x.numel(), act)
+        return out
+
+    def embedding(self, ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor, *, name=None):
+        """ids int32 [B, L] -> tok[ids] + pos[:L]  f16 [B, L, D]."""
+        B, L = ids.shape
+        D = tok.shape[1]
+        out = self.buf(name, (B, L, D))
+        self._small("embedding", (ids, tok, pos, out), _ptr(ids), _ptr(tok), _ptr(pos), _ptr(out), B, L, D)
+        return out
+
+    def softmax_rows(self, x: torch.Tensor, scale: float = 1.0):
+        """In-place softmax(scale * x) over the last dim of a 2-D-viewable f16 tensor."""
+        cols = x.shape[-1]
+        self._small("softmax_rows", (x,), _ptr(x), x.numel() // cols, cols, x.stride(-2), float(scale))
+        return x
+
+    def maxpool3x3s2(self, x: torch.Tensor, *, name=None):
+        B, H, W, Cc = x.shape
+        out = self.buf(name, (B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, Cc))
+        self._small("maxpool3x3s2", (x, out), _ptr(x), _ptr(out), B, H, W, Cc)
+        return out

@@ -1,0 +1,272 @@
+"""Lowering of the Genima networks to libgenima_hip.so ops (through an ``Engine``), NHWC throughout.
+
+Each ``emit_*`` function walks one architecture exactly as the reference's third-party modules execute it
+(oracle/sd_torch.py is the CPU restatement with the same structure) and enqueues / records the
+fused kernels:
+  ResnetBlock2D      = GN+SiLU | conv3x3 (+bias +time shift) | GN+SiLU | conv3x3 (+bias +shortcut residual)   [4-5 launches]
+  Transformer2DModel = GN | proj_in | LN | qk-proj | v-proj(transposed) | flash-attn | out-proj(+res) | LN | q-proj |
+                       flash-attn(ctx K/V hoisted) | out-proj(+res) | LN | GEGLU-proj | ff-out(+res) | proj_out(+res)
+  up-block concat    = virtual (two-source A operand / two-source GroupNorm), never materialised
+  nearest-2x + conv  = one conv with the upsample folded into the gather
+W is a ``packing.pack_state_dict`` result (device f16).  Names follow the diffusers checkpoint keys.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from ._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU
+from .engine import Engine
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+def _heads(cfg, i):
+    ahd = cfg["attention_head_dim"]
+    return ahd[i] if isinstance(ahd, (list, tuple)) else ahd
+
+
+# ------------------------------------------------------------------------------------------------ time embedding
+def emit_time_shifts(E: Engine, W, cfg, t_dev: torch.Tensor) -> torch.Tensor:
+    """t_dev f32 [B] -> all ResNet time shifts [B, temb_total] (one GEMM for every ``time_emb_proj``)."""
+    c0 = cfg["block_out_channels"][0]
+    e = E.timestep_embedding(t_dev, c0, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0), name="t_sin")
+    e = E.linear(e, W["time_embedding.linear_1.weight"], W["time_embedding.linear_1.bias"], act=ACT_SILU, name="t_l1")
+    # linear_2, then the SiLU every ResnetBlock2D applies to temb before its time_emb_proj
+    e = E.linear(e, W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"], act=ACT_SILU, name="t_l2")
+    return E.linear(e, W["time_emb_proj_all.weight"], W["time_emb_proj_all.bias"], name="t_shifts")
+
+
+def _shift_for(W, shifts: Optional[torch.Tensor], prefix: str):
+    if shifts is None:
+        return None, 0
+    off, n = W["__meta__"]["temb_slices"][prefix]
+    return shifts[:, off:off + n], shifts.shape[1]
+
+
+# ------------------------------------------------------------------------------------------------ blocks
+def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float):
+    with E.scope(p):
+        h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps, act=ACT_SILU, x2=x2, name="n1")
+        sh, ld = _shift_for(W, shifts, p) if (p + ".time_emb_proj.weight") in W else (None, 0)
+        h = E.conv2d(h, W[p + ".conv1.weight"], W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
+        h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
+        if (p + ".conv_shortcut.weight") in W:
+            sc = E.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"], ksize=1, x2=x2, name="sc")
+        else:
+            assert x2 is None
+            sc = x
+        return E.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], residual=sc, name="c2")
+
+
+def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
+    """K / V^T projections of the (constant) prompt states for every cross-attention layer, hoisted out of the step loop."""
+    B, L, _ = ctx.shape
+    kv = {}
+    for name in W:
+        if name.endswith(".attn2.to_k.weight"):
+            p = name[: -len(".to_k.weight")]
+            with E.scope(tag + "/" + p):
+                k = E.linear(ctx, W[name], name="k")
+                vt = E.linear(ctx, W[p + ".to_v.weight"], transposed_out=True, rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
+            kv[p] = (k, vt)
+    return kv
+
+
+def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
+    B, H, Wd, Cc = x.shape
+    N = H * Wd
+    with E.scope(p):
+        h = E.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups, 1e-6, name="gn")
+        h = E.linear(h.view(B, N, Cc), W[p + ".proj_in.weight"], W[p + ".proj_in.bias"], name="pin")
+        k = 0
+        while f"{p}.transformer_blocks.{k}.norm1.weight" in W:
+            b = f"{p}.transformer_blocks.{k}"
+            with E.scope(f"tb{k}"):
+                n = E.layernorm(h, W[b + ".norm1.weight"], W[b + ".norm1.bias"], name="ln1")
+                qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")
+                vt = E.linear(n, W[b + ".attn1.to_v.weight"], transposed_out=True, rows_per_batch=N, pad_cols=_rup(N, 64), name="vt")
+                a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
+                h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
+                n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")
+                q = E.linear(n, W[b + ".attn2.to_q.weight"], name="cq")
+                ck, cvt = kv[b + ".attn2"]
+                a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                h = E.linear(a, W[b + ".attn2.to_out.0.weight"], W[b + ".attn2.to_out.0.bias"], residual=h, name="cao")
+                n = E.layernorm(h, W[b + ".norm3.weight"], W[b + ".norm3.bias"], name="ln3")
+                g = E.linear(n, W[b + ".ff.net.0.proj.weight"], W[b + ".ff.net.0.proj.bias"], act=ACT_GEGLU, name="ffg")
+                h = E.linear(g, W[b + ".ff.net.2.weight"], W[b + ".ff.net.2.bias"], residual=h, name="ffo")
+            k += 1
+        out = E.linear(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"], residual=x.view(B, N, Cc), name="pout")
+        return out.view(B, H, Wd, Cc)
+
+
+def _emit_encoder(E: Engine, W, cfg, h, shifts, kv):
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    skips = [h]
+    nlev = len(cfg["block_out_channels"])
+    for i, btype in enumerate(cfg["down_block_types"]):
+        for j in range(cfg["layers_per_block"]):
+            h = emit_resnet(E, W, f"down_blocks.{i}.resnets.{j}", h, None, shifts, G, eps)
+            if btype == "CrossAttnDownBlock2D":
+                h = emit_transformer(E, W, f"down_blocks.{i}.attentions.{j}", h, kv, _heads(cfg, i), G)
+            skips.append(h)
+        if i != nlev - 1:
+            p = f"down_blocks.{i}.downsamplers.0.conv"
+            h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, name=p)
+            skips.append(h)
+    return h, skips
+
+
+def _emit_mid(E: Engine, W, cfg, h, shifts, kv):
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    h = emit_resnet(E, W, "mid_block.resnets.0", h, None, shifts, G, eps)
+    h = emit_transformer(E, W, "mid_block.attentions.0", h, kv, _heads(cfg, len(cfg["block_out_channels"]) - 1), G)
+    return emit_resnet(E, W, "mid_block.resnets.1", h, None, shifts, G, eps)
+
+
+def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down_res: Optional[Sequence[torch.Tensor]] = None,
+              mid_res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x8: scaled latents [B, H, W, 8] (channels >= in_channels zero).  Returns eps [B, H, W, 8] (first out_channels valid)."""
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    with E.scope("unet"):
+        shifts = emit_time_shifts(E, W, cfg, t_dev)
+        h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], name="conv_in")
+        h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
+        if down_res is not None:
+            skips = [E.add(s, r, name=f"skip_add{i}") for i, (s, r) in enumerate(zip(skips, down_res))]
+        h = _emit_mid(E, W, cfg, h, shifts, kv)
+        if mid_res is not None:
+            h = E.add(h, mid_res, name="mid_add")
+        nlev = len(cfg["block_out_channels"])
+        for i, btype in enumerate(cfg["up_block_types"]):
+            for j in range(cfg["layers_per_block"] + 1):
+                h = emit_resnet(E, W, f"up_blocks.{i}.resnets.{j}", h, skips.pop(), shifts, G, eps)
+                if btype == "CrossAttnUpBlock2D":
+                    h = emit_transformer(E, W, f"up_blocks.{i}.attentions.{j}", h, kv, _heads(cfg, nlev - 1 - i), G)
+            if i != nlev - 1:
+                p = f"up_blocks.{i}.upsamplers.0.conv"
+                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
+        h = E.groupnorm(h, W["conv_norm_out.weight"], W["conv_norm_out.bias"], G, eps, act=ACT_SILU, name="norm_out")
+        return E.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], name="conv_out")
+
+
+def emit_controlnet_cond(E: Engine, W, cfg, cond8: torch.Tensor) -> torch.Tensor:
+    """controlnet_cond_embedding: constant over the denoise loop, so the pipeline runs it once per call."""
+    p = "controlnet_cond_embedding"
+    with E.scope("cn_cond"):
+        h = E.conv2d(cond8, W[p + ".conv_in.weight"], W[p + ".conv_in.bias"], act=ACT_SILU, name="in")
+        n = len(cfg["conditioning_embedding_out_channels"]) - 1
+        for i in range(n):
+            h = E.conv2d(h, W[f"{p}.blocks.{2 * i}.weight"], W[f"{p}.blocks.{2 * i}.bias"], act=ACT_SILU, name=f"b{2 * i}")
+            h = E.conv2d(h, W[f"{p}.blocks.{2 * i + 1}.weight"], W[f"{p}.blocks.{2 * i + 1}.bias"], act=ACT_SILU, stride=2, name=f"b{2 * i + 1}")
+        return E.conv2d(h, W[p + ".conv_out.weight"], W[p + ".conv_out.bias"], name="out")
+
+
+def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, conditioning_scale: float = 1.0):
+    """-> (list of 12 down residuals, mid residual), NHWC."""
+    with E.scope("cn"):
+        shifts = emit_time_shifts(E, W, cfg, t_dev)
+        h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], residual=cond_emb, name="conv_in")
+        h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
+        h = _emit_mid(E, W, cfg, h, shifts, kv)
+        outs = []
+        for i, s in enumerate(skips):
+            p = f"controlnet_down_blocks.{i}"
+            outs.append(E.conv2d(s, W[p + ".weight"], W[p + ".bias"], ksize=1, out_scale=conditioning_scale, name=p))
+        p = "controlnet_mid_block"
+        mid = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], ksize=1, out_scale=conditioning_scale, name=p)
+        return outs, mid
+
+
+# ------------------------------------------------------------------------------------------------ AutoencoderKL
+def _emit_vae_attention(E: Engine, W, p: str, x, groups: int):
+    """Single-head, d = C attention of the VAE mid block: QK^T and PV as plain MFMA GEMMs around a row softmax (the d=512
+    head does not fit the flash kernel's register tile; it is 1.4 % of the decoder's FLOPs)."""
+    B, H, Wd, Cc = x.shape
+    N = H * Wd
+    with E.scope(p):
+        h = E.groupnorm(x, W[p + ".group_norm.weight"], W[p + ".group_norm.bias"], groups, 1e-6, name="gn").view(B, N, Cc)
+        q = E.linear(h, W[p + ".to_q.weight"], W[p + ".to_q.bias"], name="q")
+        k = E.linear(h, W[p + ".to_k.weight"], W[p + ".to_k.bias"], name="k")
+        Np = _rup(N, 64)
+        vt = E.linear(h, W[p + ".to_v.weight"], W[p + ".to_v.bias"], transposed_out=True, rows_per_batch=N, pad_cols=Np, name="vt")
+        a = E.buf("a", (B, N, Cc))
+        s = E.buf("s", (N, Np), zero=True)
+        for b in range(B):
+            E.linear(q[b], k[b], out=s[:, :N] if Np == N else s[:, :N])
+            E.softmax_rows(s[:, :N], float(Cc) ** -0.5)
+            E.linear(s[:, :N], vt[b][:, :N], out=a[b])
+        o = E.linear(a, W[p + ".to_out.0.weight"], W[p + ".to_out.0.bias"], residual=x.view(B, N, Cc), name="o")
+        return o.view(B, H, Wd, Cc)
+
+
+def _emit_vae_mid(E, W, p, h, G):
+    h = emit_resnet(E, W, p + ".resnets.0", h, None, None, G, 1e-6)
+    h = _emit_vae_attention(E, W, p + ".attentions.0", h, G)
+    return emit_resnet(E, W, p + ".resnets.1", h, None, None, G, 1e-6)
+
+
+def emit_vae_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
+    """z8: latents / scaling_factor, [B, h, w, 8] (channels >= 4 zero) -> image [B, 8h, 8w, 8] (first 3 channels valid)."""
+    G = cfg["norm_num_groups"]
+    n = len(cfg["block_out_channels"])
+    with E.scope("vae_dec"):
+        h = E.conv2d(z8, W["post_quant_conv.weight"], W["post_quant_conv.bias"], ksize=1, name="pq")
+        h = E.conv2d(h, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"], name="conv_in")
+        h = _emit_vae_mid(E, W, "decoder.mid_block", h, G)
+        for i in range(n):
+            for j in range(cfg["layers_per_block"] + 1):
+                h = emit_resnet(E, W, f"decoder.up_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6)
+            if i != n - 1:
+                p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
+        h = E.groupnorm(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, 1e-6, act=ACT_SILU, name="norm_out")
+        return E.conv2d(h, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], name="conv_out")
+
+
+def emit_vae_encode_moments(E: Engine, W, cfg, x8: torch.Tensor) -> torch.Tensor:
+    """x8: image in [-1, 1], [B, H, W, 8] -> moments [B, H/8, W/8, 8] = (mean[0:4], logvar[4:8]) before clamping."""
+    G = cfg["norm_num_groups"]
+    n = len(cfg["block_out_channels"])
+    with E.scope("vae_enc"):
+        h = E.conv2d(x8, W["encoder.conv_in.weight"], W["encoder.conv_in.bias"], name="conv_in")
+        for i in range(n):
+            for j in range(cfg["layers_per_block"]):
+                h = emit_resnet(E, W, f"encoder.down_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6)
+            if i != n - 1:
+                p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, pad=(0, 0, 1, 1), name=p)  # F.pad (0,1,0,1)
+        h = _emit_vae_mid(E, W, "encoder.mid_block", h, G)
+        h = E.groupnorm(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], G, 1e-6, act=ACT_SILU, name="norm_out")
+        h = E.conv2d(h, W["encoder.conv_out.weight"], W["encoder.conv_out.bias"], name="conv_out")
+        return E.conv2d(h, W["quant_conv.weight"], W["quant_conv.bias"], ksize=1, name="quant")
+
+
+# ------------------------------------------------------------------------------------------------ CLIP text tower
+def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor) -> torch.Tensor:
+    """ids int32 [B, L] -> last_hidden_state f16 [B, L, D] (after final_layer_norm)."""
+    B, L = ids.shape
+    heads = cfg["num_attention_heads"]
+    eps = cfg.get("layer_norm_eps", 1e-5)
+    D = cfg["hidden_size"]
+    act = ACT_QUICK_GELU if cfg["hidden_act"] == "quick_gelu" else ACT_GELU
+    with E.scope("clip"):
+        x = E.embedding(ids, W["text_model.embeddings.token_embedding.weight"],
+                        W["text_model.embeddings.position_embedding.weight"], name="emb")
+        for i in range(cfg["num_hidden_layers"]):
+            p = f"text_model.encoder.layers.{i}"
+            with E.scope(f"l{i}"):
+                n = E.layernorm(x, W[p + ".layer_norm1.weight"], W[p + ".layer_norm1.bias"], eps, name="ln1")
+                qk = E.linear(n, W[p + ".self_attn.qk_proj.weight"], W[p + ".self_attn.qk_proj.bias"], name="qk")
+                vt = E.linear(n, W[p + ".self_attn.v_proj.weight"], W[p + ".self_attn.v_proj.bias"], transposed_out=True,
+                              rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
+                a = E.attention(qk[:, :, :D], qk[:, :, D:], vt, heads, causal=True, name="sa")
+                x = E.linear(a, W[p + ".self_attn.out_proj.weight"], W[p + ".self_attn.out_proj.bias"], residual=x, name="o")
+                n = E.layernorm(x, W[p + ".layer_norm2.weight"], W[p + ".layer_norm2.bias"], eps, name="ln2")
+                h = E.linear(n, W[p + ".mlp.fc1.weight"], W[p + ".mlp.fc1.bias"], act=act, name="fc1")
+                x = E.linear(h, W[p + ".mlp.fc2.weight"], W[p + ".mlp.fc2.bias"], residual=x, name="fc2")
+        return E.layernorm(x, W["text_model.final_layer_norm.weight"], W["text_model.final_layer_norm.bias"], eps, name="ln_f")

@@ -1,0 +1,102 @@
+"""Weight repacking: diffusers/transformers-named fp32 state dicts -> the f16 device layouts libgenima_hip.so consumes.
+
+  * Conv2d  OIHW  -> [Cout_pad8, KH*KW*Cin_pad8]  (tap-major, channel-minor: the implicit-GEMM K order); zero rows/cols in
+    the padding so padded output channels are exact zeros and padded input channels are ignored.
+  * Linear  [out, in] kept as is (K contiguous).
+  * GEGLU   ``ff.net.0.proj`` [8C, C] -> alternating 32-row blocks [hidden | gate] (gn_gemm GN_ACT_GEGLU contract).
+  * Self-attention ``to_q``/``to_k`` fused into one [2C, C] projection (``attn1.to_qk`` / ``self_attn.qk_proj``).
+  * All ``time_emb_proj`` Linears of a network concatenated into one [sum Cout, temb] GEMM (``time_emb_proj_all``) whose
+    output columns are sliced per ResNet block by pointer offset (gn_gemm ``ldshift``).
+Explicit and caller-owned, as SURVEY.md section 8(b) asks: nothing is repacked behind the caller's back.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+import torch
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def pack_conv_weight(w: torch.Tensor, cin_splits=None) -> torch.Tensor:
+    """OIHW fp32 -> [Cout_pad8, KH*KW*Cin_pad8] f16.  ``cin_splits=(C1, C2)`` keeps a virtual-concat boundary (each part
+    must already be a multiple of 8)."""
+    O, I, KH, KW = w.shape
+    Ip, Op = _rup(I, 8), _rup(O, 8)
+    p = torch.zeros((Op, KH, KW, Ip), dtype=torch.float32)
+    p[:O, :, :, :I] = w.permute(0, 2, 3, 1)
+    return p.reshape(Op, KH * KW * Ip).to(torch.float16).contiguous()
+
+
+def pack_vec(b: torch.Tensor, n_pad: int) -> torch.Tensor:
+    out = torch.zeros((n_pad,), dtype=torch.float32)
+    out[: b.numel()] = b
+    return out.to(torch.float16).contiguous()
+
+
+def pack_geglu(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    n2 = w.shape[0]
+    half = n2 // 2
+    assert half % 32 == 0
+    wh, wg = w[:half].reshape(half // 32, 32, -1), w[half:].reshape(half // 32, 32, -1)
+    wp = torch.stack([wh, wg], dim=1).reshape(n2, -1)
+    bh, bg = b[:half].reshape(half // 32, 32), b[half:].reshape(half // 32, 32)
+    bp = torch.stack([bh, bg], dim=1).reshape(n2)
+    return wp.to(torch.float16).contiguous(), bp.to(torch.float16).contiguous()
+
+
+def pack_state_dict(sd: Dict[str, torch.Tensor], device) -> "OrderedDict[str, torch.Tensor]":
+    """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries)."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    temb_w, temb_b, temb_slices, off = [], [], OrderedDict(), 0
+    for name, t in sd.items():
+        t = t.detach().to(torch.float32).cpu()
+        if t.dim() == 4:
+            out[name] = pack_conv_weight(t)
+            bn = name[: -len("weight")] + "bias"
+            if bn in sd:
+                out[bn] = pack_vec(sd[bn].detach().float().cpu(), out[name].shape[0])
+        elif t.dim() == 2:
+            if name.endswith("ff.net.0.proj.weight"):
+                bn = name[: -len("weight")] + "bias"
+                wp, bp = pack_geglu(t, sd[bn].detach().float().cpu())
+                out[name], out[bn] = wp, bp
+                continue
+            if name.endswith("time_emb_proj.weight"):
+                bn = name[: -len("weight")] + "bias"
+                temb_w.append(t)
+                temb_b.append(sd[bn].detach().float().cpu())
+                temb_slices[name[: -len(".time_emb_proj.weight")]] = (off, t.shape[0])
+                off += t.shape[0]
+            if t.shape[1] % 8 != 0:  # pad the reduction dim
+                tp = torch.zeros((t.shape[0], _rup(t.shape[1], 8)))
+                tp[:, : t.shape[1]] = t
+                t = tp
+            out[name] = t.to(torch.float16).contiguous()
+        elif t.dim() == 1:
+            if name not in out:  # conv / geglu biases were handled with their weights
+                out[name] = t.to(torch.float16).contiguous()
+        else:
+            out[name] = t.to(torch.float16).contiguous()
+    # fused self-attention q|k projections
+    for name in list(sd.keys()):
+        for qn, kn, fused in ((".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_qk.weight"),
+                              (".self_attn.q_proj.weight", ".self_attn.k_proj.weight", ".self_attn.qk_proj.weight")):
+            if name.endswith(qn):
+                base = name[: -len(qn)]
+                out[base + fused] = torch.cat([sd[name], sd[base + kn]], dim=0).to(torch.float16).contiguous()
+                qb, kb = name[: -len("weight")] + "bias", (base + kn)[: -len("weight")] + "bias"
+                if qb in sd:
+                    out[(base + fused)[: -len("weight")] + "bias"] = torch.cat([sd[qb], sd[kb]]).to(torch.float16).contiguous()
+    meta = {}
+    if temb_w:
+        out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(torch.float16).contiguous()
+        out["time_emb_proj_all.bias"] = torch.cat(temb_b, dim=0).to(torch.float16).contiguous()
+        meta["temb_slices"] = temb_slices
+        meta["temb_total"] = off
+    dev = OrderedDict((k, v.to(device)) for k, v in out.items())
+    dev["__meta__"] = meta  # type: ignore[assignment]
+    return dev

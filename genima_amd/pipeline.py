@@ -1,0 +1,275 @@
+"""``StableDiffusionControlNetPipeline``-shaped denoise pipeline on libgenima_hip.so.
+
+Keeps the call surface the reference uses (controller/agent/sd_controlnet_agent.py:67-76,
+diffusion/train_controlnet_genima.py:632-638; semantics in SURVEY.md Appendix D):
+    pipe(prompt=, image=, negative_prompt=, num_inference_steps=, guidance_scale=, generator=)  ->  out.images / out[0]
+but the whole call -- CLIP text encode, ControlNet cond-embedding, N x (ControlNet + UNet + Euler step), VAE decode, uint8
+post-process -- is lowered ONCE per (batch, size, steps) shape to a recorded ``gn_program`` and replayed from C++ on one HIP
+stream (optionally as a captured hipGraph), so nothing returns to Python inside the loop.  Work hoisted out of the step loop
+because it is constant across steps: the cross-attention K/V projections of the prompt (23 layers) and the ControlNet
+conditioning embedding.
+"""
+from __future__ import annotations
+
+import zlib
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from . import graphs
+from .engine import Engine
+from .host import AutoencoderKL, CLIPTextModel, ControlNetModel, UNet2DConditionModel
+from .scheduler import EulerDiscreteScheduler
+from ._lib import GenimaHipError
+
+
+class HashTokenizer:
+    """Stand-in tokenizer: the CLIP BPE vocab/merges are not available offline, so words are hashed to
+    ids in [1000, vocab-3); BOS/EOS/pad ids and the pad-to-77 shape follow the SD-2.x tokenizer.  A real
+    ``transformers.CLIPTokenizer`` can be passed to the pipeline instead; with a released checkpoint it must be."""
+
+    model_max_length = 77
+
+    def __init__(self, vocab_size: int = 49408, pad_token_id: int = 0):
+        self.vocab_size, self.pad_token_id = vocab_size, pad_token_id
+        self.bos_token_id, self.eos_token_id = vocab_size - 2, vocab_size - 1
+
+    def __call__(self, text, padding="max_length", max_length=None, truncation=True, return_tensors="pt"):
+        texts = [text] if isinstance(text, str) else list(text)
+        L = max_length or self.model_max_length
+        ids = np.full((len(texts), L), self.pad_token_id, dtype=np.int64)
+        lo, hi = min(1000, self.vocab_size // 4), self.vocab_size - 3
+        for i, t in enumerate(texts):
+            toks = [self.bos_token_id] + [lo + zlib.crc32(w.encode()) % (hi - lo) for w in t.lower().split()][: L - 2]
+            toks.append(self.eos_token_id)
+            ids[i, : len(toks)] = toks
+        return SimpleNamespace(input_ids=torch.from_numpy(ids))
+
+
+class PipelineOutput:
+    def __init__(self, images, nsfw_content_detected=None):
+        self.images = images
+        self.nsfw_content_detected = nsfw_content_detected
+
+    def __getitem__(self, i):
+        return (self.images, self.nsfw_content_detected)[i]
+
+
+def randn_latents(shape, generator, device, dtype=torch.float16) -> torch.Tensor:
+    """diffusers ``randn_tensor`` semantics: with a list of generators sample i is drawn as
+    (1, C, H, W) from generator[i] (the reference passes the SAME generator B times -> sequential draws from one stream)."""
+    def draw(shp, g):
+        gdev = g.device if g is not None else torch.device(device)
+        return torch.randn(shp, generator=g, device=gdev, dtype=dtype).to(device)
+
+    if isinstance(generator, (list, tuple)):
+        if len(generator) == 1:
+            generator = generator[0]
+        else:
+            assert len(generator) == shape[0], "one generator per sample"
+            return torch.cat([draw((1,) + tuple(shape[1:]), g) for g in generator], dim=0)
+    return draw(tuple(shape), generator)
+
+
+class StableDiffusionControlNetPipeline:
+    def __init__(self, vae: AutoencoderKL, text_encoder: CLIPTextModel, tokenizer, unet: UNet2DConditionModel,
+                 controlnet: ControlNetModel, scheduler: EulerDiscreteScheduler, safety_checker=None, feature_extractor=None,
+                 requires_safety_checker=False):
+        self.vae, self.text_encoder, self.tokenizer = vae, text_encoder, tokenizer or HashTokenizer(text_encoder.config["vocab_size"])
+        self.unet, self.controlnet, self.scheduler = unet, controlnet, scheduler
+        self.safety_checker = safety_checker
+        self.vae_scale_factor = 2 ** (len(vae.config["block_out_channels"]) - 1)
+        self.device = torch.device("cpu")
+        self._progs = {}
+        self.use_graph = False
+        self._progress = True
+
+    # ---- construction ----------------------------------------------------------------------------------------------
+    @classmethod
+    def from_pretrained(cls, path, controlnet=None, safety_checker=None, torch_dtype=None, variant=None, **kw):
+        """Reads the diffusers pipeline directory layout (``unet/``, ``vae/``, ``text_encoder/``, ``scheduler/``)."""
+        import json
+        import os
+
+        unet = UNet2DConditionModel.from_pretrained(path, "unet")
+        vae = AutoencoderKL.from_pretrained(path, "vae")
+        text = CLIPTextModel.from_pretrained(path, "text_encoder")
+        with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
+            sched = EulerDiscreteScheduler.from_config(json.load(f))
+        tok = None
+        try:  # a real CLIP tokenizer if its vocab is present
+            from transformers import CLIPTokenizer
+
+            if os.path.exists(os.path.join(path, "tokenizer", "vocab.json")):
+                tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
+        except Exception:
+            tok = None
+        if controlnet is None:
+            controlnet = ControlNetModel.from_unet(unet)
+        return cls(vae, text, tok, unet, controlnet, sched, safety_checker)
+
+    @classmethod
+    def from_synthetic(cls, family: dict, seed: int = 0):
+        """Random-init pipeline of a config family (no checkpoints exist offline; SURVEY.md section 8d synthetic weights)."""
+        unet = UNet2DConditionModel.from_config(family["unet"], seed + 1)
+        cn = ControlNetModel.from_config(family["controlnet"], seed + 2)
+        vae = AutoencoderKL.from_config(family["vae"], seed + 3)
+        text = CLIPTextModel.from_config(family["text"], seed + 4)
+        return cls(vae, text, None, unet, cn, EulerDiscreteScheduler.from_config(family["scheduler"]))
+
+    # ---- knobs the agent calls (controller/agent/diffusion_agent.py:21-42) -------------------------------------------------
+    def to(self, device=None, *a, **k):
+        if device is not None and not isinstance(device, torch.dtype):
+            for m in (self.vae, self.text_encoder, self.unet, self.controlnet):
+                m.to(device)
+            self.device = self.unet.device
+            self._progs.clear()
+        return self
+
+    def set_progress_bar_config(self, disable=False, **kw):
+        self._progress = not disable
+
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None  # flash attention on MFMA is the only attention path
+
+    def fuse_qkv_projections(self, vae=False, **k):
+        return None  # q|k are always fused at pack time
+
+    def upcast_vae(self):
+        return None
+
+    def enable_vae_slicing(self):
+        return None
+
+    def enable_hip_graph(self, flag: bool = True):
+        """Replay each call as one captured hipGraph (the HIP equivalent of the reference's torch.compile reduce-overhead)."""
+        self.use_graph = flag
+        self._progs.clear()
+
+    # ---- program construction -----------------------------------------------------------------------------------------------
+    def _build(self, B: int, H: int, W: int, steps: int):
+        dev = self.device
+        E = Engine(dev, record=True)
+        s = self.vae_scale_factor
+        h, w = H // s, W // s
+        L = self.tokenizer.model_max_length if hasattr(self.tokenizer, "model_max_length") else 77
+        io = SimpleNamespace()
+        io.ids = E.buf("in_ids", (B, L), dtype=torch.int32, zero=True)
+        io.image_u8 = E.buf("in_image", (B, H, W, 3), dtype=torch.uint8, zero=True)
+        io.latents = E.buf("latents", (B, h, w, self.unet.config["in_channels"]), zero=True)
+        sch = self.scheduler
+        sch.set_timesteps(steps)
+        io.timesteps = [int(t) for t in sch.timesteps.tolist()]
+
+        ctx = graphs.emit_clip_text(E, self.text_encoder.W, self.text_encoder.config, io.ids)
+        kv_cn = graphs.emit_cross_kv(E, self.controlnet.W, ctx, "cn")
+        kv_un = graphs.emit_cross_kv(E, self.unet.W, ctx, "unet")
+        cond8 = E.image_u8_to_f16(io.image_u8, 8, 1.0, 0.0, name="cond8")  # VaeImageProcessor(do_normalize=False)
+        cemb = graphs.emit_controlnet_cond(E, self.controlnet.W, self.controlnet.config, cond8)
+        io.first_step_op = E.num_ops
+        for i in range(steps):
+            sigma, sigma_next = float(sch.sigmas[i]), float(sch.sigmas[i + 1])
+            t_dev = torch.full((B,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
+            E._keepalive(t_dev)
+            x8 = E.scale_pad(io.latents, sch.input_scale(i), 8, name="x8")
+            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0)
+            eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid)
+            E.euler_step(io.latents, eps, sigma, sigma_next)
+            if i == 0:
+                io.ops_per_step = E.num_ops - io.first_step_op
+        io.first_vae_op = E.num_ops
+        z8 = E.scale_pad(io.latents, 1.0 / self.vae.config["scaling_factor"], 8, name="z8")
+        img = graphs.emit_vae_decode(E, self.vae.W, self.vae.config, z8)
+        io.out_u8 = E.image_f16_to_u8(img, name="out_u8")
+        io.engine = E
+        if self.use_graph:
+            side = torch.cuda.Stream(device=dev)
+            E.use_stream(side)
+            with torch.cuda.stream(side):
+                E.run()  # warm-up outside capture (lazy module loads)
+                side.synchronize()
+                E.capture()
+            io.stream = side
+        return io
+
+    def program(self, B, H, W, steps):
+        key = (B, H, W, steps)
+        if key not in self._progs:
+            if self.unet.W is None:
+                raise GenimaHipError("pipeline is not on a ROCm device: call pipe.to('cuda') first (no CPU fallback)")
+            self._progs[key] = self._build(B, H, W, steps)
+        return self._progs[key]
+
+    # ---- the call ------------------------------------------------------------------------------------------------------
+    def encode_ids(self, prompt) -> torch.Tensor:
+        tok = self.tokenizer(prompt, padding="max_length", max_length=getattr(self.tokenizer, "model_max_length", 77),
+                             truncation=True, return_tensors="pt")
+        return tok.input_ids
+
+    @staticmethod
+    def _images_to_u8(image, B) -> torch.Tensor:
+        if isinstance(image, torch.Tensor):
+            t = image
+            if t.dtype != torch.uint8:  # float NCHW in [0,1] like VaeImageProcessor accepts
+                t = (t.permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8)
+            return t
+        imgs = image if isinstance(image, (list, tuple)) else [image]
+        arr = np.stack([np.asarray(im.convert("RGB") if hasattr(im, "convert") else im, dtype=np.uint8) for im in imgs])
+        if arr.shape[0] == 1 and B > 1:
+            arr = np.repeat(arr, B, axis=0)
+        return torch.from_numpy(arr)
+
+    def __call__(self, prompt=None, image=None, negative_prompt=None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 generator=None, latents: Optional[torch.Tensor] = None, output_type: str = "pil", prompt_ids=None,
+                 height=None, width=None, return_dict: bool = True, **kw):
+        if guidance_scale > 1.0:
+            raise NotImplementedError("classifier-free guidance (guidance_scale > 1) is not on the Genima hot path "
+                                      "(the reference always runs guidance_scale=0.0; SURVEY.md Appendix D.1)")
+        if prompt_ids is None:
+            prompt_ids = self.encode_ids(prompt)
+        B = prompt_ids.shape[0]
+        img_u8 = self._images_to_u8(image, B)
+        assert img_u8.shape[0] == B, "one control image per prompt"
+        H, W = int(img_u8.shape[1]), int(img_u8.shape[2])
+        io = self.program(B, H, W, num_inference_steps)
+        E: Engine = io.engine
+        s = self.vae_scale_factor
+        C = self.unet.config["in_channels"]
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps)
+        if latents is None:
+            latents = randn_latents((B, C, H // s, W // s), generator, self.device)
+            latents = latents * sch.init_noise_sigma
+        else:
+            latents = latents.to(self.device, torch.float16) * sch.init_noise_sigma
+        if sch.draws_step_noise and generator is not None:
+            for _ in range(num_inference_steps):  # mirror diffusers 0.29.0's per-step (unused) randn draw
+                randn_latents((B, C, H // s, W // s), generator, self.device)
+        stream = getattr(io, "stream", None)
+        cur = torch.cuda.current_stream(self.device)
+        io.ids.copy_(prompt_ids.to(torch.int32), non_blocking=False)
+        io.image_u8.copy_(img_u8)
+        io.latents.copy_(latents.permute(0, 2, 3, 1))
+        if stream is not None:
+            stream.wait_stream(cur)
+            E.launch()
+            cur.wait_stream(stream)
+        else:
+            E.use_stream(cur)
+            E.run()
+        out = io.out_u8
+        if output_type == "latent":
+            images = io.latents.permute(0, 3, 1, 2).clone()
+        elif output_type in ("pt", "np_u8"):
+            images = out.clone()
+        else:
+            arr = out.cpu().numpy()  # D->H 768 KB / sample + the call's only sync
+            if output_type == "np":
+                images = arr
+            else:
+                from PIL import Image
+
+                images = [Image.fromarray(a) for a in arr]
+        return PipelineOutput(images) if return_dict else (images, None)

@@ -1,0 +1,184 @@
+/*
+ * genima_hip.h -- C ABI of libgenima_hip.so: the MI355X (gfx950 / CDNA4) kernels under the Genima hot path.
+ *
+ * The reference (MohitShridhar/genima) has no FFI of its own: its device arithmetic is reached through
+ * Python seams.  This header is the boundary the build puts *underneath* those seams; each entry
+ * point cites the reference call site whose third-party device op it replaces.  Conventions (binding):
+ *   - extern "C", plain C types only; no C++ exceptions cross the boundary.
+ *   - every function returns int32_t status: 0 = ok, negative = error (gn_last_error() has the thread-local message).
+ *   - the caller owns ALL device memory (weights, activations, workspaces) and passes raw device pointers + shapes;
+ *     the library never allocates device memory.  *_workspace_bytes() queries precede ops that need scratch.
+ *   - functions enqueue on the gn_ctx's stream and never synchronise (asynchronous w.r.t. the host).
+ *   - activations are NHWC ("[B, H*W, C]" row-major == the token layout of the transformer blocks); f16 storage with
+ *     f32 accumulation (the reference runs torch_dtype=float16: controller/agent/sd_controlnet_agent.py:34,40).
+ *   - weights are packed [Cout][KH*KW*Cin] (tap-major, channel-minor; K contiguous) by the host (genima_amd/packing.py).
+ */
+#ifndef GENIMA_HIP_H
+#define GENIMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GN_OK 0
+#define GN_ERR_INVALID (-1)      /* bad argument / unsupported shape */
+#define GN_ERR_HIP (-2)          /* a HIP runtime call failed */
+#define GN_ERR_UNSUPPORTED (-3)
+
+/* epilogue activations */
+enum { GN_ACT_NONE = 0, GN_ACT_SILU = 1, GN_ACT_GELU = 2, GN_ACT_QUICK_GELU = 3, GN_ACT_RELU = 4, GN_ACT_GEGLU = 5 };
+/* output modes of the GEMM epilogue */
+enum { GN_OUT_ROWMAJOR = 0, GN_OUT_BATCH_TRANSPOSED = 1 };
+
+typedef struct gn_ctx gn_ctx;
+typedef struct gn_program gn_program;
+
+/* ---- context ------------------------------------------------------------------------------------------------ */
+int32_t gn_version(void);
+const char* gn_last_error(void);
+/* stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the default stream. */
+int32_t gn_ctx_create(int32_t device, void* stream, gn_ctx** out);
+int32_t gn_ctx_destroy(gn_ctx* ctx);
+int32_t gn_ctx_set_stream(gn_ctx* ctx, void* stream);
+
+/* ---- K1/K3/K6/K7/K8: MFMA implicit-GEMM convolution and Linear (one kernel family) --------------------------------
+ * out[m, n] = epilogue( sum_k A[m, k] * W[n, k] )            M = B*Ho*Wo (conv) or rows (linear), K = KH*KW*(C1+C2)
+ * Replaces the cuDNN conv / cuBLAS GEMM calls reached from `self.pipe(...)` (controller/agent/sd_controlnet_agent.py:67-76)
+ * and `controlnet(...)` / `unet(...)` / `vae.encode` / `text_encoder` (diffusion/train_controlnet_genima.py:1324-1388).
+ * Epilogue order:  v = acc + bias[n] + shift[m / rows_per_batch, n];  v = act(v);  v *= out_scale;  v += residual[m, n].
+ * GN_ACT_GEGLU: W rows are packed in alternating 32-row blocks [hidden | gate]; out[m, j] = hidden * gelu(gate), out has N/2 cols.
+ */
+typedef struct gn_gemm_desc {
+  const void* a;          /* A source 1: dense [M, lda] or NHWC [B, H, W, C1] */
+  const void* a2;         /* conv only: second NHWC source [B, H, W, C2], virtually concatenated on channels; or NULL */
+  const void* w;          /* [N, ldw] f16, K contiguous */
+  const void* bias;       /* [N] f16 or NULL */
+  const void* shift;      /* [M / rows_per_batch, ldshift] f16 or NULL (time-embedding shift, K3) */
+  const void* residual;   /* [M, ldr] f16 or NULL */
+  void* out;              /* f16 */
+  void* workspace;        /* f32 split-K scratch (gn_gemm_workspace_bytes) or NULL when splitk <= 1 */
+  int64_t M, N, K;
+  int64_t lda, ldw, ldr, ldo;
+  int64_t ldshift;        /* row stride of shift (0 = N) */
+  int32_t conv;           /* 0 = dense A, 1 = implicit-GEMM gather */
+  int32_t B, H, W, C1, C2;         /* conv: source tensor dims (before the optional nearest-2x upsample) */
+  int32_t KH, KW, stride, pad_t, pad_l, Ho, Wo;
+  int32_t upsample2x;     /* conv: 1 = input is nearest-upsampled 2x on the fly (K8) */
+  int32_t act;            /* GN_ACT_* */
+  int32_t out_mode;       /* GN_OUT_*; BATCH_TRANSPOSED: out[b][n][m - b*rows_per_batch], row stride ldo, batch stride N*ldo */
+  int32_t rows_per_batch; /* for shift / transposed output; 0 = M */
+  int32_t splitk;         /* 0 = library heuristic, >=1 explicit */
+  float out_scale;        /* 1.0f = none */
+} gn_gemm_desc;
+int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
+int32_t gn_gemm(gn_ctx* ctx, const gn_gemm_desc* d);
+
+/* ---- K4/K5/K11: flash-style attention forward --------------------------------------------------------------------
+ * o[b, i, h*D + :] = softmax_j(scale * q[b,i,h] . k[b,j,h]) v[b,j,h]; V is consumed TRANSPOSED (vt[b][h*D + d][j], produced
+ * for free by the V projection's GN_OUT_BATCH_TRANSPOSED epilogue).  Replaces xformers memory_efficient_attention / torch SDPA
+ * (controller/agent/diffusion_agent.py:35-36, diffusion/train_controlnet_genima.py:1125-1126).  D in {32, 64}.
+ * vt row stride must be a multiple of 8 and cover round_up(Nk, 64) columns (pad columns must hold finite values). */
+typedef struct gn_attn_desc {
+  const void* q; const void* k; const void* vt; void* o;
+  int64_t q_bs, k_bs, vt_bs, o_bs;   /* batch strides (elements) */
+  int32_t q_rs, k_rs, vt_rs, o_rs;   /* row strides (elements) */
+  int32_t B, heads, Nq, Nk, D;
+  int32_t causal;
+  float scale;
+} gn_attn_desc;
+int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d);
+
+/* ---- K2: GroupNorm(+SiLU), NHWC --------------------------------------------------------------------------------
+ * y = act(GroupNorm_G(cat(x, x2)) * gamma + beta).  Three launches: coalesced partial statistics over pixel slabs, a finalize
+ * that folds (mean, rstd, gamma, beta) into per-(b, c) scale/shift, and a coalesced apply.  Replaces torch
+ * native_group_norm + silu (every ResnetBlock2D / Transformer2DModel entry / conv_norm_out). */
+typedef struct gn_groupnorm_desc {
+  const void* x; const void* x2;     /* NHWC f16; x2 optional concat source */
+  const void* gamma; const void* beta; /* [C1+C2] f16 */
+  void* y;                           /* [B, HW, C1+C2] f16 */
+  void* workspace;                   /* gn_groupnorm_workspace_bytes() */
+  int32_t B, HW, C1, C2, groups;
+  int32_t act;                       /* GN_ACT_NONE or GN_ACT_SILU */
+  float eps;
+} gn_groupnorm_desc;
+int64_t gn_groupnorm_workspace_bytes(const gn_groupnorm_desc* d);
+int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d);
+
+/* ---- K7: LayerNorm over the last dim of [M, C] (C % 8 == 0, C <= 4096) --------------------------------------------- */
+int32_t gn_layernorm_fwd(gn_ctx* ctx, const void* x, const void* gamma, const void* beta, void* y,
+                         int64_t M, int32_t C, float eps);
+
+/* ---- K9: sinusoidal timestep embedding -> f16 [B, dim]  (t: device f32 [B]) ------------------------------------- */
+int32_t gn_timestep_embedding(gn_ctx* ctx, const float* t, void* out, int32_t B, int32_t dim, int32_t flip_sin_to_cos,
+                              float freq_shift);
+
+/* ---- K10: scheduler elementwise ops on f16 latents [n] ------------------------------------------------------------
+ * gn_scale_pad:  out[p, 0:C] = x[p, 0:C] * scale, out[p, C:Cpad] = 0       (scale_model_input / latents/scaling_factor,
+ *                and the channel padding the implicit-GEMM conv wants for Cin = 4)
+ * gn_euler_step: x <- x + eps * (sigma_next - sigma), f32 math, f16 storage; eps has row stride ld_eps
+ * gn_add_noise:  out = a[b] * x0 + c[b] * noise  (DDPM add_noise, diffusion/train_controlnet_genima.py:1359) */
+int32_t gn_scale_pad(gn_ctx* ctx, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad, float scale);
+int32_t gn_euler_step(gn_ctx* ctx, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps, float sigma,
+                      float sigma_next);
+int32_t gn_add_noise(gn_ctx* ctx, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                     void* out, int32_t B, int64_t per_sample);
+
+/* ---- K14: image pre/post-processing ------------------------------------------------------------------------------
+ * gn_image_u8_to_f16: uint8 NHWC [pixels, 3] -> f16 [pixels, Cpad]: v/255*mul + add  (VaeImageProcessor.preprocess)
+ * gn_image_f16_to_u8: f16 [pixels, ld] -> uint8 [pixels, 3]: round(clamp(v/2+0.5, 0, 1)*255)  (postprocess, Appendix D.6) */
+int32_t gn_image_u8_to_f16(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float mul, float add);
+int32_t gn_image_f16_to_u8(gn_ctx* ctx, const void* in, uint8_t* out, int64_t pixels, int32_t ld);
+
+/* ---- misc elementwise / gather ------------------------------------------------------------------------------------ */
+int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n);              /* f16, n % 8 == 0 */
+int32_t gn_act(gn_ctx* ctx, const void* x, void* out, int64_t n, int32_t act);                /* f16, n % 8 == 0 */
+int32_t gn_embedding(gn_ctx* ctx, const int32_t* ids, const void* tok, const void* pos, void* out, int32_t B,
+                     int32_t L, int32_t D);                                                   /* CLIP token + position */
+int32_t gn_softmax_rows(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale); /* in place, f16 */
+int32_t gn_maxpool3x3s2(gn_ctx* ctx, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C);
+
+/* ---- op programs: record once, replay on the stream (eagerly or as a captured hipGraph) ---------------------------
+ * The host classes (UNet2DConditionModel / ControlNetModel / AutoencoderKL / pipeline) lower a forward pass to a flat list of
+ * the ops above with all buffers pre-allocated, so the 5-step denoise loop runs without returning to Python. */
+int32_t gn_program_create(gn_ctx* ctx, gn_program** out);
+int32_t gn_program_destroy(gn_program* p);
+int32_t gn_program_add_gemm(gn_program* p, const gn_gemm_desc* d);
+int32_t gn_program_add_attention(gn_program* p, const gn_attn_desc* d);
+int32_t gn_program_add_groupnorm(gn_program* p, const gn_groupnorm_desc* d);
+int32_t gn_program_add_layernorm(gn_program* p, const void* x, const void* gamma, const void* beta, void* y, int64_t M,
+                                 int32_t C, float eps);
+int32_t gn_program_add_timestep_embedding(gn_program* p, const float* t, void* out, int32_t B, int32_t dim,
+                                          int32_t flip_sin_to_cos, float freq_shift);
+int32_t gn_program_add_scale_pad(gn_program* p, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad,
+                                 float scale);
+int32_t gn_program_add_euler_step(gn_program* p, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps,
+                                  float sigma, float sigma_next);
+int32_t gn_program_add_image_f16_to_u8(gn_program* p, const void* in, uint8_t* out, int64_t pixels, int32_t ld);
+int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad,
+                                       float mul, float add);
+int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n);
+int32_t gn_program_add_act(gn_program* p, const void* x, void* out, int64_t n, int32_t act);
+int32_t gn_program_add_embedding(gn_program* p, const int32_t* ids, const void* tok, const void* pos, void* out,
+                                 int32_t B, int32_t L, int32_t D);
+int32_t gn_program_add_softmax_rows(gn_program* p, void* x, int64_t rows, int32_t cols, int32_t ld, float scale);
+int32_t gn_program_add_maxpool3x3s2(gn_program* p, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C);
+int64_t gn_program_num_ops(const gn_program* p);
+/* first..last (exclusive) op range; last < 0 = to the end */
+int32_t gn_program_run(gn_program* p, int64_t first, int64_t last);
+int32_t gn_program_capture(gn_program* p);   /* capture the whole program into a hipGraph on the ctx stream */
+int32_t gn_program_launch(gn_program* p);    /* replay the captured graph */
+
+/* ---- timing helper: HIP events on the ctx stream (bench.py's roofline leg) ------------------------------------- */
+int32_t gn_event_create(void** ev);
+int32_t gn_event_destroy(void* ev);
+int32_t gn_event_record(gn_ctx* ctx, void* ev);
+int32_t gn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int32_t gn_stream_synchronize(gn_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENIMA_HIP_H */

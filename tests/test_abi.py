@@ -1,0 +1,62 @@
+"""-m "not gpu": libgenima_hip.so builds, loads and exports every symbol include/genima_hip.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from genima_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "genima_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_header_symbols():
+    build.build(verbose=False)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 45
+    for n in names:
+        assert hasattr(lib, n), f"libgenima_hip.so does not export {n}"
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_loader_binds_and_reports_version():
+    lib = _lib.load()
+    assert lib.gn_version() == 100
+    assert ctypes.sizeof(_lib.GemmDesc) == 8 * 8 + 8 * 8 + 19 * 4 + 4  # matches the C struct (no hidden padding)
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    from genima_amd import configs
+    from genima_amd.engine import Engine
+    from genima_amd.host import UNet2DConditionModel
+    from genima_amd._lib import GenimaHipError
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(GenimaHipError):
+        Engine("cuda:0")
+    with pytest.raises(GenimaHipError):
+        Engine("cpu")
+    m = UNet2DConditionModel.from_config(configs.TINY_UNET)
+    with pytest.raises(GenimaHipError):
+        m(torch.zeros(1, 4, 16, 16), 999, torch.zeros(1, 77, 128))
+    with pytest.raises(GenimaHipError):
+        m.to("cuda")
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "genima_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"

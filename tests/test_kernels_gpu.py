@@ -1,0 +1,260 @@
+"""-m gpu: per-kernel parity of libgenima_hip.so (through the C ABI via genima_amd.engine) against fp32 torch-CPU
+restatements of the same op on the same f16-rounded inputs (the oracle for floating-point kernels)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, q16, randn_h
+
+pytestmark = pytest.mark.gpu
+
+ACT = {"none": 0, "silu": 1, "gelu": 2, "quick_gelu": 3, "relu": 4}
+
+
+def ref_act(x, act):
+    return {"none": lambda v: v, "silu": F.silu, "gelu": F.gelu, "quick_gelu": lambda v: v * torch.sigmoid(1.702 * v),
+            "relu": F.relu}[act](x)
+
+
+# ---------------------------------------------------------------------------------------------------- GEMM (Linear)
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1000, 320, 320), (77, 1024, 1024), (4096, 640, 2560), (64, 1280, 5120),
+                                   (8, 2560, 1280), (130, 192, 72)])
+@pytest.mark.parametrize("act", ["none", "gelu"])
+def test_linear(engine, M, N, K, act):
+    x, w, b = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5), randn_h(N, seed=3, scale=0.1)
+    r = randn_h(M, N, seed=4)
+    y = engine.linear(x, w, b, act=ACT[act], residual=r)
+    ref = ref_act(x.float().cpu() @ w.float().cpu().t() + b.float().cpu(), act) + r.float().cpu()
+    assert_close(y, ref, what=f"linear {M}x{N}x{K} {act}")
+
+
+def test_linear_transposed_mfma_layout(engine):
+    """A = I with an ASYMMETRIC W catches a row/col swap in the MFMA C/D mapping (cdna_hip_programming.md rule 16)."""
+    K = N = 128
+    x = torch.eye(K, dtype=torch.float16, device="cuda")
+    w = (torch.arange(N * K, dtype=torch.float32).reshape(N, K) % 251 / 64.0).to(torch.float16).cuda()
+    y = engine.linear(x, w)
+    assert torch.equal(y.float().cpu(), w.float().cpu().t())
+
+
+@pytest.mark.parametrize("splitk", [2, 5])
+def test_linear_splitk(engine, splitk):
+    M, N, K = 96, 320, 2560
+    x, w, b = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5), randn_h(N, seed=3)
+    y = engine.linear(x, w, b, act=ACT["silu"], splitk=splitk)
+    ref = F.silu(x.float().cpu() @ w.float().cpu().t() + b.float().cpu())
+    assert_close(y, ref, what=f"splitk {splitk}")
+
+
+def test_linear_auto_splitk_small_m(engine):
+    M, N, K = 64, 1280, 11520
+    x, w = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5)
+    y = engine.linear(x, w)
+    assert_close(y, x.float().cpu() @ w.float().cpu().t(), what="auto splitk")
+
+
+def test_geglu(engine):
+    from genima_amd.packing import pack_geglu
+
+    M, C = 200, 320
+    x = randn_h(M, C, seed=1)
+    w = torch.randn(8 * C, C, generator=torch.Generator().manual_seed(2)) * C ** -0.5
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    wp, bp = pack_geglu(q16(w), q16(b))
+    y = engine.linear(x, wp.cuda(), bp.cuda(), act=5)
+    h = x.float().cpu() @ q16(w).t() + q16(b)
+    hid, gate = h.chunk(2, dim=-1)
+    assert y.shape == (M, 4 * C)
+    assert_close(y, hid * F.gelu(gate), what="geglu")
+
+
+def test_linear_transposed_out(engine):
+    B, L, K, N = 3, 77, 128, 192
+    x, w = randn_h(B, L, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5)
+    vt = engine.linear(x, w, transposed_out=True, rows_per_batch=L, pad_cols=128)
+    ref = (x.float().cpu() @ w.float().cpu().t()).transpose(1, 2)
+    assert vt.shape == (B, N, 128)
+    assert_close(vt[:, :, :L], ref, what="transposed out")
+    assert float(vt[:, :, L:].abs().max()) == 0.0
+
+
+# ---------------------------------------------------------------------------------------------------- conv
+def pack(w):
+    from genima_amd.packing import pack_conv_weight
+
+    return pack_conv_weight(w).cuda()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride", [
+    (2, 64, 64, 16, 16, 3, 1), (1, 320, 320, 32, 32, 3, 1), (2, 128, 256, 17, 23, 3, 2), (1, 640, 320, 8, 8, 1, 1),
+    (1, 8, 320, 64, 64, 3, 1), (2, 16, 32, 40, 40, 3, 2), (1, 96, 96, 24, 24, 3, 1), (1, 320, 8, 32, 32, 3, 1),
+    (1, 8, 64, 64, 64, 7, 2), (1, 1280, 1280, 8, 8, 3, 1)])
+def test_conv2d(engine, B, Cin, Cout, H, W, k, stride):
+    g = torch.Generator().manual_seed(5)
+    x = q16(torch.randn(B, Cin, H, W, generator=g))
+    w = q16(torch.randn(Cout, Cin, k, k, generator=g) * (Cin * k * k) ** -0.5)
+    b = q16(torch.randn(Cout, generator=g) * 0.1)
+    y = engine.conv2d(nhwc(x).half().cuda(), pack(w), b.half().cuda(), ksize=k, stride=stride)
+    ref = F.conv2d(x, w, b, stride=stride, padding=k // 2)
+    assert_close(y, nhwc(ref), what=f"conv {Cin}->{Cout} {H}x{W} k{k} s{stride}")
+
+
+def test_conv2d_fused_epilogue_concat_upsample(engine):
+    """Virtual concat + nearest-2x upsample folded into the gather + time shift + SiLU + residual in one launch."""
+    g = torch.Generator().manual_seed(6)
+    B, C1, C2, Cout, H, W = 2, 64, 128, 192, 12, 10
+    x1, x2 = q16(torch.randn(B, C1, H, W, generator=g)), q16(torch.randn(B, C2, H, W, generator=g))
+    w = q16(torch.randn(Cout, C1 + C2, 3, 3, generator=g) * (9 * (C1 + C2)) ** -0.5)
+    b = q16(torch.randn(Cout, generator=g) * 0.1)
+    sh = q16(torch.randn(B, Cout, generator=g))
+    res = q16(torch.randn(B, Cout, 2 * H, 2 * W, generator=g))
+    y = engine.conv2d(nhwc(x1).half().cuda(), pack(w), b.half().cuda(), x2=nhwc(x2).half().cuda(), shift=sh.half().cuda(),
+                      residual=nhwc(res).half().cuda(), act=1, upsample2x=True)
+    up = F.interpolate(torch.cat([x1, x2], 1), scale_factor=2.0, mode="nearest")
+    ref = F.silu(F.conv2d(up, w, b, padding=1) + sh[:, :, None, None]) + res
+    assert_close(y, nhwc(ref), what="fused conv")
+
+
+def test_conv2d_asymmetric_pad(engine):
+    """VAE encoder downsample: F.pad(0,1,0,1) then 3x3 stride 2 pad 0."""
+    g = torch.Generator().manual_seed(7)
+    x = q16(torch.randn(1, 64, 16, 16, generator=g))
+    w = q16(torch.randn(64, 64, 3, 3, generator=g) / 24.0)
+    y = engine.conv2d(nhwc(x).half().cuda(), pack(w), None, stride=2, pad=(0, 0, 1, 1))
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, None, stride=2)
+    assert_close(y, nhwc(ref), what="asym pad conv")
+
+
+# ---------------------------------------------------------------------------------------------------- attention
+def ref_attention(q, k, v, heads, causal=False):
+    B, Nq, C = q.shape
+    d = C // heads
+    qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    s = qh @ kh.transpose(-1, -2) * d ** -0.5
+    if causal:
+        s = s + torch.full((Nq, k.shape[1]), float("-inf")).triu(1)
+    return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk,D,causal", [
+    (2, 5, 256, 256, 64, False), (1, 2, 1024, 1024, 64, False), (2, 4, 64, 77, 64, False), (2, 16, 77, 77, 64, True),
+    (1, 10, 300, 77, 64, False), (2, 8, 259, 259, 32, False), (1, 8, 20, 259, 32, False), (1, 1, 4096, 4096, 64, False)])
+def test_attention(engine, B, heads, Nq, Nk, D, causal):
+    C = heads * D
+    q, k, v = randn_h(B, Nq, C, seed=1), randn_h(B, Nk, C, seed=2), randn_h(B, Nk, C, seed=3)
+    Np = (Nk + 63) // 64 * 64
+    vt = torch.full((B, C, Np), float("nan"), dtype=torch.float16, device="cuda")  # pad columns are never trusted
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    o = engine.attention(q, k, vt, heads, Nk=Nk, causal=causal)
+    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, causal)
+    assert_close(o, ref, rel=2e-3, what=f"attention {B}x{heads}x{Nq}x{Nk}x{D} causal={causal}")
+
+
+def test_attention_strided_qk_and_spike(engine):
+    """q|k as column slices of one fused projection, and a spiked key forcing a large online-softmax rescale mid-sequence."""
+    B, heads, N, D = 1, 5, 512, 64
+    C = heads * D
+    qk = randn_h(B, N, 2 * C, seed=1)
+    qk[0, 300, C:] *= 6.0
+    v = randn_h(B, N, C, seed=3)
+    vt = v.transpose(1, 2).contiguous()
+    o = engine.attention(qk[:, :, :C], qk[:, :, C:], vt, heads)
+    ref = ref_attention(qk[:, :, :C].float().cpu(), qk[:, :, C:].float().cpu(), v.float().cpu(), heads)
+    assert_close(o, ref, rel=2e-3, what="strided/spiked attention")
+
+
+# ---------------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("B,H,W,C,act", [(2, 64, 64, 320, 1), (1, 8, 8, 1280, 1), (2, 32, 32, 128, 0), (1, 128, 128, 128, 1),
+                                         (1, 16, 16, 2560, 1), (2, 7, 9, 64, 1)])
+def test_groupnorm(engine, B, H, W, C, act):
+    g = torch.Generator().manual_seed(8)
+    x = q16(torch.randn(B, C, H, W, generator=g) * 2.0 + 0.5)
+    gm, bt = q16(1 + 0.1 * torch.randn(C, generator=g)), q16(0.1 * torch.randn(C, generator=g))
+    y = engine.groupnorm(nhwc(x).half().cuda(), gm.half().cuda(), bt.half().cuda(), 32, 1e-5, act=act)
+    ref = F.group_norm(x, 32, gm, bt, 1e-5)
+    ref = F.silu(ref) if act else ref
+    assert_close(y, nhwc(ref), what=f"groupnorm {C}@{H}x{W}")
+
+
+def test_groupnorm_concat(engine):
+    g = torch.Generator().manual_seed(9)
+    x1, x2 = q16(torch.randn(2, 320, 16, 16, generator=g)), q16(torch.randn(2, 640, 16, 16, generator=g) * 3)
+    gm, bt = q16(1 + 0.1 * torch.randn(960, generator=g)), q16(0.1 * torch.randn(960, generator=g))
+    y = engine.groupnorm(nhwc(x1).half().cuda(), gm.half().cuda(), bt.half().cuda(), 32, 1e-5, act=1, x2=nhwc(x2).half().cuda())
+    ref = F.silu(F.group_norm(torch.cat([x1, x2], 1), 32, gm, bt, 1e-5))
+    assert_close(y, nhwc(ref), what="groupnorm concat")
+
+
+@pytest.mark.parametrize("M,C", [(4096, 320), (77, 1024), (1000, 1280), (5, 256), (130, 4096)])
+def test_layernorm(engine, M, C):
+    g = torch.Generator().manual_seed(10)
+    x = q16(torch.randn(M, C, generator=g) * 2 + 1)
+    gm, bt = q16(1 + 0.1 * torch.randn(C, generator=g)), q16(0.1 * torch.randn(C, generator=g))
+    y = engine.layernorm(x.half().cuda(), gm.half().cuda(), bt.half().cuda(), 1e-5)
+    assert_close(y, F.layer_norm(x, (C,), gm, bt, 1e-5), what=f"layernorm {M}x{C}")
+
+
+# ---------------------------------------------------------------------------------------------------- small ops
+def test_timestep_embedding(engine):
+    from oracle.sd_torch import timestep_embedding
+
+    t = torch.tensor([999.0, 799.0, 0.0, 199.0])
+    y = engine.timestep_embedding(t.cuda(), 320)
+    assert_close(y, timestep_embedding(t, 320), what="timestep embedding")
+
+
+def test_euler_and_scale(engine):
+    import numpy as np
+
+    from oracle import scheduler as S
+
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(2, 8, 8, 4, generator=g) * 14.6).half()
+    eps8 = torch.randn(2, 8, 8, 8, generator=g).half()
+    xs = engine.scale_pad(x.cuda(), 0.068265, 8)
+    assert_close(xs[..., :4], x.float() * 0.068265, what="scale_pad")
+    assert float(xs[..., 4:].abs().max()) == 0.0
+    xd = x.clone().cuda()
+    engine.euler_step(xd, eps8.cuda(), 14.614647, 5.087765)
+    ref = S.euler_step(eps8[..., :4].numpy(), 14.614647, 5.087765, x.numpy())
+    assert np.array_equal(xd.cpu().numpy(), ref), "euler step must match the oracle bit-for-bit in f16"
+
+
+def test_image_pre_post(engine):
+    from genima_amd.weights import counter_bytes
+    from oracle.sd_torch import vae_postprocess_u8
+
+    img = torch.from_numpy(counter_bytes(1, "img", 2 * 32 * 32 * 3).reshape(2, 32, 32, 3))
+    f = engine.image_u8_to_f16(img.cuda(), 8)
+    assert torch.equal(f[..., :3].cpu(), (img.float() / 255.0).half())
+    assert float(f[..., 3:].abs().max()) == 0.0
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(2, 16, 16, 8, generator=g) * 0.8).half()
+    u = engine.image_f16_to_u8(x.cuda())
+    ref = vae_postprocess_u8(x[..., :3].permute(0, 3, 1, 2).float())
+    diff = (u.cpu().int() - ref.int()).abs()
+    assert int(diff.max()) <= 1 and float((diff > 0).float().mean()) < 0.02  # f16 (x/2+0.5) vs f32: rare 1-LSB ties
+
+
+def test_misc_ops(engine):
+    a, b = randn_h(4, 33, 64, seed=1), randn_h(4, 33, 64, seed=2)
+    assert_close(engine.add(a, b), a.float().cpu() + b.float().cpu(), what="add")
+    assert_close(engine.act(a, 1), F.silu(a.float().cpu()), what="silu")
+    ids = torch.tensor([[5, 1, 0, 7], [2, 2, 9, 3]], dtype=torch.int32)
+    tok, pos = randn_h(10, 64, seed=3), randn_h(4, 64, seed=4)
+    e = engine.embedding(ids.cuda(), tok, pos)
+    assert_close(e, tok.float().cpu()[ids.long()] + pos.float().cpu()[None], what="embedding")
+    s = randn_h(37, 4096, seed=5, scale=3.0)
+    ref = torch.softmax(s.float().cpu() * 0.25, -1)
+    engine.softmax_rows(s, 0.25)
+    assert_close(s, ref, what="softmax rows")
+    x = randn_h(2, 17, 19, 64, seed=6)
+    mp = engine.maxpool3x3s2(x)
+    ref = F.max_pool2d(x.float().cpu().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(mp.float().cpu(), ref)
