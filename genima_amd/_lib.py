@@ -117,6 +117,12 @@ def load() -> C.CDLL:
         raise GenimaHipError(
             f"{LIB_PATH} is missing: build it with `python -m genima_amd.build` (hipcc --offload-arch=gfx950). "
             "The Genima HIP path has no CPU/eager fallback.")
+    # torch owns the device memory and streams we are handed, so libgenima_hip.so must bind to the SAME HIP runtime instance
+    # torch loaded (its bundled libamdhip64, same SONAME): import + initialise torch first, then dlopen.
+    import torch
+
+    if torch.cuda.is_available():
+        torch.cuda.init()
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover

@@ -23,17 +23,19 @@ struct GNParams {
 };
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
-  extern __shared__ float lds[];  // [C] sums, [C] sumsq
+  // LDS: per-(pixel-lane, channel) partial sums [PY][C] and sums of squares [PY][C]; every slot has exactly one writer and
+  // the group reduction below walks them in a fixed order, so the statistics are bit-reproducible run to run.
+  extern __shared__ float lds[];
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int CC = p.C >> 3;
-  for (int i = tid; i < 2 * p.C; i += 256) lds[i] = 0.0f;
-  __syncthreads();
   const int TX = CC < 256 ? CC : 256;
   const int PY = 256 / TX;
   const int cxt = tid % TX, py = tid / TX;
   const int r0 = chunk * p.rows;
   const int r1 = min(p.HW, r0 + p.rows);
+  float* lsum = lds;
+  float* lsq = lds + PY * p.C;
   if (py < PY) {
     for (int cx = cxt; cx < CC; cx += TX) {
       const int c0 = cx * 8;
@@ -51,15 +53,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        atomicAdd(&lds[c0 + e], s[e]);
-        atomicAdd(&lds[p.C + c0 + e], ss[e]);
+        lsum[py * p.C + c0 + e] = s[e];
+        lsq[py * p.C + c0 + e] = ss[e];
       }
     }
   }
   __syncthreads();
   if (tid < p.G) {
     float s = 0.f, ss = 0.f;
-    for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c) { s += lds[c]; ss += lds[p.C + c]; }
+    for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c)
+      for (int y = 0; y < PY; ++y) { s += lsum[y * p.C + c]; ss += lsq[y * p.C + c]; }
     float* out = p.partials + (((long)b * p.chunks + chunk) * p.G + tid) * 2;
     out[0] = s;
     out[1] = ss;
@@ -207,7 +210,8 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.act = d->act; p.eps = d->eps;
   p.partials = (float*)d->workspace;
   p.scsh = p.partials + (long)d->B * gn_pick_chunks(d->B, d->HW) * d->groups * 2;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * C * sizeof(float), ctx->stream, p);
+  const int cc = C >> 3, tx = cc < 256 ? cc : 256, pyn = 256 / tx;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();

@@ -54,6 +54,7 @@ class Engine:
         self._keep = []  # tensors referenced by recorded ops
         self._scope = []
         self.captured = False
+        self.meta = []  # per recorded op: dict(kind, flops, bytes) -- algorithmic work for the roofline accounting
 
     # ------------------------------------------------------------------------------------------------ housekeeping
     def __del__(self):
@@ -139,6 +140,10 @@ class Engine:
         if self.record:
             check(self.lib.gn_program_add_gemm(self._prog, C.byref(d)), "gn_program_add_gemm")
             self._keepalive(*keep, ws)
+            kind = (f"conv{d.KH}x{d.KW}" if d.conv else "linear")
+            n_out = d.N // 2 if d.act == ACT_GEGLU else d.N
+            self.meta.append(dict(kind=kind, flops=2.0 * d.M * d.N * d.K, bytes=2.0 * (d.M * d.K / max(1, d.KH * d.KW if d.conv else 1) + d.N * d.K + d.M * n_out),
+                                  shape=(int(d.M), int(d.N), int(d.K))))
         else:
             check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm")
 
@@ -233,6 +238,8 @@ class Engine:
         if self.record:
             check(self.lib.gn_program_add_attention(self._prog, C.byref(d)), "gn_program_add_attention")
             self._keepalive(q, k, vt, out)
+            fl = 4.0 * B * heads * Nq * Nk * D * (0.5 if causal else 1.0)
+            self.meta.append(dict(kind="attention", flops=fl, bytes=2.0 * B * Cq * (2 * Nq + 2 * Nk), shape=(B, heads, Nq, Nk, D)))
         else:
             check(self.lib.gn_attention_fwd(self._ctx, C.byref(d)), "gn_attention_fwd")
         return out
@@ -255,6 +262,7 @@ class Engine:
         if self.record:
             check(self.lib.gn_program_add_groupnorm(self._prog, C.byref(d)), "gn_program_add_groupnorm")
             self._keepalive(x, x2, gamma, beta, out, ws)
+            self.meta.append(dict(kind="groupnorm", flops=0.0, bytes=2.0 * 2 * B * HW * (C1 + C2), shape=(B, HW, C1 + C2)))
         else:
             check(self.lib.gn_groupnorm_fwd(self._ctx, C.byref(d)), "gn_groupnorm_fwd")
         return out
@@ -269,6 +277,7 @@ class Engine:
         if self.record:
             check(self.lib.gn_program_add_layernorm(self._prog, *args), "gn_program_add_layernorm")
             self._keepalive(x, gamma, beta, out)
+            self.meta.append(dict(kind="layernorm", flops=0.0, bytes=2.0 * 2 * M * Cc, shape=(M, Cc)))
         else:
             check(self.lib.gn_layernorm_fwd(self._ctx, *args), "gn_layernorm_fwd")
         return out
@@ -278,6 +287,7 @@ class Engine:
         if self.record:
             check(getattr(self.lib, "gn_program_add_" + fn_name)(self._prog, *args), "gn_program_add_" + fn_name)
             self._keepalive(*keep)
+            self.meta.append(dict(kind=fn_name, flops=0.0, bytes=float(sum(t.numel() * t.element_size() for t in keep if t is not None)), shape=()))
         else:
             check(getattr(self.lib, "gn_" + fn_name)(self._ctx, *args), "gn_" + fn_name)
 

@@ -53,11 +53,11 @@ class HipModule:
     default_config = None
     weight_name = "diffusion_pytorch_model.safetensors"
 
-    def __init__(self, config: dict, state_dict=None, seed: int = 0):
+    def __init__(self, config: dict, state_dict=None, seed: int = 0, gen_device="cpu"):
         self.config = FrozenConfig(copy.deepcopy(dict(config)))
         self._schema = type(self).schema_fn(self.config)
         if state_dict is None:
-            state_dict = weights.synth_state_dict(self._schema, seed)
+            state_dict = weights.synth_state_dict(self._schema, seed, device=gen_device)
         self._check(state_dict)
         self._sd = OrderedDict((k, state_dict[k].detach().to(torch.float32)) for k in self._schema)
         self.device = torch.device("cpu")
@@ -76,8 +76,9 @@ class HipModule:
                 raise ValueError(f"{type(self).__name__}: {k} has shape {tuple(sd[k].shape)}, expected {tuple(shp)}")
 
     @classmethod
-    def from_config(cls, config, seed: int = 0):
-        return cls(config, None, seed)
+    def from_config(cls, config, seed: int = 0, gen_device="cpu"):
+        """Random-init module with the seeded synthetic weights of weights.synth_state_dict (drawn on ``gen_device``)."""
+        return cls(config, None, seed, gen_device)
 
     @classmethod
     def from_pretrained(cls, path, subfolder: Optional[str] = None, torch_dtype=None, variant=None, **kw):

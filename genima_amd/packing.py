@@ -26,13 +26,13 @@ def pack_conv_weight(w: torch.Tensor, cin_splits=None) -> torch.Tensor:
     must already be a multiple of 8)."""
     O, I, KH, KW = w.shape
     Ip, Op = _rup(I, 8), _rup(O, 8)
-    p = torch.zeros((Op, KH, KW, Ip), dtype=torch.float32)
+    p = torch.zeros((Op, KH, KW, Ip), dtype=torch.float32, device=w.device)
     p[:O, :, :, :I] = w.permute(0, 2, 3, 1)
     return p.reshape(Op, KH * KW * Ip).to(torch.float16).contiguous()
 
 
 def pack_vec(b: torch.Tensor, n_pad: int) -> torch.Tensor:
-    out = torch.zeros((n_pad,), dtype=torch.float32)
+    out = torch.zeros((n_pad,), dtype=torch.float32, device=b.device)
     out[: b.numel()] = b
     return out.to(torch.float16).contiguous()
 
@@ -53,26 +53,26 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device) -> "OrderedDict[str, to
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     temb_w, temb_b, temb_slices, off = [], [], OrderedDict(), 0
     for name, t in sd.items():
-        t = t.detach().to(torch.float32).cpu()
+        t = t.detach().to(torch.float32)
         if t.dim() == 4:
             out[name] = pack_conv_weight(t)
             bn = name[: -len("weight")] + "bias"
             if bn in sd:
-                out[bn] = pack_vec(sd[bn].detach().float().cpu(), out[name].shape[0])
+                out[bn] = pack_vec(sd[bn].detach().float(), out[name].shape[0])
         elif t.dim() == 2:
             if name.endswith("ff.net.0.proj.weight"):
                 bn = name[: -len("weight")] + "bias"
-                wp, bp = pack_geglu(t, sd[bn].detach().float().cpu())
+                wp, bp = pack_geglu(t, sd[bn].detach().float())
                 out[name], out[bn] = wp, bp
                 continue
             if name.endswith("time_emb_proj.weight"):
                 bn = name[: -len("weight")] + "bias"
                 temb_w.append(t)
-                temb_b.append(sd[bn].detach().float().cpu())
+                temb_b.append(sd[bn].detach().float())
                 temb_slices[name[: -len(".time_emb_proj.weight")]] = (off, t.shape[0])
                 off += t.shape[0]
             if t.shape[1] % 8 != 0:  # pad the reduction dim
-                tp = torch.zeros((t.shape[0], _rup(t.shape[1], 8)))
+                tp = torch.zeros((t.shape[0], _rup(t.shape[1], 8)), device=t.device)
                 tp[:, : t.shape[1]] = t
                 t = tp
             out[name] = t.to(torch.float16).contiguous()

@@ -111,12 +111,12 @@ class StableDiffusionControlNetPipeline:
         return cls(vae, text, tok, unet, controlnet, sched, safety_checker)
 
     @classmethod
-    def from_synthetic(cls, family: dict, seed: int = 0):
+    def from_synthetic(cls, family: dict, seed: int = 0, gen_device="cpu"):
         """Random-init pipeline of a config family (no checkpoints exist offline; SURVEY.md section 8d synthetic weights)."""
-        unet = UNet2DConditionModel.from_config(family["unet"], seed + 1)
-        cn = ControlNetModel.from_config(family["controlnet"], seed + 2)
-        vae = AutoencoderKL.from_config(family["vae"], seed + 3)
-        text = CLIPTextModel.from_config(family["text"], seed + 4)
+        unet = UNet2DConditionModel.from_config(family["unet"], seed + 1, gen_device)
+        cn = ControlNetModel.from_config(family["controlnet"], seed + 2, gen_device)
+        vae = AutoencoderKL.from_config(family["vae"], seed + 3, gen_device)
+        text = CLIPTextModel.from_config(family["text"], seed + 4, gen_device)
         return cls(vae, text, None, unet, cn, EulerDiscreteScheduler.from_config(family["scheduler"]))
 
     # ---- knobs the agent calls (controller/agent/diffusion_agent.py:21-42) -------------------------------------------------
@@ -158,10 +158,13 @@ class StableDiffusionControlNetPipeline:
         io = SimpleNamespace()
         io.ids = E.buf("in_ids", (B, L), dtype=torch.int32, zero=True)
         io.image_u8 = E.buf("in_image", (B, H, W, 3), dtype=torch.uint8, zero=True)
-        io.latents = E.buf("latents", (B, h, w, self.unet.config["in_channels"]), zero=True)
+        Cl = self.unet.config["in_channels"]
+        io.noise = E.buf("in_noise", (B, h, w, Cl), zero=True)       # unit-variance draws (randn_tensor), NHWC
+        io.latents = E.buf("latents", (B, h, w, Cl), zero=True)
         sch = self.scheduler
         sch.set_timesteps(steps)
         io.timesteps = [int(t) for t in sch.timesteps.tolist()]
+        E.scale_pad(io.noise, sch.init_noise_sigma, Cl, out=io.latents)  # latents = randn * init_noise_sigma
 
         ctx = graphs.emit_clip_text(E, self.text_encoder.W, self.text_encoder.config, io.ids)
         kv_cn = graphs.emit_cross_kv(E, self.controlnet.W, ctx, "cn")
@@ -241,9 +244,8 @@ class StableDiffusionControlNetPipeline:
         sch.set_timesteps(num_inference_steps)
         if latents is None:
             latents = randn_latents((B, C, H // s, W // s), generator, self.device)
-            latents = latents * sch.init_noise_sigma
         else:
-            latents = latents.to(self.device, torch.float16) * sch.init_noise_sigma
+            latents = latents.to(self.device, torch.float16)  # unit-variance, scaled by init_noise_sigma on the device
         if sch.draws_step_noise and generator is not None:
             for _ in range(num_inference_steps):  # mirror diffusers 0.29.0's per-step (unused) randn draw
                 randn_latents((B, C, H // s, W // s), generator, self.device)
@@ -251,7 +253,7 @@ class StableDiffusionControlNetPipeline:
         cur = torch.cuda.current_stream(self.device)
         io.ids.copy_(prompt_ids.to(torch.int32), non_blocking=False)
         io.image_u8.copy_(img_u8)
-        io.latents.copy_(latents.permute(0, 2, 3, 1))
+        io.noise.copy_(latents.permute(0, 2, 3, 1))
         if stream is not None:
             stream.wait_stream(cur)
             E.launch()

@@ -60,6 +60,36 @@ def counter_uniform(seed: int, name: str, n: int) -> np.ndarray:
     return out
 
 
+def _s64(x: int) -> int:
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _lsr(x: torch.Tensor, k: int) -> torch.Tensor:
+    return (x >> k) & ((1 << (64 - k)) - 1)  # logical shift on two's-complement int64
+
+
+def _splitmix64_t(x: torch.Tensor) -> torch.Tensor:
+    x = x + _s64(0x9E3779B97F4A7C15)
+    z = (x ^ _lsr(x, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ _lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    return z ^ _lsr(z, 31)
+
+
+def counter_uniform_torch(seed: int, name: str, n: int, device) -> torch.Tensor:
+    """Bit-identical to ``counter_uniform`` (tests/test_cpu_oracle.py) but runs as int64 torch ops on ``device`` -- the
+    1.65 G synthetic parameters of the full SD-Turbo family are drawn on the GPU in seconds instead of minutes of numpy."""
+    b0 = torch.tensor([_s64(seed * 0x9E3779B97F4A7C15 + _fnv1a64(name))], dtype=torch.int64, device=device)
+    base = _splitmix64_t(b0)
+    out = torch.empty(n, dtype=torch.float32, device=device)
+    chunk = 1 << 26
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        z = _splitmix64_t(torch.arange(s, e, dtype=torch.int64, device=device) + base)
+        out[s:e] = _lsr(z, 40).to(torch.float32) * (1.0 / (1 << 24)) * 2.0 - 1.0
+    return out
+
+
 def counter_bytes(seed: int, name: str, n: int) -> np.ndarray:
     """``n`` uint8 values (synthetic images)."""
     u = counter_uniform(seed, name, n)
@@ -88,18 +118,22 @@ def _init_rule(name: str, shape):
     return ("uniform", _SQRT3 / max(fan_in, 1) ** 0.5)
 
 
-def synth_state_dict(schema: "OrderedDict[str, tuple]", seed: int, prefix: str = "") -> "OrderedDict[str, torch.Tensor]":
-    """fp32 master state dict for ``schema`` (see module docstring)."""
+def synth_state_dict(schema: "OrderedDict[str, tuple]", seed: int, prefix: str = "", device="cpu") -> "OrderedDict[str, torch.Tensor]":
+    """fp32 master state dict for ``schema`` (see module docstring).  ``device='cuda'`` draws on the GPU (same bits)."""
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    on_cpu = torch.device(device).type == "cpu"
     for name, shape in schema.items():
         n = int(np.prod(shape)) if len(shape) else 1
         kind, scale = _init_rule(name, shape)
-        u = counter_uniform(seed, prefix + name, n)
-        if kind == "gamma":
-            v = 1.0 + scale * u
+        if on_cpu:
+            u = torch.from_numpy(counter_uniform(seed, prefix + name, n))
         else:
-            v = scale * u
-        sd[name] = torch.from_numpy(np.ascontiguousarray(v.astype(np.float32)).reshape(shape))
+            u = counter_uniform_torch(seed, prefix + name, n, device)
+        # identical f32 op order on both paths: scale * u (+ 1.0)
+        v = u * np.float32(scale)
+        if kind == "gamma":
+            v = v + 1.0
+        sd[name] = v.reshape(shape)
     return sd
 
 

