@@ -81,6 +81,20 @@ def per_op_profile(pipe, io):
     return agg
 
 
+def host_threads() -> int:
+    """Threads the CPU baseline may use: the scheduler affinity, capped by the cgroup CPU quota (the GPU boxes expose 256
+    logical CPUs but cap the container at cpu.max = 16 CPUs; oversubscribing made torch 30x slower.  2 threads per quota CPU
+    measured best: tools/probe_cpu.py)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, 2 * int(round(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(max_seconds=30.0):
     """fp32 torch-CPU oracle on a bounded sample of the same workload: one denoise step (ControlNet + UNet forward) at full
     SD-Turbo width, B=1, latent 32x32 (one 256x256 view) -- 244.2 GFLOP algorithmic.  Scaled to the metric's unit by FLOPs:
@@ -88,12 +102,13 @@ def cpu_baseline(max_seconds=30.0):
     from genima_amd import configs, schema, weights
     from oracle import sd_torch as O
 
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     torch.set_num_threads(cores)
     fam = configs.family("sd-turbo")
     t0 = time.time()
-    usd = weights.synth_state_dict(schema.unet_schema(fam["unet"]), 21)
-    csd = weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), 22)
+    gdev = "cuda" if torch.cuda.is_available() else "cpu"  # draw on the GPU (same bits as the numpy path), copy to host
+    usd = {k: v.cpu() for k, v in weights.synth_state_dict(schema.unet_schema(fam["unet"]), 21, device=gdev).items()}
+    csd = {k: v.cpu() for k, v in weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), 22, device=gdev).items()}
     gen_s = time.time() - t0
     g = torch.Generator().manual_seed(0)
     x, ctx = torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, 77, 1024, generator=g)

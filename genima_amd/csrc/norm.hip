@@ -18,8 +18,20 @@ struct GNParams {
   const f16* x; const f16* x2; const f16* gamma; const f16* beta; f16* y;
   float* partials;  // [B][chunks][G][2]
   float* scsh;      // [B][C][2]
-  int B, HW, C1, C2, C, G, cpg, chunks, rows, act;
+  int B, HW, C1, C2, C, G, cpg, chunks, rows, achunks, arows, act;
   float eps;
+};
+
+// (channel-chunk, pixel-lane) thread mapping shared by the stats and apply kernels: TX = min(C/8, 256) lanes walk the
+// 16-byte channel chunks of a pixel (fully coalesced), PY = 256 / TX pixel lanes walk the rows of the block's slab.
+struct GNMap {
+  int TX, PY, cxt, py;
+  __device__ GNMap(int CC, int tid) {
+    TX = CC < 256 ? CC : 256;
+    PY = 256 / TX;
+    cxt = tid % TX;
+    py = tid / TX;
+  }
 };
 
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
@@ -29,32 +41,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x, b = blockIdx.y;
   const int CC = p.C >> 3;
-  const int TX = CC < 256 ? CC : 256;
-  const int PY = 256 / TX;
-  const int cxt = tid % TX, py = tid / TX;
+  const GNMap mp(CC, tid);
   const int r0 = chunk * p.rows;
   const int r1 = min(p.HW, r0 + p.rows);
   float* lsum = lds;
-  float* lsq = lds + PY * p.C;
-  if (py < PY) {
-    for (int cx = cxt; cx < CC; cx += TX) {
+  float* lsq = lds + mp.PY * p.C;
+  if (mp.py < mp.PY) {
+    for (int cx = mp.cxt; cx < CC; cx += mp.TX) {
       const int c0 = cx * 8;
       const f16* src;
       int cs, co;
       if (c0 < p.C1) { src = p.x; cs = p.C1; co = c0; } else { src = p.x2; cs = p.C2; co = c0 - p.C1; }
+      src += (long)b * p.HW * cs + co;
       float s[8], ss[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
-      for (int r = r0 + py; r < r1; r += PY) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(src + ((long)b * p.HW + r) * cs + co);
+      int r = r0 + mp.py;
+      for (; r + 3 * mp.PY < r1; r += 4 * mp.PY) {  // 4 independent 16-byte loads in flight per lane
+        uint4 raw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(src + (long)(r + u * mp.PY) * cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f16x8 v = *reinterpret_cast<const f16x8*>(&raw[u]);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; ss[e] += f * f; }
+        }
+      }
+      for (; r < r1; r += mp.PY) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(src + (long)r * cs);
         const f16x8 v = *reinterpret_cast<const f16x8*>(&raw);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; ss[e] += f * f; }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        lsum[py * p.C + c0 + e] = s[e];
-        lsq[py * p.C + c0 + e] = ss[e];
+        lsum[mp.py * p.C + c0 + e] = s[e];
+        lsq[mp.py * p.C + c0 + e] = ss[e];
       }
     }
   }
@@ -62,7 +85,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
   if (tid < p.G) {
     float s = 0.f, ss = 0.f;
     for (int c = tid * p.cpg; c < (tid + 1) * p.cpg; ++c)
-      for (int y = 0; y < PY; ++y) { s += lsum[y * p.C + c]; ss += lsq[y * p.C + c]; }
+      for (int y = 0; y < mp.PY; ++y) { s += lsum[y * p.C + c]; ss += lsq[y * p.C + c]; }
     float* out = p.partials + (((long)b * p.chunks + chunk) * p.G + tid) * 2;
     out[0] = s;
     out[1] = ss;
@@ -70,62 +93,99 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
 }
 
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const GNParams p) {
+  // all 256 threads share the partial reduction: thread (g, part) sums chunks part, part + P, ... (independent loads), the
+  // P part sums are then combined in a fixed order -> deterministic, and the dependent-load chain is chunks / P long.
+  __shared__ double dsum[256], dsq[256];
   __shared__ float mean_s[256], rstd_s[256];
   const int tid = threadIdx.x, b = blockIdx.x;
-  if (tid < p.G) {
-    double s = 0.0, ss = 0.0;
-    for (int ch = 0; ch < p.chunks; ++ch) {
-      const float* in = p.partials + (((long)b * p.chunks + ch) * p.G + tid) * 2;
-      s += (double)in[0];
-      ss += (double)in[1];
+  const int P = 256 / p.G;
+  const int g = tid % p.G, part = tid / p.G;
+  double s = 0.0, ss = 0.0;
+  if (part < P) {
+    for (int ch = part; ch < p.chunks; ch += P) {
+      const float2 in = *reinterpret_cast<const float2*>(p.partials + (((long)b * p.chunks + ch) * p.G + g) * 2);
+      s += (double)in.x;
+      ss += (double)in.y;
     }
+  }
+  dsum[tid] = s;
+  dsq[tid] = ss;
+  __syncthreads();
+  if (tid < p.G) {
+    double ts = 0.0, tss = 0.0;
+    for (int q = 0; q < P; ++q) { ts += dsum[q * p.G + tid]; tss += dsq[q * p.G + tid]; }
     const double n = (double)p.HW * (double)p.cpg;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
+    const double mean = ts / n;
+    double var = tss / n - mean * mean;
     if (var < 0.0) var = 0.0;
     mean_s[tid] = (float)mean;
     rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
   }
   __syncthreads();
   for (int c = tid; c < p.C; c += 256) {
-    const int g = c / p.cpg;
-    const float a = rstd_s[g] * (float)p.gamma[c];
+    const int gg = c / p.cpg;
+    const float a = rstd_s[gg] * (float)p.gamma[c];
     float* o = p.scsh + ((long)b * p.C + c) * 2;
     o[0] = a;
-    o[1] = (float)p.beta[c] - mean_s[g] * a;
+    o[1] = (float)p.beta[c] - mean_s[gg] * a;
   }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
+  // same (chunk, pixel-lane) mapping as the stats kernel: a lane keeps the scale/shift of its 8 channels in registers and
+  // streams its rows -- per element traffic is one 16-byte load + one 16-byte store, nothing else.
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x, b = blockIdx.y;
   const int CC = p.C >> 3;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (idx >= (long)p.HW * CC) return;
-  const int r = (int)(idx / CC);
-  const int c0 = (int)(idx - (long)r * CC) * 8;
-  const f16* src;
-  int cs, co;
-  if (c0 < p.C1) { src = p.x; cs = p.C1; co = c0; } else { src = p.x2; cs = p.C2; co = c0 - p.C1; }
-  const long pix = (long)b * p.HW + r;
-  const uint4 raw = *reinterpret_cast<const uint4*>(src + pix * cs + co);
-  const f16x8 v = *reinterpret_cast<const f16x8*>(&raw);
-  const f32x4* sc = reinterpret_cast<const f32x4*>(p.scsh + ((long)b * p.C + c0) * 2);
-  f16x8 o;
+  const GNMap mp(CC, tid);
+  if (mp.py >= mp.PY) return;
+  const int r0 = chunk * p.arows;
+  const int r1 = min(p.HW, r0 + p.arows);
+  for (int cx = mp.cxt; cx < CC; cx += mp.TX) {
+    const int c0 = cx * 8;
+    const f16* src;
+    int cs, co;
+    if (c0 < p.C1) { src = p.x; cs = p.C1; co = c0; } else { src = p.x2; cs = p.C2; co = c0 - p.C1; }
+    src += (long)b * p.HW * cs + co;
+    f16* dst = p.y + (long)b * p.HW * p.C + c0;
+    float a[8], sft[8];
+    {
+      const f32x4* sc = reinterpret_cast<const f32x4*>(p.scsh + ((long)b * p.C + c0) * 2);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const f32x4 q = sc[e];  // (a0, s0, a1, s1)
-    float y0 = (float)v[2 * e] * q[0] + q[1];
-    float y1 = (float)v[2 * e + 1] * q[2] + q[3];
-    if (p.act == GN_ACT_SILU) { y0 = act_silu(y0); y1 = act_silu(y1); }
-    o[2 * e] = (f16)y0;
-    o[2 * e + 1] = (f16)y1;
+      for (int e = 0; e < 4; ++e) {
+        const f32x4 q = sc[e];
+        a[2 * e] = q[0]; sft[2 * e] = q[1]; a[2 * e + 1] = q[2]; sft[2 * e + 1] = q[3];
+      }
+    }
+    auto body = [&](const uint4& raw, int r) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(&raw);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float yv = (float)v[e] * a[e] + sft[e];
+        if (p.act == GN_ACT_SILU) yv = act_silu(yv);
+        o[e] = (f16)yv;
+      }
+      *reinterpret_cast<uint4*>(dst + (long)r * p.C) = *reinterpret_cast<uint4*>(&o);
+    };
+    int r = r0 + mp.py;
+    for (; r + 3 * mp.PY < r1; r += 4 * mp.PY) {
+      uint4 raw[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint4*>(src + (long)(r + u * mp.PY) * cs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) body(raw[u], r + u * mp.PY);
+    }
+    for (; r < r1; r += mp.PY) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(src + (long)r * cs);
+      body(raw, r);
+    }
   }
-  *reinterpret_cast<uint4*>(p.y + pix * p.C + c0) = *reinterpret_cast<uint4*>(&o);
 }
 
 int gn_pick_chunks(int B, int HW) {
-  long c = cdiv64(2048, B);
-  const long maxc = cdiv64(HW, 8);
+  long c = cdiv64(1024, B);
+  const long maxc = cdiv64(HW, 16);
   if (c > maxc) c = maxc;
   if (c < 1) c = 1;
   return (int)c;
@@ -211,12 +271,19 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.partials = (float*)d->workspace;
   p.scsh = p.partials + (long)d->B * gn_pick_chunks(d->B, d->HW) * d->groups * 2;
   const int cc = C >> 3, tx = cc < 256 ? cc : 256, pyn = 256 / tx;
+  {  // apply slabs: ~4096 blocks over the chip, at least 4 rows per pixel lane
+    long ac = cdiv64(4096, d->B);
+    const long maxc = cdiv64(d->HW, 4 * pyn);
+    if (ac > maxc) ac = maxc;
+    if (ac < 1) ac = 1;
+    p.arows = (int)cdiv64(d->HW, ac);
+    p.achunks = (int)cdiv64(d->HW, p.arows);
+  }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
-  const long per_b = (long)p.HW * (C >> 3);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)cdiv64(per_b, 256), p.B), dim3(256), 0, ctx->stream, p);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(p.achunks, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
