@@ -57,7 +57,7 @@ def synthetic_inputs(pipe, B, H, W, device, rank):
     return ids.to(device), img.to(device), lat.to(device)
 
 
-def per_op_profile(pipe, io):
+def per_op_profile(pipe, io, dump=None):
     """Replay the recorded program once op by op with HIP events on the engine's stream; aggregate by kernel family."""
     E = io.engine
     n = E.num_ops
@@ -69,8 +69,14 @@ def per_op_profile(pipe, io):
         E.event_record(evs[i + 1])
     E.synchronize()
     agg = {}
+    by_shape = {}
     for i, m in enumerate(E.meta[:n]):
         ms = E.event_elapsed_ms(evs[i], evs[i + 1])
+        s = by_shape.setdefault((m["kind"], tuple(m["shape"])), dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        s["ms"] += ms
+        s["flops"] += m["flops"]
+        s["bytes"] += m["bytes"]
+        s["launches"] += 1
         a = agg.setdefault(m["kind"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
         a["ms"] += ms
         a["flops"] += m["flops"]
@@ -78,6 +84,12 @@ def per_op_profile(pipe, io):
         a["launches"] += 1
     for ev in evs:
         E.lib.gn_event_destroy(ev)
+    if dump:
+        with open(dump, "w") as f:
+            f.write("kind,shape,launches,total_ms,avg_us,TFLOP/s,GB/s\n")
+            for (k, shp), a in sorted(by_shape.items(), key=lambda kv: -kv[1]["ms"]):
+                f.write(f"{k},{'x'.join(map(str, shp))},{a['launches']},{a['ms']:.3f},{1000 * a['ms'] / a['launches']:.1f},"
+                        f"{a['flops'] / (a['ms'] * 1e-3) / 1e12:.1f},{a['bytes'] / (a['ms'] * 1e-3) / 1e9:.0f}\n")
     return agg
 
 
@@ -141,6 +153,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay each call as one captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write the per-(kernel, shape) HIP-event timing table of one call to this CSV")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -220,7 +233,7 @@ def main():
         io = pipe.program(B, H, W, args.denoise_steps)
         if args.graph:
             io.engine.use_stream(io.stream)
-        agg = per_op_profile(pipe, io)
+        agg = per_op_profile(pipe, io, args.dump_ops)
         gemm_kinds = [k for k in agg if k.startswith("conv") or k == "linear"]
         g_ms = sum(agg[k]["ms"] for k in gemm_kinds)
         g_fl = sum(agg[k]["flops"] for k in gemm_kinds)
