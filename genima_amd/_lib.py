@@ -63,6 +63,7 @@ SIGNATURES = {
     "gn_ctx_set_stream": (_I32, [_P, _P]),
     "gn_gemm_workspace_bytes": (_I64, [C.POINTER(GemmDesc)]),
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
+    "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
     "gn_groupnorm_workspace_bytes": (_I64, [C.POINTER(GroupNormDesc)]),
     "gn_groupnorm_fwd": (_I32, [_P, C.POINTER(GroupNormDesc)]),

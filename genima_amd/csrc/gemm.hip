@@ -7,21 +7,25 @@
 //   * activations are NHWC f16, so a conv's A operand is an on-the-fly gather of 16-byte channel chunks
 //     (tap-major K = KH*KW*Cin) and a Linear's A operand is the same loader with a dense row stride;
 //   * weights are [N][K] f16 (K contiguous) for both;
-//   * BMxBNx64 block tile, 4 waves, v_mfma_f32_32x32x16_f16 with f32 accumulation;
+//   * BMxBNx64 block tile, 4 or 8 waves, v_mfma_f32_32x32x16_f16 with f32 accumulation;
 //   * global -> registers -> LDS staging, double-buffered, next tile's loads in flight under the current tile's MFMAs
 //     (one barrier per K tile); LDS rows are 128 B with the XOR swizzle of common.h (conflict-free ds_read_b128);
+//   * the conv gather keeps, per staged row, the source pixel of the CURRENT filter tap (or -1 when the tap falls in the
+//     padding); it is recomputed only when the K walk crosses into the next tap (every Cin/64 tiles), so the per-tile cost
+//     of a gathered load is one multiply-add -- the same as the dense loader;
 //   * operands are swapped (D = W_tile * A_tile^T) so each lane ends up with 4 consecutive output channels of one output
 //     row: 8-byte bias / residual loads and 8-byte stores in the epilogue;
 //   * epilogue fuses bias, per-batch time-embedding shift, SiLU/GELU/QuickGELU/ReLU/GEGLU, scale and residual add;
 //   * optional split-K over gridDim.y with an f32 workspace and a fused reduce+epilogue kernel (small-M layers);
 //   * blockIdx -> tile mapping is XCD-aware (each XCD walks a contiguous run of tiles, N fastest, so the A rows an XCD's L2
 //     holds are reused across the N tiles).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BK = 64;          // K tile (f16 elements) = 128-byte LDS rows
-constexpr int NTHREADS = 256;   // 4 waves
+constexpr int BK = 64;  // K tile (f16 elements) = 128-byte LDS rows
 
 struct GemmParams {
   const f16* a;
@@ -41,6 +45,26 @@ struct GemmParams {
   int tiles_m, tiles_n;
 };
 
+// erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below f16 resolution): ~12 VALU instead of ocml erff's ~50, which
+// matters because the GEGLU / GELU epilogues run on K = 320..1280 GEMMs where the epilogue is a visible share of the tile time.
+__device__ __forceinline__ float fast_erf(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.0f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gemm_act(float x, int act) {
+  switch (act) {
+    case GN_ACT_SILU: return act_silu(x);
+    case GN_ACT_GELU: return gelu_fast(x);
+    case GN_ACT_QUICK_GELU: return act_quick_gelu(x);
+    case GN_ACT_RELU: return fmaxf(x, 0.0f);
+    default: return x;
+  }
+}
+
 // ---- epilogue for 4 consecutive output channels [nb, nb+4) of row m -------------------------------------------------
 __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int nb, float v0, float v1, float v2, float v3) {
   float v[4] = {v0, v1, v2, v3};
@@ -58,7 +82,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
   }
   if (p.act != GN_ACT_NONE) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = apply_act(v[i], p.act);
+    for (int i = 0; i < 4; ++i) v[i] = gemm_act(v[i], p.act);
   }
   if (p.out_scale != 1.0f) {
 #pragma unroll
@@ -82,7 +106,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
   }
 }
 
-// GEGLU: hidden block hb (4 consecutive packed rows) and the matching gate block -> 4 output columns at oc.
+// GEGLU: 4 consecutive packed hidden rows at nh and the matching gate rows at ng -> 4 output columns at oc.
 __device__ __forceinline__ void epilogue_geglu4(const GemmParams& p, int m, int nh, int ng, int oc, const float* h,
                                                 const float* g) {
   float hv[4], gv[4];
@@ -96,17 +120,19 @@ __device__ __forceinline__ void epilogue_geglu4(const GemmParams& p, int m, int 
   }
   f16x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (f16)(hv[i] * act_gelu(gv[i]));
+  for (int i = 0; i < 4; ++i) o[i] = (f16)(hv[i] * gelu_fast(gv[i]));
   *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + oc) = o;
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
-  static_assert(WM * WN == 4, "4 waves");
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int RPP = NT / 8;  // tile rows staged per pass (8 lanes x 16 B cover one 128-byte row)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM >= 1 && TN >= 1, "wave tile >= 32x32");
-  constexpr int RA = BM / 32, RB = BN / 32;  // 16-byte chunks per thread per tile
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows must be a multiple of the staging pass");
+  constexpr int RA = BM / RPP, RB = BN / RPP;  // 16-byte chunks per thread per tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
@@ -133,36 +159,60 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
 
   // ---- loader state -------------------------------------------------------------------------------------------------
   const int chunk = tid & 7;
-  const int row0 = tid >> 3;  // 0..31
+  const int row0 = tid >> 3;
   int kcur = kbeg + chunk * 8;
 
-  // conv gather state
   const int Cin = p.C1 + p.C2;
-  int iy0[RA], ix0[RA];
-  long boff[RA];
-  int cc = 0, dy = 0, dx = 0;
   const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
+  int iy0[RA], ix0[RA], pbase[RA];  // conv: output-pixel origin and batch pixel base of each staged row
+  int pix[RA];                      // conv: source pixel of the current tap (-1 = padding / row out of range)
+  const f16* arow[RA];              // dense: row pointers
+  int cc = 0, dy = 0, dx = 0;
+
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+      const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+      pix[i] = ok ? pbase[i] + sy * p.W + sx : -1;
+    }
+  };
+
   if constexpr (CONV) {
     const int hw = p.Ho * p.Wo;
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-      const int m = m0 + row0 + 32 * i;
+      const int m = m0 + row0 + RPP * i;
       if (m < p.M) {
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         iy0[i] = oy * p.stride - p.pad_t;
         ix0[i] = ox * p.stride - p.pad_l;
-        boff[i] = (long)b * p.H * p.W;
+        pbase[i] = b * p.H * p.W;
       } else {
         iy0[i] = -(1 << 28);
         ix0[i] = -(1 << 28);
-        boff[i] = 0;
+        pbase[i] = 0;
       }
     }
     const int tap = kcur / Cin;
     cc = kcur - tap * Cin;
     dy = tap / p.KW;
     dx = tap - dy * p.KW;
+    set_tap();
+  } else {
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+      const int m = m0 + row0 + RPP * i;
+      arow[i] = (m < p.M) ? p.a + (long)m * p.lda : nullptr;
+    }
+  }
+  const f16* wrow[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int n = n0 + row0 + RPP * i;
+    wrow[i] = (n < p.N) ? p.w + (long)n * p.ldw : nullptr;
   }
 
   uint4 ra[RA], rb[RB];
@@ -170,42 +220,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
   auto load_tile = [&]() {
     const bool kok = kcur < kend;
     if constexpr (CONV) {
+      const bool first = cc < p.C1;
+      const f16* src = first ? p.a : p.a2;
+      const int cs = first ? p.C1 : p.C2;
+      const int co = first ? cc : cc - p.C1;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-        const bool ok = kok && (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (ok) {
-          const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
-          const long pix = boff[i] + (long)sy * p.W + sx;
-          const f16* src = (cc < p.C1) ? (p.a + pix * p.C1 + cc) : (p.a2 + pix * p.C2 + (cc - p.C1));
-          v = *reinterpret_cast<const uint4*>(src);
-        }
+        if (kok && pix[i] >= 0) v = *reinterpret_cast<const uint4*>(src + (long)pix[i] * cs + co);
         ra[i] = v;
       }
     } else {
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const int m = m0 + row0 + 32 * i;
         uint4 v = make_uint4(0, 0, 0, 0);
-        if (kok && m < p.M) v = *reinterpret_cast<const uint4*>(p.a + (long)m * p.lda + kcur);
+        if (kok && arow[i]) v = *reinterpret_cast<const uint4*>(arow[i] + kcur);
         ra[i] = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-      const int n = n0 + row0 + 32 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (kok && n < p.N) v = *reinterpret_cast<const uint4*>(p.w + (long)n * p.ldw + kcur);
+      if (kok && wrow[i]) v = *reinterpret_cast<const uint4*>(wrow[i] + kcur);
       rb[i] = v;
     }
     // advance to the next K tile
     kcur += BK;
     if constexpr (CONV) {
       cc += BK;
-      while (cc >= Cin) {
-        cc -= Cin;
-        if (++dx == p.KW) { dx = 0; ++dy; }
+      if (cc >= Cin) {
+        do {
+          cc -= Cin;
+          if (++dx == p.KW) { dx = 0; ++dy; }
+        } while (cc >= Cin);
+        set_tap();
       }
     }
   };
@@ -214,9 +262,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const GemmParams p) {
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(As + lds_swz<128>(row0 + 32 * i, chunk)) = ra[i];
+    for (int i = 0; i < RA; ++i) *reinterpret_cast<uint4*>(As + lds_swz<128>(row0 + RPP * i, chunk)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(Bs + lds_swz<128>(row0 + 32 * i, chunk)) = rb[i];
+    for (int i = 0; i < RB; ++i) *reinterpret_cast<uint4*>(Bs + lds_swz<128>(row0 + RPP * i, chunk)) = rb[i];
   };
 
   f32x16 acc[TN][TM];
@@ -319,32 +367,55 @@ template <int BM, int BN, int WM, int WN>
 void launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, 1);
   if (conv)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(NTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(NTHREADS), 0, st, p);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
 }
 
 struct Plan {
+  int cfg;  // index into kCfg
   int bm, bn, splitk, kper;
 };
 
-// Tile / split-K heuristic: the largest tile that still gives >= ~1 block per CU without much padded-N waste; split K when
-// the grid would leave most of the 256 CUs idle (8x8 / 16x16 latent levels, batch-1 inference).
+// tile configurations: {BM, BN}; efficiency = relative MFMA rate measured on large problems (tools/bench_gemm.py)
+struct Cfg { int bm, bn; double eff; };
+constexpr Cfg kCfg[] = {{256, 128, 1.08}, {128, 128, 1.00}, {128, 64, 0.80}, {64, 64, 0.55}};
+constexpr int kNumCfg = 4;
+
+int g_tile_override = -2;
+int tile_override() {
+  if (g_tile_override == -2) {
+    const char* e = getenv("GN_GEMM_TILE");  // tuning aid: force a tile configuration index
+    g_tile_override = e ? atoi(e) : -1;
+  }
+  return g_tile_override;
+}
+
+// Tile / split-K heuristic: maximise (config efficiency) x (useful fraction of the padded tile grid) x (fraction of the 256
+// CUs' block slots the grid fills); split K when the grid would leave most CUs idle (8x8 / 16x16 latent levels, batch 1).
 Plan plan_gemm(const gn_gemm_desc* d) {
   const int64_t M = d->M, N = d->N, K = d->K;
   Plan pl;
+  int best = 1;
   if (d->act == GN_ACT_GEGLU) {
-    pl.bm = 128; pl.bn = 128;
+    best = (M >= 4096) ? 0 : 1;  // GEGLU needs wave tiles >= 64 columns: the two 128-wide-N configurations
   } else {
-    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    int best = 2;
-    for (int c = 0; c < 3; ++c) {
-      const int64_t tm = cdiv64(M, cand[c][0]), tn = cdiv64(N, cand[c][1]);
-      const double waste = (double)(tm * cand[c][0] * tn * cand[c][1]) / (double)(M * N);
-      if (tm * tn >= 256 && waste <= 1.13) { best = c; break; }
+    double bs = -1.0;
+    for (int c = 0; c < kNumCfg; ++c) {
+      const int64_t tm = cdiv64(M, kCfg[c].bm), tn = cdiv64(N, kCfg[c].bn);
+      const double useful = (double)(M * N) / (double)(tm * kCfg[c].bm * tn * kCfg[c].bn);
+      const double blocks = (double)(tm * tn);
+      const double slots = 256.0 * (kCfg[c].bm * kCfg[c].bn >= 128 * 128 ? 2.0 : 3.0);
+      double fill = blocks >= slots ? blocks / (ceil(blocks / slots) * slots) : blocks / slots;
+      if (fill < 0.05) fill = 0.05;
+      const double score = kCfg[c].eff * useful * (0.35 + 0.65 * fill);
+      if (score > bs) { bs = score; best = c; }
     }
-    pl.bm = cand[best][0]; pl.bn = cand[best][1];
   }
+  const int ov = tile_override();
+  if (ov >= 0 && ov < kNumCfg && !(d->act == GN_ACT_GEGLU && ov > 1)) best = ov;
+  pl.cfg = best;
+  pl.bm = kCfg[best].bm; pl.bn = kCfg[best].bn;
   const int64_t blocks = cdiv64(M, pl.bm) * cdiv64(N, pl.bn);
   int sk = d->splitk;
   if (sk <= 0) {
@@ -366,6 +437,11 @@ Plan plan_gemm(const gn_gemm_desc* d) {
 }
 
 }  // namespace
+
+extern "C" int32_t gn_set_gemm_tile_override(int32_t cfg) {
+  g_tile_override = cfg < 0 ? -1 : cfg;
+  return GN_OK;
+}
 
 extern "C" int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d) {
   if (!d) return 0;
@@ -405,6 +481,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     GN_REQUIRE(d->K == (int64_t)d->KH * d->KW * (d->C1 + d->C2), "gn_gemm(conv): K != KH*KW*(C1+C2)");
     GN_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "gn_gemm(conv): M != B*Ho*Wo");
     GN_REQUIRE(d->stride >= 1 && d->KH >= 1 && d->KW >= 1 && d->H > 0 && d->W > 0, "gn_gemm(conv): bad geometry");
+    GN_REQUIRE((int64_t)d->B * d->H * d->W < (1ll << 31), "gn_gemm(conv): source tensor has too many pixels");
   } else {
     GN_REQUIRE(d->lda % 8 == 0 && d->lda >= d->K, "gn_gemm: lda (%ld) must be a multiple of 8 and >= K", (long)d->lda);
   }
@@ -419,9 +496,12 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
 
   const bool conv = d->conv != 0;
-  if (pl.bm == 128 && pl.bn == 128) launch_cfg<128, 128, 2, 2>(p, conv, ctx->stream);
-  else if (pl.bm == 128 && pl.bn == 64) launch_cfg<128, 64, 2, 2>(p, conv, ctx->stream);
-  else launch_cfg<64, 64, 2, 2>(p, conv, ctx->stream);
+  switch (pl.cfg) {
+    case 0: launch_cfg<256, 128, 4, 2>(p, conv, ctx->stream); break;
+    case 1: launch_cfg<128, 128, 2, 2>(p, conv, ctx->stream); break;
+    case 2: launch_cfg<128, 64, 2, 2>(p, conv, ctx->stream); break;
+    default: launch_cfg<64, 64, 2, 2>(p, conv, ctx->stream); break;
+  }
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {
     const long total = (long)p.M * (p.N >> 2);

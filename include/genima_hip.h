@@ -74,6 +74,8 @@ typedef struct gn_gemm_desc {
   float out_scale;        /* 1.0f = none */
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
+/* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
+int32_t gn_set_gemm_tile_override(int32_t cfg);
 int32_t gn_gemm(gn_ctx* ctx, const gn_gemm_desc* d);
 
 /* ---- K4/K5/K11: flash-style attention forward --------------------------------------------------------------------
