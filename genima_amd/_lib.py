@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
         ("conv", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("upsample2x", C.c_int32), ("act", C.c_int32), ("out_mode", C.c_int32),
-        ("rows_per_batch", C.c_int32), ("splitk", C.c_int32), ("out_scale", C.c_float),
+        ("rows_per_batch", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float),
     ]
 
 

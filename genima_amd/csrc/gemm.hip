@@ -377,10 +377,12 @@ struct Plan {
   int bm, bn, splitk, kper;
 };
 
-// tile configurations: {BM, BN}; efficiency = relative MFMA rate measured on large problems (tools/bench_gemm.py)
-struct Cfg { int bm, bn; double eff; };
-constexpr Cfg kCfg[] = {{256, 128, 1.08}, {128, 128, 1.00}, {128, 64, 0.80}, {64, 64, 0.55}};
-constexpr int kNumCfg = 4;
+// tile configurations: {BM, BN, relative MFMA rate on large problems (tools/bench_gemm.py), GEGLU-capable (wave tile >= 64
+// columns)}.  Index + 1 is the public gn_gemm_desc::tile value.
+struct Cfg { int bm, bn; double eff; bool geglu; };
+constexpr Cfg kCfg[] = {{256, 128, 1.00, true}, {128, 128, 1.00, true}, {128, 64, 0.85, false}, {64, 64, 0.65, false},
+                        {256, 64, 0.90, true},  {128, 256, 1.00, true}};
+constexpr int kNumCfg = 6;
 
 int g_tile_override = -2;
 int tile_override() {
@@ -396,16 +398,18 @@ int tile_override() {
 Plan plan_gemm(const gn_gemm_desc* d) {
   const int64_t M = d->M, N = d->N, K = d->K;
   Plan pl;
+  const bool geglu = d->act == GN_ACT_GEGLU;
   int best = 1;
-  if (d->act == GN_ACT_GEGLU) {
-    best = (M >= 4096) ? 0 : 1;  // GEGLU needs wave tiles >= 64 columns: the two 128-wide-N configurations
-  } else {
+  {
+    // fallback heuristic when the caller did not autotune (genima_amd/engine.py times every configuration per shape):
+    // score = tile efficiency x useful fraction of the padded grid x how evenly the grid fills the 256 CUs
     double bs = -1.0;
     for (int c = 0; c < kNumCfg; ++c) {
+      if (geglu && !kCfg[c].geglu) continue;
       const int64_t tm = cdiv64(M, kCfg[c].bm), tn = cdiv64(N, kCfg[c].bn);
       const double useful = (double)(M * N) / (double)(tm * kCfg[c].bm * tn * kCfg[c].bn);
       const double blocks = (double)(tm * tn);
-      const double slots = 256.0 * (kCfg[c].bm * kCfg[c].bn >= 128 * 128 ? 2.0 : 3.0);
+      const double slots = 256.0 * (kCfg[c].bm * kCfg[c].bn > 128 * 128 ? 1.0 : (kCfg[c].bm * kCfg[c].bn == 128 * 128 ? 2.0 : 3.0));
       double fill = blocks >= slots ? blocks / (ceil(blocks / slots) * slots) : blocks / slots;
       if (fill < 0.05) fill = 0.05;
       const double score = kCfg[c].eff * useful * (0.35 + 0.65 * fill);
@@ -413,7 +417,9 @@ Plan plan_gemm(const gn_gemm_desc* d) {
     }
   }
   const int ov = tile_override();
-  if (ov >= 0 && ov < kNumCfg && !(d->act == GN_ACT_GEGLU && ov > 1)) best = ov;
+  if (ov >= 0 && ov < kNumCfg) best = ov;
+  if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
+  if (geglu && !kCfg[best].geglu) best = 1;
   pl.cfg = best;
   pl.bm = kCfg[best].bm; pl.bn = kCfg[best].bn;
   const int64_t blocks = cdiv64(M, pl.bm) * cdiv64(N, pl.bn);
@@ -500,7 +506,9 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 0: launch_cfg<256, 128, 4, 2>(p, conv, ctx->stream); break;
     case 1: launch_cfg<128, 128, 2, 2>(p, conv, ctx->stream); break;
     case 2: launch_cfg<128, 64, 2, 2>(p, conv, ctx->stream); break;
-    default: launch_cfg<64, 64, 2, 2>(p, conv, ctx->stream); break;
+    case 3: launch_cfg<64, 64, 2, 2>(p, conv, ctx->stream); break;
+    case 4: launch_cfg<256, 64, 4, 1>(p, conv, ctx->stream); break;
+    default: launch_cfg<128, 256, 2, 4>(p, conv, ctx->stream); break;
   }
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {

@@ -14,6 +14,8 @@ Layout conventions: activations NHWC f16 ``[B, H, W, C]`` == token-major ``[B, H
 from __future__ import annotations
 
 import ctypes as C
+import json
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -33,9 +35,40 @@ def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
+TUNE_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_tune_gfx950.json")
+_tune_cache: Optional[dict] = None
+_tune_dirty = [False]
+
+
+def _tune_table() -> dict:
+    global _tune_cache
+    if _tune_cache is None:
+        try:
+            with open(TUNE_PATH) as f:
+                _tune_cache = {k: int(v) for k, v in json.load(f).items()}
+        except Exception:
+            _tune_cache = {}
+    return _tune_cache
+
+
+def save_tune_table():
+    """Persist newly measured tile choices next to the package (and under gpurun_out/ so a GPU-box run can be committed)."""
+    if not _tune_dirty[0]:
+        return
+    for path in (TUNE_PATH, os.path.join(os.path.dirname(os.path.dirname(TUNE_PATH)), "gpurun_out", "gemm_tune_gfx950.json")):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    json.dump(dict(sorted(_tune_table().items())), f, indent=0)
+        except OSError:
+            pass
+    _tune_dirty[0] = False
+
+
 class Engine:
-    def __init__(self, device="cuda:0", record: bool = False):
+    def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None):
         self.lib = _lib.load()
+        self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise GenimaHipError("the Genima HIP engine needs a ROCm device (torch device 'cuda:N'); there is no CPU path")
@@ -131,7 +164,49 @@ class Engine:
         return float(ms.value)
 
     # ------------------------------------------------------------------------------------------------ GEMM family
+    # ---- per-shape tile autotuning ---------------------------------------------------------------------------------
+    # The best block tile of the implicit-GEMM kernel depends on (M, N, K) and on how the tile grid fills 256 CUs / 8 XCDs in
+    # ways a closed-form heuristic misses (tools/bench_gemm.py: up to 1.6x between configurations on hot-path shapes), so a
+    # recording engine times every configuration once per distinct problem and remembers the winner.  Tile choice does not
+    # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
+    # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
+    N_TILE_CFGS = 6
+
+    @staticmethod
+    def _tune_key(d: GemmDesc) -> str:
+        return "|".join(str(int(v)) for v in (d.conv, d.M, d.N, d.K, d.C1, d.C2, d.KH, d.stride, d.upsample2x, d.act,
+                                              d.out_mode, 1 if d.residual else 0))
+
+    def _autotune(self, d: GemmDesc):
+        key = self._tune_key(d)
+        table = _tune_table()
+        if key in table:
+            return table[key]
+        best, best_ms = 0, float("inf")
+        cands = (1, 2, 5, 6) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
+        e0, e1 = self.event(), self.event()
+        for c in cands:
+            d.tile = c
+            nb = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
+            d.workspace = self._workspace(nb).data_ptr() if nb > 0 else None
+            for _ in range(2):
+                check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm(autotune)")
+            self.event_record(e0)
+            for _ in range(4):
+                check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm(autotune)")
+            self.event_record(e1)
+            ms = self.event_elapsed_ms(e0, e1)
+            if ms < best_ms:
+                best, best_ms = c, ms
+        self.lib.gn_event_destroy(e0)
+        self.lib.gn_event_destroy(e1)
+        table[key] = best
+        _tune_dirty[0] = True
+        return best
+
     def _gemm(self, d: GemmDesc, keep):
+        if self.autotune and d.tile == 0 and d.splitk == 0:
+            d.tile = self._autotune(d)
         ws_bytes = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
         ws = None
         if ws_bytes > 0:

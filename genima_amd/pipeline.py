@@ -187,6 +187,9 @@ class StableDiffusionControlNetPipeline:
         img = graphs.emit_vae_decode(E, self.vae.W, self.vae.config, z8)
         io.out_u8 = E.image_f16_to_u8(img, name="out_u8")
         io.engine = E
+        from .engine import save_tune_table
+
+        save_tune_table()
         if self.use_graph:
             side = torch.cuda.Stream(device=dev)
             E.use_stream(side)

@@ -71,6 +71,8 @@ typedef struct gn_gemm_desc {
   int32_t out_mode;       /* GN_OUT_*; BATCH_TRANSPOSED: out[b][n][m - b*rows_per_batch], row stride ldo, batch stride N*ldo */
   int32_t rows_per_batch; /* for shift / transposed output; 0 = M */
   int32_t splitk;         /* 0 = library heuristic, >=1 explicit */
+  int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} block tile
+                             (the host autotunes this per shape: genima_amd/engine.py) */
   float out_scale;        /* 1.0f = none */
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);

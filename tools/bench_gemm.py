@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genima_amd.engine import Engine  # noqa: E402
 
 E = Engine("cuda:0")
-CFG = ["256x128", "128x128", "128x64", "64x64"]
+CFG = ["256x128", "128x128", "128x64", "64x64", "256x64", "128x256"]
 
 
 def timeit(fn, iters=20):
@@ -24,7 +24,7 @@ def timeit(fn, iters=20):
     return E.event_elapsed_ms(a, b) / iters
 
 
-def run(name, fn, flops, cfgs=(0, 1, 2, 3)):
+def run(name, fn, flops, cfgs=(0, 1, 2, 3, 4, 5)):
     row = []
     for c in cfgs:
         E.lib.gn_set_gemm_tile_override(c)
@@ -63,4 +63,4 @@ for tok, c in [(4096, 320), (1024, 640), (256, 1280)]:
     x = h(B * tok, c)
     w = h(8 * c, c)
     b = h(8 * c)
-    run(f"geglu {B}x{tok} C={c}", lambda: E.linear(x, w, b, act=5), 2.0 * B * tok * c * 8 * c, cfgs=(0, 1))
+    run(f"geglu {B}x{tok} C={c}", lambda: E.linear(x, w, b, act=5), 2.0 * B * tok * c * 8 * c, cfgs=(0, 1, 4, 5))
