@@ -9,13 +9,24 @@
 // 8 *consecutive* keys: converting them to f16 gives the PV B-operand directly and the V^T fragment is one ds_read_b128.
 // V arrives already transposed ([b][h*D+d][key]) from the V projection's epilogue, so both tiles use the same 16-byte-chunk
 // XOR-swizzled LDS image as the GEMM kernel (conflict-free ds_read_b128).
-// Block = 4 waves x 32 query rows; key tile = 64; global -> register -> LDS staging with the next tile's loads in flight
-// under the current tile's MFMAs.
+//
+// At D = 64 the kernel is VALU-bound, not MFMA-bound (256 MFMA flops vs ~10 f32 VALU ops per score at a 16:1 rate ratio), so
+// the softmax is trimmed to ~5 VALU per score:
+//   * the softmax scale is folded into the exponent:  p = exp2(fma(s, c, -m)),  c = scale*log2(e); the max is taken on raw s;
+//   * masking (key >= Nk, causal) runs only in the tiles that need it (block-uniform branch);
+//   * the O^T / l rescale is deferred: it runs only when some row's max grew by more than 2^THR since its last rescale
+//     (wave-uniform branch; P stays <= 2^THR, harmless for f16's relative precision) -- on typical data once or twice per row;
+//   * P is packed with v_cvt_pk_f16_f32 and its row sum taken with v_dot2c_f32_f16 on the packed pairs (the sum then matches
+//     the f16 P that enters the PV MFMA exactly);
+//   * v_max3_f32 chains for the row max.
+// K/V tiles are double-buffered in LDS (one barrier per 64-key tile), global -> register loads of tile t+1 are in flight under
+// the MFMAs of tile t.  Block = 4 waves x 32 query rows.
 #include "common.h"
 
 namespace {
 
-constexpr int KT = 64;  // keys per tile
+constexpr int KT = 64;       // keys per tile
+constexpr float THR = 8.0f;  // deferred-rescale threshold in log2 units
 
 struct AttnParams {
   const f16* q; const f16* k; const f16* vt; f16* o;
@@ -39,9 +50,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   constexpr int VLD = (D * 8) / 256;     // chunks per thread (V^T)
   static_assert(KLD >= 1 && VLD >= 1, "tile too small for 256 threads");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[K_BYTES + V_BYTES];
-  unsigned char* Ks = smem;
-  unsigned char* Vs = smem + K_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (K_BYTES + V_BYTES)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -67,7 +76,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   for (int t = 0; t < DT; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
-  float m_run = -1e30f, l_run = 0.0f;
+  float m_run = -1e30f;  // running max in exponent units (raw score * scale_log2), as of the last rescale
+  float l_run = 0.0f;    // this lane's half of the row sum
+  const float c = p.scale_log2;
 
   // key range: causal rows never look past their own index
   int nk_eff = p.Nk;
@@ -101,7 +112,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
       rv[i] = v;
     }
   };
-  auto store_tile = [&]() {
+  auto store_tile = [&](int buf) {
+    unsigned char* Ks = smem + buf * (K_BYTES + V_BYTES);
+    unsigned char* Vs = Ks + K_BYTES;
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
       const int id = tid + 256 * i;
@@ -117,58 +130,82 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
   };
 
-  if (ntiles > 0) load_tile(0);
-  for (int t = 0; t < ntiles; ++t) {
-    __syncthreads();  // everyone finished reading the previous tile
-    store_tile();
-    __syncthreads();
-    if (t + 1 < ntiles) load_tile(t + 1);
+  if (ntiles > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
 
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(t + 1);
+    const unsigned char* Ks = smem + cur * (K_BYTES + V_BYTES);
+    const unsigned char* Vs = Ks + K_BYTES;
     const int j0 = t * KT;
-    // ---- S^T = K . Q^T for the two 32-key sub-tiles --------------------------------------------------------------------
+
+    // ---- S^T = K . Q^T for the two 32-key sub-tiles (raw scores) ---------------------------------------------------------
     f32x16 s[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[u][r] = 0.0f;
-#pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<ROWB>(u * 32 + l31, ks * 2 + hi));
-        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+        if (ks == 0) {
+          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], zero, 0, 0, 0);  // C = inline constant 0
+        } else {
+          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
+        }
       }
     }
     // accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7)   (K rows were stored bit-2/3 swapped)
-    float mx = -1e30f;
+    const bool need_mask = (j0 + KT > p.Nk) || (p.causal && j0 + KT - 1 > q0);  // block-uniform
+    if (need_mask) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
-        float v = s[u][r] * p.scale_log2;
-        const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
-        v = dead ? -INFINITY : v;
-        s[u][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
+          const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
+          s[u][r] = dead ? -INFINITY : s[u][r];
+        }
+    }
+    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[1][0]);
+    mx = fmaxf(mx, s[1][1]);
+#pragma unroll
+    for (int r = 2; r < 16; r += 2) {
+      mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
+      mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;  // exponent units; -inf stays -inf (c > 0)
+    // deferred rescale: only when some row's max outgrew its reference by more than THR (wave-uniform)
+    if (__any(mx > m_run + THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    }
+    const float nm = -m_run;
     f16x8 pf[2][2];
+    float psum = 0.0f;
+    const f16x2 ones = {(f16)1.0f, (f16)1.0f};
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f(s[u][r] - m_new);
-        psum += pv;
-        pf[u][r >> 3][r & 7] = (f16)pv;
+      for (int r = 0; r < 16; r += 2) {
+        f16x2 pp;
+        pp[0] = (f16)__builtin_amdgcn_exp2f(fmaf(s[u][r], c, nm));
+        pp[1] = (f16)__builtin_amdgcn_exp2f(fmaf(s[u][r + 1], c, nm));
+        psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
+        pf[u][r >> 3][r & 7] = pp[0];
+        pf[u][r >> 3][(r & 7) + 1] = pp[1];
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
+    l_run += psum;
     // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -179,6 +216,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
           f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(dt * 32 + l31, u * 4 + sstep * 2 + hi));
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][sstep], oacc[dt], 0, 0, 0);
         }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ----------------------------------------------------------------------------------
@@ -208,6 +248,7 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   GN_REQUIRE(d->vt_rs >= ((d->Nk + 63) / 64) * 64, "gn_attention_fwd: vt row stride %d must cover round_up(Nk=%d, 64)", d->vt_rs, d->Nk);
   GN_REQUIRE(((uintptr_t)d->q & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->vt & 15) == 0 && ((uintptr_t)d->o & 7) == 0, "gn_attention_fwd: pointer alignment");
   GN_REQUIRE(d->q_bs % 8 == 0 && d->k_bs % 8 == 0 && d->vt_bs % 8 == 0 && d->o_bs % 4 == 0, "gn_attention_fwd: batch strides alignment");
+  GN_REQUIRE(d->scale > 0.0f, "gn_attention_fwd: scale must be positive");
   AttnParams p;
   p.q = (const f16*)d->q; p.k = (const f16*)d->k; p.vt = (const f16*)d->vt; p.o = (f16*)d->o;
   p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.vt_bs = d->vt_bs; p.o_bs = d->o_bs;
