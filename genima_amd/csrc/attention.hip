@@ -20,7 +20,10 @@
 //     the f16 P that enters the PV MFMA exactly);
 //   * v_max3_f32 chains for the row max.
 // K/V tiles are double-buffered in LDS (one barrier per 64-key tile), global -> register loads of tile t+1 are in flight under
-// the MFMAs of tile t.  Block = 4 waves x 32 query rows.
+// the MFMAs of tile t.  Block = NW waves x TQ x 32 query rows (template): more rows per block amortise the K/V staging and
+// LDS fragment reads over more MFMAs; the launcher picks the variant by problem size.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -38,51 +41,60 @@ struct AttnParams {
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 
-template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+template <int D, int NW, int TQ>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * TQ * 32;   // query rows per block
   constexpr int ROWB = D * 2;        // K tile row bytes
   constexpr int KCH = D / 8;         // 16-byte chunks per K row
   constexpr int KS = D / 16;         // k16 steps of QK^T
   constexpr int DT = D / 32;         // 32-row d tiles of O^T
   constexpr int K_BYTES = KT * ROWB; // K tile: [64 keys][D]
   constexpr int V_BYTES = D * 128;   // V^T tile: [D rows][64 keys]
-  constexpr int KLD = (KT * KCH) / 256;  // chunks per thread (K)
-  constexpr int VLD = (D * 8) / 256;     // chunks per thread (V^T)
-  static_assert(KLD >= 1 && VLD >= 1, "tile too small for 256 threads");
+  constexpr int KLD = (KT * KCH) / NT;  // chunks per thread (K)
+  constexpr int VLD = (D * 8) / NT;     // chunks per thread (V^T)
+  static_assert(KLD >= 1 && VLD >= 1, "tile too small for the block");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (K_BYTES + V_BYTES)];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * 128;
-  const int qrow = q0 + wave * 32 + l31;
+  const int q0 = blockIdx.x * QB;
+  const int qw = q0 + wave * (TQ * 32) + l31;  // this lane's query row in q-tile 0 (+32 per further tile)
 
   const f16* qp = p.q + (long)b * p.q_bs + (long)h * D;
   const f16* kp = p.k + (long)b * p.k_bs + (long)h * D;
   const f16* vp = p.vt + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
 
   // Q fragments (B operand): lane holds Q[qrow][16*ks + 8*hi .. +8]
-  f16x8 qf[KS];
+  f16x8 qf[TQ][KS];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (qrow < p.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)qrow * p.q_rs + ks * 16 + hi * 8);
-    qf[ks] = *reinterpret_cast<f16x8*>(&v);
-  }
+  for (int tq = 0; tq < TQ; ++tq)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      const int qrow = qw + 32 * tq;
+      if (qrow < p.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)qrow * p.q_rs + ks * 16 + hi * 8);
+      qf[tq][ks] = *reinterpret_cast<f16x8*>(&v);
+    }
 
-  f32x16 oacc[DT];
+  f32x16 oacc[TQ][DT];
+  float m_run[TQ], l_run[TQ];
 #pragma unroll
-  for (int t = 0; t < DT; ++t)
+  for (int tq = 0; tq < TQ; ++tq) {
+    m_run[tq] = -1e30f;  // running max in exponent units (raw score * scale_log2), as of the last rescale
+    l_run[tq] = 0.0f;    // this lane's half of the row sum
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[t][r] = 0.0f;
-  float m_run = -1e30f;  // running max in exponent units (raw score * scale_log2), as of the last rescale
-  float l_run = 0.0f;    // this lane's half of the row sum
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[tq][t][r] = 0.0f;
+  }
   const float c = p.scale_log2;
 
   // key range: causal rows never look past their own index
   int nk_eff = p.Nk;
-  if (p.causal) nk_eff = min(p.Nk, q0 + 128);
+  if (p.causal) nk_eff = min(p.Nk, q0 + QB);
   const int ntiles = (nk_eff + KT - 1) / KT;
 
   uint4 rk[KLD], rv[VLD];
@@ -90,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const int j0 = t * KT;
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
-      const int id = tid + 256 * i;
+      const int id = tid + NT * i;
       const int key = id / KCH, ch = id % KCH;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (j0 + key < p.Nk) v = *reinterpret_cast<const uint4*>(kp + (long)(j0 + key) * p.k_rs + ch * 8);
@@ -98,7 +110,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
 #pragma unroll
     for (int i = 0; i < VLD; ++i) {
-      const int id = tid + 256 * i;
+      const int id = tid + NT * i;
       const int drow = id >> 3, ch = id & 7;
       uint4 v = *reinterpret_cast<const uint4*>(vp + (long)drow * p.vt_rs + j0 + ch * 8);
       const int kb = j0 + ch * 8;
@@ -117,14 +129,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     unsigned char* Vs = Ks + K_BYTES;
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
-      const int id = tid + 256 * i;
+      const int id = tid + NT * i;
       const int key = id / KCH, ch = id % KCH;
       const int row = (key & 32) | swap23(key & 31);
       *reinterpret_cast<uint4*>(Ks + lds_swz<ROWB>(row, ch)) = rk[i];
     }
 #pragma unroll
     for (int i = 0; i < VLD; ++i) {
-      const int id = tid + 256 * i;
+      const int id = tid + NT * i;
       const int drow = id >> 3, ch = id & 7;
       *reinterpret_cast<uint4*>(Vs + lds_swz<128>(drow, ch)) = rv[i];
     }
@@ -136,6 +148,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   }
   __syncthreads();
 
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f16x2 ones = {(f16)1.0f, (f16)1.0f};
+
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
@@ -143,78 +158,80 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     const unsigned char* Ks = smem + cur * (K_BYTES + V_BYTES);
     const unsigned char* Vs = Ks + K_BYTES;
     const int j0 = t * KT;
-
-    // ---- S^T = K . Q^T for the two 32-key sub-tiles (raw scores) ---------------------------------------------------------
-    f32x16 s[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<ROWB>(u * 32 + l31, ks * 2 + hi));
-        if (ks == 0) {
-          const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[0], zero, 0, 0, 0);  // C = inline constant 0
-        } else {
-          s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[u], 0, 0, 0);
-        }
-      }
-    }
-    // accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7)   (K rows were stored bit-2/3 swapped)
     const bool need_mask = (j0 + KT > p.Nk) || (p.causal && j0 + KT - 1 > q0);  // block-uniform
-    if (need_mask) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
-          const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
-          s[u][r] = dead ? -INFINITY : s[u][r];
-        }
-    }
-    float mx = fmaxf(fmaxf(s[0][0], s[0][1]), s[1][0]);
-    mx = fmaxf(mx, s[1][1]);
-#pragma unroll
-    for (int r = 2; r < 16; r += 2) {
-      mx = fmaxf(fmaxf(mx, s[0][r]), s[0][r + 1]);
-      mx = fmaxf(fmaxf(mx, s[1][r]), s[1][r + 1]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;  // exponent units; -inf stays -inf (c > 0)
-    // deferred rescale: only when some row's max outgrew its reference by more than THR (wave-uniform)
-    if (__any(mx > m_run + THR)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[dt][r] *= alpha;
-    }
-    const float nm = -m_run;
-    f16x8 pf[2][2];
-    float psum = 0.0f;
-    const f16x2 ones = {(f16)1.0f, (f16)1.0f};
+
+    // ---- S^T = K . Q^T for the two 32-key sub-tiles (raw scores); each K fragment feeds TQ MFMAs ----------------------------
+    f32x16 s[TQ][2];
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        f16x2 pp;
-        pp[0] = (f16)__builtin_amdgcn_exp2f(fmaf(s[u][r], c, nm));
-        pp[1] = (f16)__builtin_amdgcn_exp2f(fmaf(s[u][r + 1], c, nm));
-        psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
-        pf[u][r >> 3][r & 7] = pp[0];
-        pf[u][r >> 3][(r & 7) + 1] = pp[1];
+      for (int ks = 0; ks < KS; ++ks) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<ROWB>(u * 32 + l31, ks * 2 + hi));
+#pragma unroll
+        for (int tq = 0; tq < TQ; ++tq)
+          s[tq][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[tq][ks], ks == 0 ? zero16 : s[tq][u], 0, 0, 0);
       }
-    l_run += psum;
-    // ---- O^T += V^T . P^T ---------------------------------------------------------------------------------------------
+
+    // ---- online softmax per q tile; accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7) ---------------------
+    f16x8 pf[TQ][2][2];
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) {
+      if (need_mask) {
+        const int qrow = qw + 32 * tq;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
+            const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
+            s[tq][u][r] = dead ? -INFINITY : s[tq][u][r];
+          }
+      }
+      float mx = fmaxf(fmaxf(s[tq][0][0], s[tq][0][1]), s[tq][1][0]);
+      mx = fmaxf(mx, s[tq][1][1]);
+#pragma unroll
+      for (int r = 2; r < 16; r += 2) {
+        mx = fmaxf(fmaxf(mx, s[tq][0][r]), s[tq][0][r + 1]);
+        mx = fmaxf(fmaxf(mx, s[tq][1][r]), s[tq][1][r + 1]);
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;  // exponent units; -inf stays -inf (c > 0)
+      // deferred rescale: only when some row's max outgrew its reference by more than THR (wave-uniform)
+      if (__any(mx > m_run[tq] + THR)) {
+        const float m_new = fmaxf(m_run[tq], mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[tq] - m_new);
+        m_run[tq] = m_new;
+        l_run[tq] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[tq][dt][r] *= alpha;
+      }
+      const float nm = -m_run[tq];
+      float psum = 0.0f;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          f16x2 pp;
+          pp[0] = (f16)__builtin_amdgcn_exp2f(fmaf(s[tq][u][r], c, nm));
+          pp[1] = (f16)__builtin_amdgcn_exp2f(fmaf(s[tq][u][r + 1], c, nm));
+          psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
+          pf[tq][u][r >> 3][r & 7] = pp[0];
+          pf[tq][u][r >> 3][(r & 7) + 1] = pp[1];
+        }
+      l_run[tq] += psum;
+    }
+    // ---- O^T += V^T . P^T; each V^T fragment feeds TQ MFMAs ----------------------------------------------------------------
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
-          f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(dt * 32 + l31, u * 4 + sstep * 2 + hi));
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u][sstep], oacc[dt], 0, 0, 0);
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(dt * 32 + l31, u * 4 + sstep * 2 + hi));
+#pragma unroll
+          for (int tq = 0; tq < TQ; ++tq)
+            oacc[tq][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[tq][u][sstep], oacc[tq][dt], 0, 0, 0);
         }
     if (more) store_tile(cur ^ 1);
     __syncthreads();
@@ -222,20 +239,40 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
   }
 
   // ---- finalize: O[q][d] = O^T[d][q] / l ----------------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
-  if (qrow < p.Nq) {
-    f16* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_rs + (long)h * D;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+  for (int tq = 0; tq < TQ; ++tq) {
+    const float l_tot = l_run[tq] + __shfl_xor(l_run[tq], 32, 64);
+    const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
+    const int qrow = qw + 32 * tq;
+    if (qrow < p.Nq) {
+      f16* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_rs + (long)h * D;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f16x4 v;
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (f16)(oacc[dt][4 * g + i] * inv);
-        *reinterpret_cast<f16x4*>(op + dt * 32 + 8 * g + 4 * hi) = v;
-      }
+        for (int g = 0; g < 4; ++g) {
+          f16x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = (f16)(oacc[tq][dt][4 * g + i] * inv);
+          *reinterpret_cast<f16x4*>(op + dt * 32 + 8 * g + 4 * hi) = v;
+        }
+    }
   }
+}
+
+template <int D, int NW, int TQ>
+void launch_attn(const AttnParams& p, int B, hipStream_t st) {
+  constexpr int QB = NW * TQ * 32;
+  dim3 grid((p.Nq + QB - 1) / QB, p.heads, B);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, NW, TQ>), grid, dim3(NW * 64), 0, st, p);
+}
+
+int attn_variant_override() {
+  static int v = -2;
+  if (v == -2) {
+    const char* e = getenv("GN_ATTN_VARIANT");  // tuning aid: 0 = 4 waves x 32 rows, 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows
+    v = e ? atoi(e) : -1;
+  }
+  return v;
 }
 
 }  // namespace
@@ -255,11 +292,20 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   p.q_rs = d->q_rs; p.k_rs = d->k_rs; p.vt_rs = d->vt_rs; p.o_rs = d->o_rs;
   p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.causal = d->causal;
   p.scale_log2 = d->scale * 1.4426950408889634f;
-  dim3 grid((d->Nq + 127) / 128, d->heads, d->B);
-  if (d->D == 64)
-    hipLaunchKernelGGL((attn_fwd_kernel<64>), grid, dim3(256), 0, ctx->stream, p);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, dim3(256), 0, ctx->stream, p);
+  if (d->D == 32) {
+    launch_attn<32, 4, 1>(p, d->B, ctx->stream);
+  } else {
+    // variant by work: big self-attention amortises K/V staging over 256-row blocks; small problems keep 128-row blocks so the
+    // grid still covers the chip
+    int v = 0;
+    const long blocks256 = (long)((d->Nq + 255) / 256) * d->heads * d->B;
+    if (d->Nk >= 512 && blocks256 >= 512) v = 1;
+    const int ov = attn_variant_override();
+    if (ov >= 0 && ov <= 2) v = ov;
+    if (v == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
+    else if (v == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
+    else launch_attn<64, 4, 1>(p, d->B, ctx->stream);
+  }
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
