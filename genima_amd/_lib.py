@@ -29,7 +29,8 @@ class GemmDesc(C.Structure):
         ("conv", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("upsample2x", C.c_int32), ("act", C.c_int32), ("out_mode", C.c_int32),
-        ("rows_per_batch", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32), ("out_scale", C.c_float),
+        ("rows_per_batch", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32), ("residual_before_act", C.c_int32),
+        ("out_scale", C.c_float),
     ]
 
 
@@ -74,6 +75,8 @@ SIGNATURES = {
     "gn_add_noise": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I64]),
     "gn_image_u8_to_f16": (_I32, [_P, _P, _P, _I64, _I32, _F, _F]),
     "gn_image_f16_to_u8": (_I32, [_P, _P, _P, _I64, _I32]),
+    "gn_image_normalize_u8": (_I32, [_P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _F]),
+    "gn_gather_rows": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_add": (_I32, [_P, _P, _P, _P, _I64]),
     "gn_act": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),

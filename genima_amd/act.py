@@ -1,0 +1,289 @@
+"""ACT controller forward on libgenima_hip.so (reference controller/method/genima_act.py).
+
+``GenimaACT`` keeps the plugin surface the eval loop uses (controller/eval_genima.py:55-64, :91-103, :243-247):
+``.act(obs_dict_of_tensors, step, eval_mode) -> Tensor[B, num_queries, action_dim]``, ``.state_dict()`` /
+``.load_state_dict(sd, strict=False)``, ``.train(bool)``, ``.encode_clip_text(tokens)``.  The forward -- ImageNet normalise ->
+ResNet-18 (FrozenBatchNorm folded into the conv weights at pack time, ReLU and the identity add fused into the conv epilogue)
+per view -> 1x1 input_proj -> views along width -> sine positions -> DETR encoder(4)/decoder(6) on the same MFMA GEMM /
+flash-attention (head dim 32) / LayerNorm kernels as the diffusion path -> heads -- runs entirely in HIP; RoboBase itself is an
+unpinned absent dependency, so the module wiring follows the public ACT/DETR semantics restated in oracle/act_torch.py
+([VERIFY] items of SURVEY.md Appendix E stay open until a real ``latest.pt`` is available).
+"""
+from __future__ import annotations
+
+import math
+import re
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+from . import configs, graphs, packing, schema, weights
+from ._lib import ACT_NONE, ACT_RELU, GenimaHipError
+from .engine import Engine
+from .host import FrozenConfig
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_RESNET18 = ((1, 64, 1), (2, 128, 2), (3, 256, 2), (4, 512, 2))
+
+
+def act_schema(cfg) -> "OrderedDict[str, tuple]":
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    d, ff = cfg["hidden_dim"], cfg["dim_feedforward"]
+
+    def bn(p, c):
+        for n in ("weight", "bias", "running_mean", "running_var"):
+            s[f"{p}.{n}"] = (c,)
+
+    s["backbone.conv1.weight"] = (64, 3, 7, 7)
+    bn("backbone.bn1", 64)
+    cin = 64
+    for li, c, stride in _RESNET18:
+        for bi in range(2):
+            p = f"backbone.layer{li}.{bi}"
+            s[p + ".conv1.weight"] = (c, cin if bi == 0 else c, 3, 3)
+            bn(p + ".bn1", c)
+            s[p + ".conv2.weight"] = (c, c, 3, 3)
+            bn(p + ".bn2", c)
+            if bi == 0 and (stride != 1 or cin != c):
+                s[p + ".downsample.0.weight"] = (c, cin, 1, 1)
+                bn(p + ".downsample.1", c)
+        cin = c
+    s["input_proj.weight"], s["input_proj.bias"] = (d, 512, 1, 1), (d,)
+
+    def mha(p):
+        s[p + ".in_proj_weight"], s[p + ".in_proj_bias"] = (3 * d, d), (3 * d,)
+        s[p + ".out_proj.weight"], s[p + ".out_proj.bias"] = (d, d), (d,)
+
+    def ffn(p):
+        s[p + ".linear1.weight"], s[p + ".linear1.bias"] = (ff, d), (ff,)
+        s[p + ".linear2.weight"], s[p + ".linear2.bias"] = (d, ff), (d,)
+
+    def ln(p):
+        s[p + ".weight"], s[p + ".bias"] = (d,), (d,)
+
+    for i in range(cfg["enc_layers"]):
+        p = f"transformer.encoder.layers.{i}"
+        mha(p + ".self_attn"); ffn(p); ln(p + ".norm1"); ln(p + ".norm2")
+    for i in range(cfg["dec_layers"]):
+        p = f"transformer.decoder.layers.{i}"
+        mha(p + ".self_attn"); mha(p + ".multihead_attn"); ffn(p); ln(p + ".norm1"); ln(p + ".norm2"); ln(p + ".norm3")
+    ln("transformer.decoder.norm")
+    s["query_embed.weight"] = (cfg["num_queries"], d)
+    s["additional_pos_embed.weight"] = (3, d)
+    s["input_proj_robot_state.0.weight"], s["input_proj_robot_state.0.bias"] = (d, cfg["state_dim"]), (d,)
+    s["input_proj_robot_state.2.weight"], s["input_proj_robot_state.2.bias"] = (d, d), (d,)
+    s["latent_out_proj.weight"], s["latent_out_proj.bias"] = (d, cfg["latent_dim"]), (d,)
+    s["task_proj.weight"], s["task_proj.bias"] = (d, cfg["lang_dim"]), (d,)
+    s["action_head.weight"], s["action_head.bias"] = (cfg["action_dim"], d), (cfg["action_dim"],)
+    s["is_pad_head.weight"], s["is_pad_head.bias"] = (1, d), (1,)
+    return s
+
+
+def sine_pos_embed(H, W, d, temperature=10000.0) -> torch.Tensor:
+    """DETR PositionEmbeddingSine(normalize=True, scale=2*pi) of one camera's map -> [H, W, d] (host constant)."""
+    npf, eps, scale = d // 2, 1e-6, 2 * math.pi
+    y = torch.arange(1, H + 1, dtype=torch.float32)[:, None].expand(H, W) / (H + eps) * scale
+    x = torch.arange(1, W + 1, dtype=torch.float32)[None, :].expand(H, W) / (W + eps) * scale
+    dim_t = temperature ** (2 * (torch.arange(npf, dtype=torch.float32) // 2) / npf)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2)
+
+
+def pack_act(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
+    """FrozenBatchNorm folded into conv weight/bias; MHA in_proj split into q|k (fused) and v; the rest through the generic packer."""
+    f32 = {k: v.detach().float() for k, v in sd.items()}
+    folded: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in f32.items():
+        m = re.match(r"(backbone\..*?)(conv\d|downsample\.0)\.weight$", k)
+        if m:
+            bnp = m.group(1) + ("bn" + m.group(2)[-1] if m.group(2).startswith("conv") else "downsample.1")
+            scale = f32[bnp + ".weight"] * (f32[bnp + ".running_var"] + 1e-5).rsqrt()
+            folded[k] = v * scale[:, None, None, None]
+            folded[k[: -len("weight")] + "bias"] = f32[bnp + ".bias"] - f32[bnp + ".running_mean"] * scale
+        elif ".bn" in k or "downsample.1." in k:
+            continue
+        elif k.endswith("in_proj_weight"):
+            p, d = k[: -len("in_proj_weight")], v.shape[1]
+            folded[p + "qk_proj.weight"], folded[p + "v_proj.weight"] = v[: 2 * d], v[2 * d:]
+            b = f32[p + "in_proj_bias"]
+            folded[p + "qk_proj.bias"], folded[p + "v_proj.bias"] = b[: 2 * d], b[2 * d:]
+            folded[p + "q_proj.weight"], folded[p + "q_proj.bias"] = v[:d], b[:d]
+            folded[p + "k_proj.weight"], folded[p + "k_proj.bias"] = v[d: 2 * d], b[d: 2 * d]
+        elif k.endswith("in_proj_bias"):
+            continue
+        else:
+            folded[k] = v
+    W = packing.pack_state_dict(folded, device)
+    for head in ("action_head", "is_pad_head"):  # pad output rows to a multiple of 8 (N % 4 == 0 for the GEMM)
+        w, b = folded[head + ".weight"], folded[head + ".bias"]
+        n8 = (w.shape[0] + 7) // 8 * 8
+        wp = torch.zeros(n8, w.shape[1]); wp[: w.shape[0]] = w
+        bp = torch.zeros(n8); bp[: b.shape[0]] = b
+        W[head + ".weight"], W[head + ".bias"] = wp.half().to(device), bp.half().to(device)
+    return W
+
+
+def emit_act_forward(E: Engine, W, cfg, img_u8_nhwc: torch.Tensor, qpos: torch.Tensor, task_emb: Optional[torch.Tensor]):
+    """img_u8_nhwc: uint8 [B, V, H, W, 3]; qpos f16 [B, state_dim_pad8]; task_emb f16 [B, lang_dim] or None."""
+    B, V, H, Wd, _ = img_u8_nhwc.shape
+    d, heads = cfg["hidden_dim"], cfg["nheads"]
+    x = E.image_normalize_u8(img_u8_nhwc.view(B * V, H, Wd, 3), IMAGENET_MEAN, IMAGENET_STD, 8)
+    p = "backbone"
+    h = E.conv2d(x, W[p + ".conv1.weight"], W[p + ".conv1.bias"], ksize=7, stride=2, act=ACT_RELU)
+    h = E.maxpool3x3s2(h)
+    for li, c, stride in _RESNET18:
+        for bi in range(2):
+            q = f"{p}.layer{li}.{bi}"
+            st = stride if bi == 0 else 1
+            y = E.conv2d(h, W[q + ".conv1.weight"], W[q + ".conv1.bias"], stride=st, act=ACT_RELU)
+            idt = h
+            if (q + ".downsample.0.weight") in W:
+                idt = E.conv2d(h, W[q + ".downsample.0.weight"], W[q + ".downsample.0.bias"], ksize=1, stride=st, pad=(0, 0, 0, 0))
+            h = E.conv2d(y, W[q + ".conv2.weight"], W[q + ".conv2.bias"], residual=idt, act=ACT_RELU, residual_before_act=True)
+    f = E.conv2d(h, W["input_proj.weight"], W["input_proj.bias"], ksize=1, pad=(0, 0, 0, 0))   # [B*V, fh, fw, d]
+    fh, fw = f.shape[1], f.shape[2]
+    f = f.view(B, V, fh, fw, d).permute(0, 2, 1, 3, 4).reshape(B, fh * V * fw, d)              # views along width (layout interop)
+    pos_img = sine_pos_embed(fh, fw, d).repeat(1, V, 1).reshape(fh * V * fw, d)
+
+    proprio = E.linear(E.linear(qpos, W["input_proj_robot_state.0.weight"], W["input_proj_robot_state.0.bias"]),
+                       W["input_proj_robot_state.2.weight"], W["input_proj_robot_state.2.bias"])
+    zeros = torch.zeros(B, W["latent_out_proj.weight"].shape[1], dtype=torch.float16, device=E.device)
+    latent = E.linear(zeros, W["latent_out_proj.weight"], W["latent_out_proj.bias"])
+    extra = [latent, proprio]
+    if cfg.get("use_lang_cond") and task_emb is not None:
+        extra.append(E.linear(task_emb, W["task_proj.weight"], W["task_proj.bias"]))
+    n_extra = len(extra)
+    N = n_extra + f.shape[1]
+    src = torch.empty(B, N, d, dtype=torch.float16, device=E.device)
+    for i, e in enumerate(extra):
+        src[:, i] = e
+    src[:, n_extra:] = f
+    pos = torch.cat([W["additional_pos_embed.weight"][:n_extra], pos_img.half().to(E.device)], dim=0)[None].expand(B, -1, -1).contiguous()
+
+    def self_attn(pfx, x_qk, x_v, n):
+        qk = E.linear(x_qk, W[pfx + ".qk_proj.weight"], W[pfx + ".qk_proj.bias"])
+        vt = E.linear(x_v, W[pfx + ".v_proj.weight"], W[pfx + ".v_proj.bias"], transposed_out=True, rows_per_batch=n,
+                      pad_cols=(n + 63) // 64 * 64)
+        return E.attention(qk[:, :, :d], qk[:, :, d:], vt, heads, Nk=n)
+
+    for i in range(cfg["enc_layers"]):
+        q = f"transformer.encoder.layers.{i}"
+        a = self_attn(q + ".self_attn", E.add(src, pos), src, N)
+        src = E.layernorm(E.linear(a, W[q + ".self_attn.out_proj.weight"], W[q + ".self_attn.out_proj.bias"], residual=src),
+                          W[q + ".norm1.weight"], W[q + ".norm1.bias"])
+        ffh = E.linear(src, W[q + ".linear1.weight"], W[q + ".linear1.bias"], act=ACT_RELU)
+        src = E.layernorm(E.linear(ffh, W[q + ".linear2.weight"], W[q + ".linear2.bias"], residual=src),
+                          W[q + ".norm2.weight"], W[q + ".norm2.bias"])
+    memory = src
+    mem_pos = E.add(memory, pos)
+    nq = cfg["num_queries"]
+    qe = W["query_embed.weight"][None].expand(B, -1, -1).contiguous()
+    tgt = torch.zeros(B, nq, d, dtype=torch.float16, device=E.device)
+    for i in range(cfg["dec_layers"]):
+        q = f"transformer.decoder.layers.{i}"
+        a = self_attn(q + ".self_attn", E.add(tgt, qe), tgt, nq)
+        tgt = E.layernorm(E.linear(a, W[q + ".self_attn.out_proj.weight"], W[q + ".self_attn.out_proj.bias"], residual=tgt),
+                          W[q + ".norm1.weight"], W[q + ".norm1.bias"])
+        m = q + ".multihead_attn"
+        cq = E.linear(E.add(tgt, qe), W[m + ".q_proj.weight"], W[m + ".q_proj.bias"])
+        ck = E.linear(mem_pos, W[m + ".k_proj.weight"], W[m + ".k_proj.bias"])
+        cvt = E.linear(memory, W[m + ".v_proj.weight"], W[m + ".v_proj.bias"], transposed_out=True, rows_per_batch=N, pad_cols=(N + 63) // 64 * 64)
+        a = E.attention(cq, ck, cvt, heads, Nk=N)
+        tgt = E.layernorm(E.linear(a, W[m + ".out_proj.weight"], W[m + ".out_proj.bias"], residual=tgt),
+                          W[q + ".norm2.weight"], W[q + ".norm2.bias"])
+        ffh = E.linear(tgt, W[q + ".linear1.weight"], W[q + ".linear1.bias"], act=ACT_RELU)
+        tgt = E.layernorm(E.linear(ffh, W[q + ".linear2.weight"], W[q + ".linear2.bias"], residual=tgt),
+                          W[q + ".norm3.weight"], W[q + ".norm3.bias"])
+    hs = E.layernorm(tgt, W["transformer.decoder.norm.weight"], W["transformer.decoder.norm.bias"])
+    a_hat = E.linear(hs, W["action_head.weight"], W["action_head.bias"])[..., : cfg["action_dim"]]
+    is_pad = E.linear(hs, W["is_pad_head.weight"], W["is_pad_head.bias"])[..., :1]
+    return a_hat, is_pad
+
+
+class GenimaACT:
+    """Controller plugin (``method._target_: method.genima_act.GenimaACT``, controller/cfgs/method/genima_act.yaml:3-4)."""
+
+    def __init__(self, config: Optional[dict] = None, state_dict=None, clip_config: Optional[dict] = None, clip_state_dict=None,
+                 device="cuda", seed: int = 0, **hydra_kwargs):
+        self.config = FrozenConfig(dict(config or configs.ACT_POLICY))
+        self.clip_config = FrozenConfig(dict(clip_config or configs.ACT_CLIP_TEXT))
+        self._schema = act_schema(self.config)
+        self._sd = OrderedDict((k, v.float()) for k, v in (state_dict or weights.synth_state_dict(self._schema, seed + 31)).items())
+        self._clip_sd = clip_state_dict or weights.synth_state_dict(schema.clip_text_schema(self.clip_config), seed + 32)
+        self.device = torch.device(device)
+        self.training = False
+        self.W = self.Wclip = None
+        self._engine: Optional[Engine] = None
+        if self.device.type == "cuda" and torch.cuda.is_available():
+            self.to(self.device)
+
+    # ---- plugin surface -------------------------------------------------------------------------------------------
+    def to(self, device):
+        dev = torch.device(device)
+        if dev.type != "cuda" or not torch.cuda.is_available():
+            raise GenimaHipError("GenimaACT needs a ROCm device; there is no CPU fallback")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.W = pack_act(self._sd, self.device)
+        self.Wclip = packing.pack_state_dict(self._clip_sd, self.device)
+        self._engine = Engine(self.device)
+        return self
+
+    def train(self, mode: bool = True):
+        self.training = mode
+        return self
+
+    def state_dict(self):
+        return OrderedDict(("actor." + k, v) for k, v in self._sd.items())
+
+    def load_state_dict(self, sd, strict: bool = False):
+        new = {k[len("actor."):] if k.startswith("actor.") else k: v for k, v in sd.items()}
+        missing = [k for k in self._schema if k not in new]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:4]}")
+        for k in self._schema:
+            if k in new:
+                self._sd[k] = new[k].detach().float().cpu()
+        if self.W is not None:
+            self.W = pack_act(self._sd, self.device)
+        return missing, [k for k in new if k not in self._schema]
+
+    def encode_clip_text(self, tokens: torch.Tensor):
+        """tokens int [B, fs, 77] -> (task_emb f32 [B, projection_dim], emb) (controller/method/genima_act.py:314-346)."""
+        if self._engine is None:
+            raise GenimaHipError("GenimaACT is not on a ROCm device")
+        E = self._engine
+        shp = tokens.shape
+        tks = tokens.reshape(-1, shp[-1]).to(self.device, torch.int32).contiguous()
+        x = graphs.emit_clip_text(E, self.Wclip, self.clip_config, tks)
+        eot = tks.argmax(dim=-1).to(torch.int32)
+        pooled = E.gather_rows(x, eot)
+        proj = E.linear(pooled, self.Wclip["text_projection.weight"])
+        out = proj.view(shp[0], shp[1], -1)[:, 0].to(torch.float32)  # text does not change across frames
+        return out, x
+
+    def act(self, obs: Dict[str, torch.Tensor], step: int = 0, eval_mode: bool = True) -> torch.Tensor:
+        """obs: {'<cam>_rgb': uint8/float [B, fs, 3, H, W], 'low_dim_state': f32 [B, fs, state], 'lang_tokens': int [B, fs, 77]}."""
+        if self._engine is None:
+            raise GenimaHipError("GenimaACT is not on a ROCm device")
+        E = self._engine
+        cfg = self.config
+        qpos = obs["low_dim_state"].to(self.device).flatten(1)
+        rgb_keys = [k for k in obs if re.match(r"rgb.*|.*_rgb$", k)]  # obs-dict key order == RoboBase camera enumeration
+        image = torch.stack([obs[k].to(self.device) for k in rgb_keys], dim=1)  # [B, V, fs, 3, H, W]
+        B = image.shape[0]
+        image = image.reshape(B, -1, 3, image.shape[-2], image.shape[-1])
+        img_u8 = image.round().clamp(0, 255).to(torch.uint8) if image.dtype != torch.uint8 else image
+        img_u8 = img_u8.permute(0, 1, 3, 4, 2).contiguous()
+        task = None
+        if cfg.get("use_lang_cond") and "lang_tokens" in obs:
+            task, _ = self.encode_clip_text(obs["lang_tokens"])
+            task = task.to(torch.float16)
+        sdim = (qpos.shape[1] + 7) // 8 * 8
+        qp = torch.zeros(B, sdim, dtype=torch.float16, device=self.device)
+        qp[:, : qpos.shape[1]] = qpos.to(torch.float16)
+        a_hat, _ = emit_act_forward(E, self.W, cfg, img_u8, qp, task)
+        return a_hat.to(torch.float32)

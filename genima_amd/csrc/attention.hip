@@ -295,11 +295,9 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   if (d->D == 32) {
     launch_attn<32, 4, 1>(p, d->B, ctx->stream);
   } else {
-    // variant by work: big self-attention amortises K/V staging over 256-row blocks; small problems keep 128-row blocks so the
-    // grid still covers the chip
+    // measured on MI355X (tools/bench_attn.py): the three block shapes are within 5 % of each other on every hot-path shape
+    // (the per-wave softmax/MFMA dependency chain, not K/V staging, is the limiter), 4 waves x 32 rows is never worse.
     int v = 0;
-    const long blocks256 = (long)((d->Nq + 255) / 256) * d->heads * d->B;
-    if (d->Nk >= 512 && blocks256 >= 512) v = 1;
     const int ov = attn_variant_override();
     if (ov >= 0 && ov <= 2) v = ov;
     if (v == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);

@@ -63,6 +63,23 @@ __global__ void image_u8_to_f16_kernel(const uint8_t* __restrict__ in, f16* __re
   for (int c = 0; c < Cpad; ++c) out[p * Cpad + c] = v[c < 8 ? c : 7];
 }
 
+struct Norm3 { float m[3], a[3]; };
+__global__ void image_normalize_u8_kernel(const uint8_t* __restrict__ in, f16* __restrict__ out, long pixels, int Cpad, Norm3 n) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= pixels) return;
+  for (int c = 0; c < Cpad; ++c)
+    out[p * Cpad + c] = c < 3 ? (f16)((float)in[p * 3 + c] * n.m[c] + n.a[c]) : (f16)0.0f;
+}
+
+__global__ void gather_rows_kernel(const f16* __restrict__ x, const int32_t* __restrict__ idx, f16* __restrict__ out, int B, int L,
+                                   int D) {
+  const int DC = D >> 3;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * DC) return;
+  const int b = i / DC, c0 = (i - b * DC) * 8;
+  *reinterpret_cast<uint4*>(out + (long)b * D + c0) = *reinterpret_cast<const uint4*>(x + ((long)b * L + idx[b]) * D + c0);
+}
+
 __global__ void image_f16_to_u8_kernel(const f16* __restrict__ in, uint8_t* __restrict__ out, long pixels, int ld) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= pixels) return;
@@ -222,6 +239,22 @@ int32_t gn_add_noise(gn_ctx* ctx, const void* x0, const void* noise, const float
 int32_t gn_image_u8_to_f16(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float mul, float add) {
   GN_REQUIRE(ctx && in && out && pixels > 0 && Cpad >= 3 && Cpad <= 8, "gn_image_u8_to_f16: bad arguments");
   hipLaunchKernelGGL(image_u8_to_f16_kernel, dim3(nblk(pixels)), dim3(256), 0, ctx->stream, in, (f16*)out, (long)pixels, Cpad, mul, add);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_image_normalize_u8(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float m0, float m1, float m2,
+                              float a0, float a1, float a2) {
+  GN_REQUIRE(ctx && in && out && pixels > 0 && Cpad >= 3, "gn_image_normalize_u8: bad arguments");
+  Norm3 n{{m0, m1, m2}, {a0, a1, a2}};
+  hipLaunchKernelGGL(image_normalize_u8_kernel, dim3(nblk(pixels)), dim3(256), 0, ctx->stream, in, (f16*)out, (long)pixels, Cpad, n);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_gather_rows(gn_ctx* ctx, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D) {
+  GN_REQUIRE(ctx && x && idx && out && B > 0 && L > 0 && D > 0 && D % 8 == 0, "gn_gather_rows: bad arguments");
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((long)B * (D / 8))), dim3(256), 0, ctx->stream, (const f16*)x, idx, (f16*)out, B, L, D);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

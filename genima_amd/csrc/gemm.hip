@@ -39,7 +39,7 @@ struct GemmParams {
   int M, N, K;
   long lda, ldw, ldr, ldo, ldshift;
   int H, W, C1, C2, KH, KW, stride, pad_t, pad_l, Ho, Wo, ups;
-  int act, out_mode, rpb;
+  int act, out_mode, rpb, res_first;
   float out_scale;
   int splitk, kper;
   int tiles_m, tiles_n;
@@ -80,6 +80,11 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)s[i];
   }
+  if (p.res && p.res_first) {  // ResNet basic block: act(conv + identity)
+    f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (long)m * p.ldr + nb);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
+  }
   if (p.act != GN_ACT_NONE) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = gemm_act(v[i], p.act);
@@ -88,7 +93,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] *= p.out_scale;
   }
-  if (p.res) {
+  if (p.res && !p.res_first) {
     f16x4 r = *reinterpret_cast<const f16x4*>(p.res + (long)m * p.ldr + nb);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
@@ -478,7 +483,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.ldshift = d->ldshift > 0 ? d->ldshift : d->N;
   p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride;
   p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Ho = d->Ho; p.Wo = d->Wo; p.ups = d->upsample2x;
-  p.act = d->act; p.out_mode = d->out_mode;
+  p.act = d->act; p.out_mode = d->out_mode; p.res_first = d->residual_before_act;
   p.rpb = d->rows_per_batch > 0 ? d->rows_per_batch : (int)d->M;
   p.out_scale = d->out_scale;
   if (d->conv) {

@@ -267,7 +267,7 @@ class Engine:
                stride: int = 1, pad: Tuple[int, int, int, int] = None, x2: Optional[torch.Tensor] = None,
                shift: Optional[torch.Tensor] = None, ldshift: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
-               name: Optional[str] = None, splitk: int = 0) -> torch.Tensor:
+               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False) -> torch.Tensor:
         """NHWC conv.  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
         pad = (top, left, bottom, right); default k//2 all round.  shift: [B, ldshift or Cout] per-batch channel shift."""
         B, H, W, C1 = x.shape
@@ -292,6 +292,7 @@ class Engine:
         d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = k, k, stride, pad[0], pad[1], Ho, Wo
         d.upsample2x, d.act, d.out_mode, d.rows_per_batch, d.splitk, d.out_scale = (int(upsample2x), act, OUT_ROWMAJOR,
                                                                                      Ho * Wo, splitk, out_scale)
+        d.residual_before_act = int(residual_before_act)
         self._gemm(d, (x, x2, w, bias, shift, residual, out))
         return out
 
@@ -431,6 +432,21 @@ class Engine:
         cols = x.shape[-1]
         self._small("softmax_rows", (x,), _ptr(x), x.numel() // cols, cols, x.stride(-2), float(scale))
         return x
+
+    def image_normalize_u8(self, img: torch.Tensor, mean, std, cpad: int = 8, *, name=None):
+        """uint8 [..., 3] -> f16 [..., cpad] = (v/255 - mean_c) / std_c  (eager only)."""
+        out = self.buf(name, tuple(img.shape[:-1]) + (cpad,))
+        m = [1.0 / (255.0 * s_) for s_ in std]
+        a = [-mu / s_ for mu, s_ in zip(mean, std)]
+        check(self.lib.gn_image_normalize_u8(self._ctx, _ptr(img), _ptr(out), img.numel() // 3, cpad, *m, *a), "gn_image_normalize_u8")
+        return out
+
+    def gather_rows(self, x: torch.Tensor, idx: torch.Tensor, *, name=None):
+        """x [B, L, D], idx int32 [B] -> [B, D] (eager only)."""
+        B, L, D = x.shape
+        out = self.buf(name, (B, D))
+        check(self.lib.gn_gather_rows(self._ctx, _ptr(x), _ptr(idx), _ptr(out), B, L, D), "gn_gather_rows")
+        return out
 
     def maxpool3x3s2(self, x: torch.Tensor, *, name=None):
         B, H, W, Cc = x.shape

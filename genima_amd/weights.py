@@ -102,9 +102,9 @@ _SQRT3 = 3.0 ** 0.5
 def _init_rule(name: str, shape):
     """Return (kind, scale) for a parameter."""
     leaf = name.rsplit(".", 1)[-1]
-    is_norm = any(t in name for t in (".norm", "norm_out", "layer_norm", "group_norm", "ln_", ".bn"))
+    is_norm = any(t in name for t in (".norm", "norm_out", "layer_norm", "group_norm", "ln_", ".bn", "downsample.1."))
     if is_norm and len(shape) == 1:
-        return ("gamma", 0.1) if leaf == "weight" else ("beta", 0.1)
+        return ("gamma", 0.1) if leaf in ("weight", "running_var") else ("beta", 0.1)
     if leaf == "bias":
         return ("uniform", 0.02 * _SQRT3)
     if "token_embedding" in name or "position_embedding" in name or name.endswith("embed.weight"):

@@ -73,6 +73,7 @@ typedef struct gn_gemm_desc {
   int32_t splitk;         /* 0 = library heuristic, >=1 explicit */
   int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} block tile
                              (the host autotunes this per shape: genima_amd/engine.py) */
+  int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
@@ -135,6 +136,12 @@ int32_t gn_add_noise(gn_ctx* ctx, const void* x0, const void* noise, const float
  * gn_image_f16_to_u8: f16 [pixels, ld] -> uint8 [pixels, 3]: round(clamp(v/2+0.5, 0, 1)*255)  (postprocess, Appendix D.6) */
 int32_t gn_image_u8_to_f16(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float mul, float add);
 int32_t gn_image_f16_to_u8(gn_ctx* ctx, const void* in, uint8_t* out, int64_t pixels, int32_t ld);
+/* ACT image path (controller/method/genima_act.py:146-148, :188): uint8 [pixels, 3] -> f16 [pixels, Cpad]: v * m_c + a_c
+ * (m_c = 1/(255 std_c), a_c = -mean_c/std_c; channels >= 3 zero) */
+int32_t gn_image_normalize_u8(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float m0, float m1,
+                              float m2, float a0, float a1, float a2);
+/* out[b, :] = x[b, idx[b], :]  (CLIP EOT-token pooling, controller/method/genima_act.py:337-343) */
+int32_t gn_gather_rows(gn_ctx* ctx, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D);
 
 /* ---- misc elementwise / gather ------------------------------------------------------------------------------------ */
 int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n);              /* f16, n % 8 == 0 */

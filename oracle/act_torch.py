@@ -1,0 +1,128 @@
+"""CPU oracle: fp32 PyTorch restatement of the ACT controller forward the reference runs through RoboBase.
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  PARITY UNPINNED: the arithmetic lives in RoboBase (unpinned git
+dependency, README.md:40-46; call sites controller/method/genima_act.py:2-18, :27-92, :165-214) which is absent from
+/root/reference and this image, and the reference has no tests.  This restates the public ACT / DETR semantics RoboBase vendors
+(SURVEY.md Appendix E): ResNet-18 with FrozenBatchNorm per view -> 1x1 input_proj -> views concatenated along width -> sine
+positional embedding -> post-norm DETR encoder(4)/decoder(6) over [latent, proprio, task] + image tokens with 20 learned queries
+-> action / is_pad heads; plus the reference-owned pieces: ImageNet normalisation (genima_act.py:146-148, :188), the 2-layer
+state MLP (:237-241), z = 0 prior at inference (:70-75).  Language conditioning is restated as a projected task token
+([VERIFY] against a real latest.pt: FiLM inside the ResNet is not restated).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+_id = lambda t: t  # noqa: E731
+
+
+def frozen_bn(sd, p, x, eps=1e-5):
+    scale = sd[p + ".weight"] * (sd[p + ".running_var"] + eps).rsqrt()
+    shift = sd[p + ".bias"] - sd[p + ".running_mean"] * scale
+    return x * scale[None, :, None, None] + shift[None, :, None, None]
+
+
+def basic_block(sd, p, x, stride, q=_id):
+    idt = x
+    h = q(F.relu(frozen_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1))))
+    h = frozen_bn(sd, p + ".bn2", F.conv2d(h, sd[p + ".conv2.weight"], None, 1, 1))
+    if (p + ".downsample.0.weight") in sd:
+        idt = q(frozen_bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0)))
+    return q(F.relu(h + idt))
+
+
+def resnet18_features(sd, x, q=_id):
+    p = "backbone"
+    h = q(F.relu(frozen_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, 2, 3))))
+    h = F.max_pool2d(h, 3, 2, 1)
+    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        h = basic_block(sd, f"{p}.layer{li}.0", h, stride, q)
+        h = basic_block(sd, f"{p}.layer{li}.1", h, 1, q)
+    return h
+
+
+def sine_pos_embed(H, W, d, temperature=10000.0) -> torch.Tensor:
+    """DETR PositionEmbeddingSine(normalize=True, scale=2*pi) for one camera's HxW map -> [d, H, W]."""
+    npf = d // 2
+    eps, scale = 1e-6, 2 * math.pi
+    y = torch.arange(1, H + 1, dtype=torch.float32)[:, None].expand(H, W)
+    x = torch.arange(1, W + 1, dtype=torch.float32)[None, :].expand(H, W)
+    y = y / (H + eps) * scale
+    x = x / (W + eps) * scale
+    dim_t = temperature ** (2 * (torch.arange(npf, dtype=torch.float32) // 2) / npf)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), dim=3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), dim=3).flatten(2)
+    return torch.cat((py, px), dim=2).permute(2, 0, 1)
+
+
+def mha(sd, p, q_in, k_in, v_in, heads, q=_id):
+    """nn.MultiheadAttention (batch-first tensors [B, N, d]) with packed in_proj."""
+    d = q_in.shape[-1]
+    W, b = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
+    qq = q(F.linear(q_in, W[:d], b[:d]))
+    kk = q(F.linear(k_in, W[d:2 * d], b[d:2 * d]))
+    vv = q(F.linear(v_in, W[2 * d:], b[2 * d:]))
+    B, Nq, _ = qq.shape
+    hd = d // heads
+    qh, kh, vh = (t.view(B, -1, heads, hd).transpose(1, 2) for t in (qq, kk, vv))
+    a = torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, dim=-1) @ vh
+    a = q(a.transpose(1, 2).reshape(B, Nq, d))
+    return F.linear(a, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
+
+
+def ln(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: torch.Tensor = None, q=_id):
+    """images_u8: [B, V, 3, H, W] values 0..255; qpos [B, state_dim]; task_emb [B, lang_dim] or None.
+    -> (a_hat [B, num_queries, action_dim], is_pad_hat [B, num_queries, 1])."""
+    B, V = images_u8.shape[:2]
+    d, heads = cfg["hidden_dim"], cfg["nheads"]
+    mean = torch.tensor(IMAGENET_MEAN)[None, :, None, None]
+    std = torch.tensor(IMAGENET_STD)[None, :, None, None]
+    x = q((images_u8.float().flatten(0, 1) / 255.0 - mean) / std)
+    f = resnet18_features(sd, x, q)                                        # [B*V, 512, h, w]
+    f = q(F.conv2d(f, sd["input_proj.weight"], sd["input_proj.bias"]))     # [B*V, d, h, w]
+    h, w = f.shape[-2:]
+    f = f.view(B, V, d, h, w).permute(0, 2, 3, 1, 4).reshape(B, d, h, V * w)   # views along width
+    pos = sine_pos_embed(h, w, d).repeat(1, 1, V)                           # [d, h, V*w]
+    src = f.flatten(2).transpose(1, 2)                                      # [B, N, d]
+    pos = q(pos.flatten(1).t())[None].expand(B, -1, -1)
+    proprio = F.linear(q(F.linear(qpos, sd["input_proj_robot_state.0.weight"], sd["input_proj_robot_state.0.bias"])),
+                       sd["input_proj_robot_state.2.weight"], sd["input_proj_robot_state.2.bias"])
+    latent = F.linear(torch.zeros(B, cfg["latent_dim"]), sd["latent_out_proj.weight"], sd["latent_out_proj.bias"])
+    extra = [latent, proprio]
+    if cfg.get("use_lang_cond") and task_emb is not None:
+        extra.append(F.linear(task_emb, sd["task_proj.weight"], sd["task_proj.bias"]))
+    n_extra = len(extra)
+    src = q(torch.cat([torch.stack(extra, dim=1), src], dim=1))
+    pos = q(torch.cat([sd["additional_pos_embed.weight"][:n_extra][None].expand(B, -1, -1), pos], dim=1))
+    for i in range(cfg["enc_layers"]):
+        p = f"transformer.encoder.layers.{i}"
+        qk = q(src + pos)
+        src = q(ln(sd, p + ".norm1", src + mha(sd, p + ".self_attn", qk, qk, src, heads, q)))
+        ff = F.linear(q(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"]))), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+        src = q(ln(sd, p + ".norm2", src + ff))
+    memory = src
+    mem_pos = q(memory + pos)
+    nq = cfg["num_queries"]
+    qpos_e = q(sd["query_embed.weight"])[None].expand(B, -1, -1)
+    tgt = torch.zeros(B, nq, d)
+    for i in range(cfg["dec_layers"]):
+        p = f"transformer.decoder.layers.{i}"
+        qk = q(tgt + qpos_e)
+        tgt = q(ln(sd, p + ".norm1", tgt + mha(sd, p + ".self_attn", qk, qk, tgt, heads, q)))
+        tgt = q(ln(sd, p + ".norm2", tgt + mha(sd, p + ".multihead_attn", q(tgt + qpos_e), mem_pos, memory, heads, q)))
+        ff = F.linear(q(F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"]))), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+        tgt = q(ln(sd, p + ".norm3", tgt + ff))
+    hs = q(ln(sd, "transformer.decoder.norm", tgt))
+    a_hat = F.linear(hs, sd["action_head.weight"], sd["action_head.bias"])
+    is_pad = F.linear(hs, sd["is_pad_head.weight"], sd["is_pad_head.bias"])
+    return a_hat, is_pad
