@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay each call as one captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-act", action="store_true", help="skip the ACT controller forward after each pipeline call")
     ap.add_argument("--dump-ops", default=None, help="write the per-(kernel, shape) HIP-event timing table of one call to this CSV")
     args = ap.parse_args()
 
@@ -180,11 +181,32 @@ def main():
     pipe.enable_hip_graph(args.graph)
     ids, img, lat = synthetic_inputs(pipe, B, H, W, dev, rank)
 
+    # ACT controller forward on the generated joint-target images (BASELINE.json configs[2]: "... + ACT controller forward")
+    act_agent = None
+    if H == 512 and not args.no_act:
+        from genima_amd.act import GenimaACT
+
+        fam = configs.family(args.family)
+        act_agent = GenimaACT(fam["act"], None, fam["act_text"], None, device=dev, seed=0)
+        g = torch.Generator().manual_seed(7 + rank)
+        act_state = torch.randn(B, 1, fam["act"]["state_dim"], generator=g).to(dev)
+        Vc = fam["act_text"]["vocab_size"]
+        act_tokens = torch.zeros(B, 1, 77, dtype=torch.int32)
+        act_tokens[:, 0, :14] = torch.tensor([Vc - 2] + [320 + i for i in range(12)] + [Vc - 1], dtype=torch.int32)
+        act_tokens = act_tokens.to(dev)
+
     def call(output_type="pt"):
-        return pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=args.denoise_steps, guidance_scale=0.0,
-                    output_type=output_type)
+        out = pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=args.denoise_steps, guidance_scale=0.0,
+                   output_type="pt" if act_agent is not None else output_type)
+        if act_agent is not None:
+            actions = act_agent.act_tiled(out.images, act_state, act_tokens)  # [B, 20, 8] on the device
+            if output_type == "np":  # the reference's brackets: images to host PIL (gen_time) + actions to host (control_time)
+                return out.images.cpu().numpy(), actions.float().cpu().numpy()
+            return actions
+        return out
 
     def barrier():
+        torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -197,10 +219,9 @@ def main():
         call()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    from genima_amd.dist import max_over_ranks
+
+    dt = max_over_ranks(dt, dev)  # the slowest rank defines the job's time
     calls = args.steps
     value = 4.0 * B * world * calls / dt
 
@@ -212,6 +233,17 @@ def main():
     torch.cuda.synchronize(dev)
     dt_host = (time.perf_counter() - t1) / max(1, min(3, calls))
 
+    act_ms = None
+    if act_agent is not None:  # controller forward alone (the reference's control_time bracket minus the D->H copy)
+        tiled = pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=args.denoise_steps, guidance_scale=0.0,
+                     output_type="pt").images
+        torch.cuda.synchronize(dev)
+        t2 = time.perf_counter()
+        for _ in range(5):
+            act_agent.act_tiled(tiled, act_state, act_tokens)
+        torch.cuda.synchronize(dev)
+        act_ms = (time.perf_counter() - t2) / 5 * 1000.0
+
     out = {
         "metric": "joint-target images/sec (SD-Turbo + ControlNet, 4-view tiled 512x512, 5 steps, incl. CLIP text + VAE decode)"
         if H == 512 else "images/sec (SD-Turbo + ControlNet 256x256 single view, 5 steps, incl. CLIP text + VAE decode)",
@@ -220,8 +252,9 @@ def main():
         "dtype": "f16 (f32 accumulate)", "data": "synthetic (seeded random-init SD-Turbo-architecture weights, counter-PRNG images)",
         "config": {"workload": desc, "family": args.family, "per_gpu_batch": B, "global_batch": B * world,
                    "image": f"{H}x{W}", "denoise_steps": args.denoise_steps, "parallelism": f"replicas x{world} (episodes sharded, no collective)",
-                   "hip_graph": bool(args.graph), "act_controller_forward": False},
+                   "hip_graph": bool(args.graph), "act_controller_forward": act_agent is not None},
         "images_per_sec_per_gpu": value / world,
+        "act_controller_ms_per_call": act_ms,
         "value_incl_d2h_to_host": (4.0 if H == 512 else 1.0) * B / dt_host,
         "algorithmic_tflops_per_gpu": GFLOP_PER_CALL.get(H, 0.0) * B * calls / dt / 1000.0,
     }

@@ -265,6 +265,22 @@ class GenimaACT:
         out = proj.view(shp[0], shp[1], -1)[:, 0].to(torch.float32)  # text does not change across frames
         return out, x
 
+    def act_tiled(self, tiled_u8: torch.Tensor, low_dim_state: torch.Tensor, lang_tokens: Optional[torch.Tensor]) -> torch.Tensor:
+        """Device-resident fast path of eval_genima.py:224-247: the pipeline's uint8 tiled output [B, 2v, 2v, 3] is untiled on
+        the device (crop order of controller/utils/misc.py:25-30 -> camera order of the tile) and fed straight to the policy."""
+        B, H2, W2, _ = tiled_u8.shape
+        v = H2 // 2
+        crops = [tiled_u8[:, y:y + v, x:x + v] for (x, y) in ((0, 0), (v, 0), (0, v), (v, v))]
+        img = torch.stack(crops, dim=1).contiguous()  # [B, 4, v, v, 3]
+        qpos = low_dim_state.to(self.device).flatten(1)
+        sdim = (qpos.shape[1] + 7) // 8 * 8
+        qp = torch.zeros(B, sdim, dtype=torch.float16, device=self.device)
+        qp[:, : qpos.shape[1]] = qpos.to(torch.float16)
+        task = None
+        if self.config.get("use_lang_cond") and lang_tokens is not None:
+            task = self.encode_clip_text(lang_tokens)[0].to(torch.float16)
+        return emit_act_forward(self._engine, self.W, self.config, img, qp, task)[0]
+
     def act(self, obs: Dict[str, torch.Tensor], step: int = 0, eval_mode: bool = True) -> torch.Tensor:
         """obs: {'<cam>_rgb': uint8/float [B, fs, 3, H, W], 'low_dim_state': f32 [B, fs, state], 'lang_tokens': int [B, fs, 77]}."""
         if self._engine is None:
