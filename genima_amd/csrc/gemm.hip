@@ -43,6 +43,7 @@ struct GemmParams {
   float out_scale;
   int splitk, kper;
   int tiles_m, tiles_n;
+  unsigned a_bytes, a2_bytes, w_bytes;  // LDS-DMA variant: buffer-descriptor extents (everything else reads as zero)
 };
 
 // erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below f16 resolution): ~12 VALU instead of ocml erff's ~50, which
@@ -127,6 +128,54 @@ __device__ __forceinline__ void epilogue_geglu4(const GemmParams& p, int m, int 
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (f16)(hv[i] * gelu_fast(gv[i]));
   *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + oc) = o;
+}
+
+// ---- wave-level epilogue: the lane holds D[n = 8g + 4hi + (r&3)][m = lane&31] of each 32x32 tile ----------------------------
+template <int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi,
+                                              int z) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + i * 32 + l31;
+    if (m >= p.M) continue;
+    if (p.splitk > 1) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N) {
+            f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+            *reinterpret_cast<f32x4*>(p.ws + ((long)z * p.M + m) * p.N + nb) = v;
+          }
+        }
+    } else if (p.act == GN_ACT_GEGLU) {
+      if constexpr (TN % 2 == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; j += 2)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nh = nbase + j * 32 + 8 * g + 4 * hi;
+            if (nh + 32 < p.N) {
+              const int oc = ((nbase + j * 32) >> 1) + 8 * g + 4 * hi;
+              float h[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+              float gg[4] = {acc[j + 1][i][4 * g], acc[j + 1][i][4 * g + 1], acc[j + 1][i][4 * g + 2],
+                             acc[j + 1][i][4 * g + 3]};
+              epilogue_geglu4(p, m, nh, nh + 32, oc, h, gg);
+            }
+          }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N)
+            epilogue_store4(p, m, nb, acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
+        }
+    }
+  }
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
@@ -311,49 +360,195 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
     cur ^= 1;
   }
 
-  // ---- epilogue: lane holds D[n = 8g + 4hi + (r&3)][m = lane&31] per 32x32 tile ----------------------------------------
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+}
+
+// ======================================================================================================================
+// LDS-DMA variant: the same tile / MFMA / epilogue structure, but the K tiles go global -> LDS directly with
+// `buffer_load_dwordx4 ... lds` (no staging VGPRs, no ds_write pass).  One wave-instruction moves 64 lanes x 16 B = eight
+// 128-byte tile rows; LDS-DMA destinations are lane-linear, so the XOR swizzle is applied on the SOURCE side: lane q fetches
+// the logical chunk (q & 7) ^ ((row >> 1) & 7) of row 8*group + (q >> 3), which lands at physical chunk q & 7 -- exactly the
+// image lds_swz<128> reads back.  Out-of-range lanes (conv padding, M/N/K tails) use an out-of-bounds buffer offset: the
+// hardware writes ZEROS to LDS for them (tools/probes/lds_dma_probe.hip verifies this on gfx950), so the conv zero padding
+// costs nothing.  Freed registers allow 128x64 wave tiles (256x256 block, 8 waves).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+constexpr unsigned kOOB = 0xFFFFFFF0u;
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile >= 32x32");
+  static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA groups per wave");
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // DMA instructions per wave per tile
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA bases live in M0)
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.kper;
+  const int kend = min(p.K, kbeg + p.kper);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // ---- loader state: this lane's row inside each 8-row group and its (swizzled) logical chunk -----------------------------
+  const int lr = lane >> 3;
+  const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+  int kcur = kbeg + chunk * 8;
+
+  const int Cin = p.C1 + p.C2;
+  const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
+  int iy0[GA], ix0[GA], pbase[GA], pix[GA];
+  unsigned aoff[GA];  // dense: byte offset of the row start (kOOB if the row is out of range)
+  int cc = 0, dy = 0, dx = 0;
+  int cu = 0;         // wave-uniform channel offset of the tile inside its tap (selects the concat source)
+
+  auto set_tap = [&]() {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = m0 + wm * WTM + i * 32 + l31;
-    if (m >= p.M) continue;
-    if (p.splitk > 1) {
+    for (int i = 0; i < GA; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+      const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+      pix[i] = ok ? pbase[i] + sy * p.W + sx : -1;
+    }
+  };
+
+  if constexpr (CONV) {
+    const int hw = p.Ho * p.Wo;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < GA; ++i) {
+      const int m = m0 + 8 * (wave + NW * i) + lr;
+      if (m < p.M) {
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        iy0[i] = oy * p.stride - p.pad_t;
+        ix0[i] = ox * p.stride - p.pad_l;
+        pbase[i] = b * p.H * p.W;
+      } else {
+        iy0[i] = -(1 << 28);
+        ix0[i] = -(1 << 28);
+        pbase[i] = 0;
+      }
+    }
+    const int tap = kcur / Cin;
+    cc = kcur - tap * Cin;
+    dy = tap / p.KW;
+    dx = tap - dy * p.KW;
+    cu = kbeg % Cin;
+    set_tap();
+  } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
-          if (nb < p.N) {
-            f32x4 v = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-            *reinterpret_cast<f32x4*>(p.ws + ((long)z * p.M + m) * p.N + nb) = v;
-          }
-        }
-    } else if (p.act == GN_ACT_GEGLU) {
-      if constexpr (TN % 2 == 0) {
+    for (int i = 0; i < GA; ++i) {
+      const int m = m0 + 8 * (wave + NW * i) + lr;
+      aoff[i] = (m < p.M) ? (unsigned)((long)m * p.lda * 2) : kOOB;
+    }
+  }
+  unsigned woff[GB];
 #pragma unroll
-        for (int j = 0; j < TN; j += 2)
+  for (int i = 0; i < GB; ++i) {
+    const int n = n0 + 8 * (wave + NW * i) + lr;
+    woff[i] = (n < p.N) ? (unsigned)((long)n * p.ldw * 2) : kOOB;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+  auto dma_tile = [&](int buf) {
+    const bool kok = kcur < kend;
+    unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+    unsigned char* Bs = As + A_BYTES;
+    if constexpr (CONV) {
+      const bool first = cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
+      const int cs = first ? p.C1 : p.C2;
+      const int co = first ? cc : cc - p.C1;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int nh = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
-            if (nh + 32 < p.N) {
-              const int oc = ((n0 + wn * WTN + j * 32) >> 1) + 8 * g + 4 * hi;
-              float h[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-              float gg[4] = {acc[j + 1][i][4 * g], acc[j + 1][i][4 * g + 1], acc[j + 1][i][4 * g + 2],
-                             acc[j + 1][i][4 * g + 3]};
-              epilogue_geglu4(p, m, nh, nh + 32, oc, h, gg);
-            }
-          }
+      for (int i = 0; i < GA; ++i) {
+        const unsigned voff = (kok && pix[i] >= 0) ? (unsigned)(((long)pix[i] * cs + co) * 2) : kOOB;
+        lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
+        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
       }
     } else {
 #pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const unsigned voff = (kok && aoff[i] != kOOB) ? aoff[i] + (unsigned)kcur * 2u : kOOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const unsigned voff = (kok && woff[i] != kOOB) ? woff[i] + (unsigned)kcur * 2u : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+    }
+    kcur += BK;
+    if constexpr (CONV) {
+      cu += BK;
+      while (cu >= Cin) cu -= Cin;
+      cc += BK;
+      if (cc >= Cin) {
+        do {
+          cc -= Cin;
+          if (++dx == p.KW) { dx = 0; ++dy; }
+        } while (cc >= Cin);
+        set_tap();
+      }
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma_tile(cur ^ 1);  // lands under this tile's MFMAs; buf[cur^1] was last read before the previous barrier
+    const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      f16x8 fa[TM], fw[TN];
+      const int c = kk * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f16x8*>(As + lds_swz<128>(wm * WTM + i * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fw[j] = *reinterpret_cast<const f16x8*>(Bs + lds_swz<128>(wn * WTN + j * 32 + l31, c));
+#pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
-          if (nb < p.N)
-            epilogue_store4(p, m, nb, acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-        }
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
+    __syncthreads();
+    cur ^= 1;
   }
+
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
 }
 
 // split-K: sum the f32 partial slabs in a fixed order and apply the fused epilogue
@@ -377,6 +572,15 @@ void launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
 }
 
+template <int BM, int BN, int WM, int WN>
+void launch_dma(const GemmParams& p, bool conv, hipStream_t st) {
+  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, 1);
+  if (conv)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
+}
+
 struct Plan {
   int cfg;  // index into kCfg
   int bm, bn, splitk, kper;
@@ -384,10 +588,34 @@ struct Plan {
 
 // tile configurations: {BM, BN, relative MFMA rate on large problems (tools/bench_gemm.py), GEGLU-capable (wave tile >= 64
 // columns)}.  Index + 1 is the public gn_gemm_desc::tile value.
-struct Cfg { int bm, bn; double eff; bool geglu; };
-constexpr Cfg kCfg[] = {{256, 128, 1.00, true}, {128, 128, 1.00, true}, {128, 64, 0.85, false}, {64, 64, 0.65, false},
-                        {256, 64, 0.90, true},  {128, 256, 1.00, true}};
-constexpr int kNumCfg = 6;
+struct Cfg { int bm, bn; double eff; bool geglu; bool dma; };
+constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, false}, {128, 64, 0.85, false, false},
+                        {64, 64, 0.65, false, false},  {256, 64, 0.90, true, false},  {128, 256, 1.00, true, false},
+                        // LDS-DMA variants (never picked by the fallback heuristic: eff 0; the host autotuner times them)
+                        {256, 256, 0.0, true, true},   {256, 128, 0.0, true, true},   {128, 128, 0.0, true, true},
+                        {128, 64, 0.0, false, true},   {64, 64, 0.0, false, true},    {256, 64, 0.0, true, true}};
+constexpr int kNumCfg = 12;
+
+// buffer-descriptor extents of the LDS-DMA variant (32-bit byte offsets; kOOB must stay out of range)
+struct DmaBytes { uint64_t a, a2, w; };
+DmaBytes dma_bytes(const gn_gemm_desc* d) {
+  DmaBytes b;
+  if (d->conv) {
+    const uint64_t px = (uint64_t)d->B * d->H * d->W;
+    b.a = px * d->C1 * 2; b.a2 = px * d->C2 * 2;
+  } else {
+    b.a = (uint64_t)d->M * d->lda * 2; b.a2 = 0;
+  }
+  b.w = (uint64_t)d->N * d->ldw * 2;
+  return b;
+}
+bool dma_eligible(const gn_gemm_desc* d) {
+  const DmaBytes b = dma_bytes(d);
+  const uint64_t lim = 0xFFFFFF00ull;
+  if (b.a >= lim || b.a2 >= lim || b.w >= lim) return false;
+  if (d->conv && d->a2 && (d->C1 % 64 != 0 || (d->C1 + d->C2) % 64 != 0)) return false;  // a K tile must not straddle the concat
+  return true;
+}
 
 int g_tile_override = -2;
 int tile_override() {
@@ -425,6 +653,10 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (ov >= 0 && ov < kNumCfg) best = ov;
   if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
   if (geglu && !kCfg[best].geglu) best = 1;
+  if (kCfg[best].dma && !dma_eligible(d)) {
+    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4};
+    best = fallback[best];
+  }
   pl.cfg = best;
   pl.bm = kCfg[best].bm; pl.bn = kCfg[best].bn;
   const int64_t blocks = cdiv64(M, pl.bm) * cdiv64(N, pl.bn);
@@ -502,6 +734,10 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   if (d->shift) GN_REQUIRE(d->rows_per_batch > 0 && p.ldshift % 4 == 0 && ((uintptr_t)d->shift & 7) == 0, "gn_gemm: shift needs rows_per_batch and 8-byte aligned rows");
 
   Plan pl = plan_gemm(d);
+  {
+    const DmaBytes db = dma_bytes(d);
+    p.a_bytes = (unsigned)db.a; p.a2_bytes = (unsigned)(db.a2 ? db.a2 : db.a); p.w_bytes = (unsigned)db.w;
+  }
   p.splitk = pl.splitk; p.kper = pl.kper;
   p.tiles_m = (int)cdiv64(d->M, pl.bm); p.tiles_n = (int)cdiv64(d->N, pl.bn);
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
@@ -513,7 +749,13 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 2: launch_cfg<128, 64, 2, 2>(p, conv, ctx->stream); break;
     case 3: launch_cfg<64, 64, 2, 2>(p, conv, ctx->stream); break;
     case 4: launch_cfg<256, 64, 4, 1>(p, conv, ctx->stream); break;
-    default: launch_cfg<128, 256, 2, 4>(p, conv, ctx->stream); break;
+    case 5: launch_cfg<128, 256, 2, 4>(p, conv, ctx->stream); break;
+    case 6: launch_dma<256, 256, 2, 4>(p, conv, ctx->stream); break;
+    case 7: launch_dma<256, 128, 4, 2>(p, conv, ctx->stream); break;
+    case 8: launch_dma<128, 128, 2, 2>(p, conv, ctx->stream); break;
+    case 9: launch_dma<128, 64, 2, 2>(p, conv, ctx->stream); break;
+    case 10: launch_dma<64, 64, 2, 2>(p, conv, ctx->stream); break;
+    default: launch_dma<256, 64, 4, 1>(p, conv, ctx->stream); break;
   }
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {
