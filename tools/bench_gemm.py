@@ -10,7 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genima_amd.engine import Engine  # noqa: E402
 
 E = Engine("cuda:0")
-CFG = ["256x128", "128x128", "128x64", "64x64", "256x64", "128x256"]
+CFG = ["256x128", "128x128", "128x64", "64x64", "256x64", "128x256",
+       "D256x256", "D256x128", "D128x128", "D128x64", "D64x64", "D256x64"]
+ALL = tuple(int(c) for c in os.environ.get("CFGS", "0,1,2,3,4,5,6,7,8,9,10,11").split(","))
 
 
 def timeit(fn, iters=20):
@@ -24,7 +26,7 @@ def timeit(fn, iters=20):
     return E.event_elapsed_ms(a, b) / iters
 
 
-def run(name, fn, flops, cfgs=(0, 1, 2, 3, 4, 5)):
+def run(name, fn, flops, cfgs=ALL):
     row = []
     for c in cfgs:
         E.lib.gn_set_gemm_tile_override(c)
@@ -63,4 +65,4 @@ for tok, c in [(4096, 320), (1024, 640), (256, 1280)]:
     x = h(B * tok, c)
     w = h(8 * c, c)
     b = h(8 * c)
-    run(f"geglu {B}x{tok} C={c}", lambda: E.linear(x, w, b, act=5), 2.0 * B * tok * c * 8 * c, cfgs=(0, 1, 4, 5))
+    run(f"geglu {B}x{tok} C={c}", lambda: E.linear(x, w, b, act=5), 2.0 * B * tok * c * 8 * c, cfgs=tuple(c for c in ALL if c in (0, 1, 4, 5, 6, 7, 8, 11)))
