@@ -229,7 +229,7 @@ class GenimaACT:
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.W = pack_act(self._sd, self.device)
         self.Wclip = packing.pack_state_dict(self._clip_sd, self.device)
-        self._engine = Engine(self.device)
+        self._engine = Engine(self.device, autotune=True)  # eager engine, but the GEMM tiles are still tuned per shape
         return self
 
     def train(self, mode: bool = True):

@@ -593,8 +593,10 @@ constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, fa
                         {64, 64, 0.65, false, false},  {256, 64, 0.90, true, false},  {128, 256, 1.00, true, false},
                         // LDS-DMA variants (never picked by the fallback heuristic: eff 0; the host autotuner times them)
                         {256, 256, 0.0, true, true},   {256, 128, 0.0, true, true},   {128, 128, 0.0, true, true},
-                        {128, 64, 0.0, false, true},   {64, 64, 0.0, false, true},    {256, 64, 0.0, true, true}};
-constexpr int kNumCfg = 12;
+                        {128, 64, 0.0, false, true},   {64, 64, 0.0, false, true},    {256, 64, 0.0, true, true},
+                        // 320-wide N tiles: the 64x64-latent UNet level (N = 320) without padded-tile waste
+                        {128, 320, 0.0, false, true},  {256, 320, 0.0, false, true}};
+constexpr int kNumCfg = 14;
 
 // buffer-descriptor extents of the LDS-DMA variant (32-bit byte offsets; kOOB must stay out of range)
 struct DmaBytes { uint64_t a, a2, w; };
@@ -654,7 +656,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
   if (geglu && !kCfg[best].geglu) best = 1;
   if (kCfg[best].dma && !dma_eligible(d)) {
-    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4};
+    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0};
     best = fallback[best];
   }
   pl.cfg = best;
@@ -755,7 +757,9 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 8: launch_dma<128, 128, 2, 2>(p, conv, ctx->stream); break;
     case 9: launch_dma<128, 64, 2, 2>(p, conv, ctx->stream); break;
     case 10: launch_dma<64, 64, 2, 2>(p, conv, ctx->stream); break;
-    default: launch_dma<256, 64, 4, 1>(p, conv, ctx->stream); break;
+    case 11: launch_dma<256, 64, 4, 1>(p, conv, ctx->stream); break;
+    case 12: launch_dma<128, 320, 2, 2>(p, conv, ctx->stream); break;
+    default: launch_dma<256, 320, 4, 2>(p, conv, ctx->stream); break;
   }
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {

@@ -71,7 +71,8 @@ typedef struct gn_gemm_desc {
   int32_t out_mode;       /* GN_OUT_*; BATCH_TRANSPOSED: out[b][n][m - b*rows_per_batch], row stride ldo, batch stride N*ldo */
   int32_t rows_per_batch; /* for shift / transposed output; 0 = M */
   int32_t splitk;         /* 0 = library heuristic, >=1 explicit */
-  int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} block tile
+  int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} register-staged block tile,
+                             7..14 = {256x256, 256x128, 128x128, 128x64, 64x64, 256x64, 128x320, 256x320} LDS-DMA block tile
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */

@@ -11,8 +11,8 @@ from genima_amd.engine import Engine  # noqa: E402
 
 E = Engine("cuda:0")
 CFG = ["256x128", "128x128", "128x64", "64x64", "256x64", "128x256",
-       "D256x256", "D256x128", "D128x128", "D128x64", "D64x64", "D256x64"]
-ALL = tuple(int(c) for c in os.environ.get("CFGS", "0,1,2,3,4,5,6,7,8,9,10,11").split(","))
+       "D256x256", "D256x128", "D128x128", "D128x64", "D64x64", "D256x64", "D128x320", "D256x320"]
+ALL = tuple(int(c) for c in os.environ.get("CFGS", "0,1,2,3,4,5,6,7,8,9,10,11,12,13").split(","))
 
 
 def timeit(fn, iters=20):
