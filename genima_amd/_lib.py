@@ -77,6 +77,12 @@ SIGNATURES = {
     "gn_image_f16_to_u8": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_image_normalize_u8": (_I32, [_P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _F]),
     "gn_gather_rows": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32]),
+    "gn_argmax_rows_i32": (_I32, [_P, _P, _P, _I32, _I32]),
+    "gn_copy4d": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),
+    "gn_program_add_image_normalize_u8": (_I32, [_P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _F]),
+    "gn_program_add_gather_rows": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32]),
+    "gn_program_add_copy4d": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),
+    "gn_program_add_argmax_rows_i32": (_I32, [_P, _P, _P, _I32, _I32]),
     "gn_add": (_I32, [_P, _P, _P, _P, _I64]),
     "gn_act": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),

@@ -127,81 +127,104 @@ def pack_act(sd: Dict[str, torch.Tensor], device) -> Dict[str, torch.Tensor]:
     return W
 
 
-def emit_act_forward(E: Engine, W, cfg, img_u8_nhwc: torch.Tensor, qpos: torch.Tensor, task_emb: Optional[torch.Tensor]):
-    """img_u8_nhwc: uint8 [B, V, H, W, 3]; qpos f16 [B, state_dim_pad8]; task_emb f16 [B, lang_dim] or None."""
+def emit_act_forward(E: Engine, W, Wclip, cfg, ccfg, img_u8_nhwc: torch.Tensor, qpos: torch.Tensor,
+                     tokens: Optional[torch.Tensor]):
+    """img_u8_nhwc: uint8 [B, V, H, W, 3]; qpos f16 [B, state_dim_pad8]; tokens int32 [B, 77] or None.
+    Every step is an Engine op (recordable: ``GenimaACT`` replays the whole controller forward from C++); the only torch calls
+    are build-time constants (sine positions, zero / broadcast buffers).  -> (a_hat [B, nq, 8-padded], is_pad [B, nq, 8-padded])."""
     B, V, H, Wd, _ = img_u8_nhwc.shape
     d, heads = cfg["hidden_dim"], cfg["nheads"]
-    x = E.image_normalize_u8(img_u8_nhwc.view(B * V, H, Wd, 3), IMAGENET_MEAN, IMAGENET_STD, 8)
-    p = "backbone"
-    h = E.conv2d(x, W[p + ".conv1.weight"], W[p + ".conv1.bias"], ksize=7, stride=2, act=ACT_RELU)
-    h = E.maxpool3x3s2(h)
-    for li, c, stride in _RESNET18:
-        for bi in range(2):
-            q = f"{p}.layer{li}.{bi}"
-            st = stride if bi == 0 else 1
-            y = E.conv2d(h, W[q + ".conv1.weight"], W[q + ".conv1.bias"], stride=st, act=ACT_RELU)
-            idt = h
-            if (q + ".downsample.0.weight") in W:
-                idt = E.conv2d(h, W[q + ".downsample.0.weight"], W[q + ".downsample.0.bias"], ksize=1, stride=st, pad=(0, 0, 0, 0))
-            h = E.conv2d(y, W[q + ".conv2.weight"], W[q + ".conv2.bias"], residual=idt, act=ACT_RELU, residual_before_act=True)
-    f = E.conv2d(h, W["input_proj.weight"], W["input_proj.bias"], ksize=1, pad=(0, 0, 0, 0))   # [B*V, fh, fw, d]
-    fh, fw = f.shape[1], f.shape[2]
-    f = f.view(B, V, fh, fw, d).permute(0, 2, 1, 3, 4).reshape(B, fh * V * fw, d)              # views along width (layout interop)
-    pos_img = sine_pos_embed(fh, fw, d).repeat(1, V, 1).reshape(fh * V * fw, d)
+    dev = E.device
+    with E.scope("act"):
+        # ---- language conditioning: CLIP text tower -> EOT row -> text_projection -> task token ---------------------------
+        task = None
+        if cfg.get("use_lang_cond") and tokens is not None:
+            xt = graphs.emit_clip_text(E, Wclip, ccfg, tokens)
+            eot = E.argmax_rows(tokens, name="eot")
+            pooled = E.gather_rows(xt, eot, name="pooled")
+            task = E.linear(pooled, Wclip["text_projection.weight"], name="task_emb")
+        # ---- ResNet-18 per view (FrozenBN folded; ReLU / identity add in the conv epilogues) ---------------------------------
+        x = E.image_normalize_u8(img_u8_nhwc.view(B * V, H, Wd, 3), IMAGENET_MEAN, IMAGENET_STD, 8, name="img")
+        p = "backbone"
+        h = E.conv2d(x, W[p + ".conv1.weight"], W[p + ".conv1.bias"], ksize=7, stride=2, act=ACT_RELU, name="c1")
+        h = E.maxpool3x3s2(h, name="mp")
+        for li, c, stride in _RESNET18:
+            for bi in range(2):
+                q = f"{p}.layer{li}.{bi}"
+                st = stride if bi == 0 else 1
+                y = E.conv2d(h, W[q + ".conv1.weight"], W[q + ".conv1.bias"], stride=st, act=ACT_RELU, name=q + ".c1")
+                idt = h
+                if (q + ".downsample.0.weight") in W:
+                    idt = E.conv2d(h, W[q + ".downsample.0.weight"], W[q + ".downsample.0.bias"], ksize=1, stride=st,
+                                   pad=(0, 0, 0, 0), name=q + ".ds")
+                h = E.conv2d(y, W[q + ".conv2.weight"], W[q + ".conv2.bias"], residual=idt, act=ACT_RELU, residual_before_act=True,
+                             name=q + ".c2")
+        f = E.conv2d(h, W["input_proj.weight"], W["input_proj.bias"], ksize=1, pad=(0, 0, 0, 0), name="input_proj")  # [B*V, fh, fw, d]
+        fh, fw = f.shape[1], f.shape[2]
+        # ---- encoder sequence [latent, proprio, (task), image tokens]; views concatenated along WIDTH ----------------------
+        n_extra = 3 if task is not None else 2
+        n_img = fh * V * fw
+        N = n_extra + n_img
+        src = E.buf("src", (B, N, d))
+        zeros = E.buf("zero_latent", (B, W["latent_out_proj.weight"].shape[1]), zero=True)
+        E.linear(zeros, W["latent_out_proj.weight"], W["latent_out_proj.bias"], out=src[:, 0])  # z = 0 prior (genima_act.py:70-75)
+        pr = E.linear(qpos, W["input_proj_robot_state.0.weight"], W["input_proj_robot_state.0.bias"], name="state0")
+        E.linear(pr, W["input_proj_robot_state.2.weight"], W["input_proj_robot_state.2.bias"], out=src[:, 1])
+        if task is not None:
+            E.linear(task, W["task_proj.weight"], W["task_proj.bias"], out=src[:, 2])
+        # f[(b*V + v), y, x, :] -> src[b, n_extra + y*(V*fw) + v*fw + x, :]   (index space (b, v, y, x), runs of d)
+        E.copy4d(f, src[:, n_extra:], (B, V, fh, fw), (V * fh * fw * d, fh * fw * d, fw * d, d),
+                 (N * d, fw * d, V * fw * d, d), d)
+        pos = E.buf("pos", (B, N, d))
+        if not getattr(pos, "_gn_init", False):  # build-time constant
+            pos_img = sine_pos_embed(fh, fw, d).repeat(1, V, 1).reshape(n_img, d)
+            pos.copy_(torch.cat([W["additional_pos_embed.weight"][:n_extra].float().cpu(), pos_img], dim=0).half()[None].expand(B, -1, -1))
+            pos._gn_init = True
 
-    proprio = E.linear(E.linear(qpos, W["input_proj_robot_state.0.weight"], W["input_proj_robot_state.0.bias"]),
-                       W["input_proj_robot_state.2.weight"], W["input_proj_robot_state.2.bias"])
-    zeros = torch.zeros(B, W["latent_out_proj.weight"].shape[1], dtype=torch.float16, device=E.device)
-    latent = E.linear(zeros, W["latent_out_proj.weight"], W["latent_out_proj.bias"])
-    extra = [latent, proprio]
-    if cfg.get("use_lang_cond") and task_emb is not None:
-        extra.append(E.linear(task_emb, W["task_proj.weight"], W["task_proj.bias"]))
-    n_extra = len(extra)
-    N = n_extra + f.shape[1]
-    src = torch.empty(B, N, d, dtype=torch.float16, device=E.device)
-    for i, e in enumerate(extra):
-        src[:, i] = e
-    src[:, n_extra:] = f
-    pos = torch.cat([W["additional_pos_embed.weight"][:n_extra], pos_img.half().to(E.device)], dim=0)[None].expand(B, -1, -1).contiguous()
+        def self_attn(pfx, x_qk, x_v, n, nm):
+            qk = E.linear(x_qk, W[pfx + ".qk_proj.weight"], W[pfx + ".qk_proj.bias"], name=nm + "qk")
+            vt = E.linear(x_v, W[pfx + ".v_proj.weight"], W[pfx + ".v_proj.bias"], transposed_out=True, rows_per_batch=n,
+                          pad_cols=(n + 63) // 64 * 64, name=nm + "vt")
+            return E.attention(qk[:, :, :d], qk[:, :, d:], vt, heads, Nk=n, name=nm + "a")
 
-    def self_attn(pfx, x_qk, x_v, n):
-        qk = E.linear(x_qk, W[pfx + ".qk_proj.weight"], W[pfx + ".qk_proj.bias"])
-        vt = E.linear(x_v, W[pfx + ".v_proj.weight"], W[pfx + ".v_proj.bias"], transposed_out=True, rows_per_batch=n,
-                      pad_cols=(n + 63) // 64 * 64)
-        return E.attention(qk[:, :, :d], qk[:, :, d:], vt, heads, Nk=n)
-
-    for i in range(cfg["enc_layers"]):
-        q = f"transformer.encoder.layers.{i}"
-        a = self_attn(q + ".self_attn", E.add(src, pos), src, N)
-        src = E.layernorm(E.linear(a, W[q + ".self_attn.out_proj.weight"], W[q + ".self_attn.out_proj.bias"], residual=src),
-                          W[q + ".norm1.weight"], W[q + ".norm1.bias"])
-        ffh = E.linear(src, W[q + ".linear1.weight"], W[q + ".linear1.bias"], act=ACT_RELU)
-        src = E.layernorm(E.linear(ffh, W[q + ".linear2.weight"], W[q + ".linear2.bias"], residual=src),
-                          W[q + ".norm2.weight"], W[q + ".norm2.bias"])
-    memory = src
-    mem_pos = E.add(memory, pos)
-    nq = cfg["num_queries"]
-    qe = W["query_embed.weight"][None].expand(B, -1, -1).contiguous()
-    tgt = torch.zeros(B, nq, d, dtype=torch.float16, device=E.device)
-    for i in range(cfg["dec_layers"]):
-        q = f"transformer.decoder.layers.{i}"
-        a = self_attn(q + ".self_attn", E.add(tgt, qe), tgt, nq)
-        tgt = E.layernorm(E.linear(a, W[q + ".self_attn.out_proj.weight"], W[q + ".self_attn.out_proj.bias"], residual=tgt),
-                          W[q + ".norm1.weight"], W[q + ".norm1.bias"])
-        m = q + ".multihead_attn"
-        cq = E.linear(E.add(tgt, qe), W[m + ".q_proj.weight"], W[m + ".q_proj.bias"])
-        ck = E.linear(mem_pos, W[m + ".k_proj.weight"], W[m + ".k_proj.bias"])
-        cvt = E.linear(memory, W[m + ".v_proj.weight"], W[m + ".v_proj.bias"], transposed_out=True, rows_per_batch=N, pad_cols=(N + 63) // 64 * 64)
-        a = E.attention(cq, ck, cvt, heads, Nk=N)
-        tgt = E.layernorm(E.linear(a, W[m + ".out_proj.weight"], W[m + ".out_proj.bias"], residual=tgt),
-                          W[q + ".norm2.weight"], W[q + ".norm2.bias"])
-        ffh = E.linear(tgt, W[q + ".linear1.weight"], W[q + ".linear1.bias"], act=ACT_RELU)
-        tgt = E.layernorm(E.linear(ffh, W[q + ".linear2.weight"], W[q + ".linear2.bias"], residual=tgt),
-                          W[q + ".norm3.weight"], W[q + ".norm3.bias"])
-    hs = E.layernorm(tgt, W["transformer.decoder.norm.weight"], W["transformer.decoder.norm.bias"])
-    a_hat = E.linear(hs, W["action_head.weight"], W["action_head.bias"])[..., : cfg["action_dim"]]
-    is_pad = E.linear(hs, W["is_pad_head.weight"], W["is_pad_head.bias"])[..., :1]
-    return a_hat, is_pad
+        for i in range(cfg["enc_layers"]):
+            q = f"transformer.encoder.layers.{i}"
+            nm = f"e{i}."
+            a = self_attn(q + ".self_attn", E.add(src, pos, name=nm + "xp"), src, N, nm)
+            s1 = E.linear(a, W[q + ".self_attn.out_proj.weight"], W[q + ".self_attn.out_proj.bias"], residual=src, name=nm + "o")
+            src = E.layernorm(s1, W[q + ".norm1.weight"], W[q + ".norm1.bias"], name=nm + "n1")
+            ffh = E.linear(src, W[q + ".linear1.weight"], W[q + ".linear1.bias"], act=ACT_RELU, name=nm + "f1")
+            s2 = E.linear(ffh, W[q + ".linear2.weight"], W[q + ".linear2.bias"], residual=src, name=nm + "f2")
+            src = E.layernorm(s2, W[q + ".norm2.weight"], W[q + ".norm2.bias"], name=nm + "n2")
+        memory = src
+        mem_pos = E.add(memory, pos, name="mem_pos")
+        nq = cfg["num_queries"]
+        qe = E.buf("query_pos", (B, nq, d))
+        if not getattr(qe, "_gn_init", False):
+            qe.copy_(W["query_embed.weight"][None].expand(B, -1, -1))
+            qe._gn_init = True
+        tgt = E.buf("tgt0", (B, nq, d), zero=True)
+        for i in range(cfg["dec_layers"]):
+            q = f"transformer.decoder.layers.{i}"
+            nm = f"d{i}."
+            a = self_attn(q + ".self_attn", E.add(tgt, qe, name=nm + "tq"), tgt, nq, nm)
+            t1 = E.linear(a, W[q + ".self_attn.out_proj.weight"], W[q + ".self_attn.out_proj.bias"], residual=tgt, name=nm + "o")
+            tgt = E.layernorm(t1, W[q + ".norm1.weight"], W[q + ".norm1.bias"], name=nm + "n1")
+            m = q + ".multihead_attn"
+            cq = E.linear(E.add(tgt, qe, name=nm + "tq2"), W[m + ".q_proj.weight"], W[m + ".q_proj.bias"], name=nm + "cq")
+            ck = E.linear(mem_pos, W[m + ".k_proj.weight"], W[m + ".k_proj.bias"], name=nm + "ck")
+            cvt = E.linear(memory, W[m + ".v_proj.weight"], W[m + ".v_proj.bias"], transposed_out=True, rows_per_batch=N,
+                           pad_cols=(N + 63) // 64 * 64, name=nm + "cvt")
+            a = E.attention(cq, ck, cvt, heads, Nk=N, name=nm + "ca")
+            t2 = E.linear(a, W[m + ".out_proj.weight"], W[m + ".out_proj.bias"], residual=tgt, name=nm + "co")
+            tgt = E.layernorm(t2, W[q + ".norm2.weight"], W[q + ".norm2.bias"], name=nm + "n2")
+            ffh = E.linear(tgt, W[q + ".linear1.weight"], W[q + ".linear1.bias"], act=ACT_RELU, name=nm + "f1")
+            t3 = E.linear(ffh, W[q + ".linear2.weight"], W[q + ".linear2.bias"], residual=tgt, name=nm + "f2")
+            tgt = E.layernorm(t3, W[q + ".norm3.weight"], W[q + ".norm3.bias"], name=nm + "n3")
+        hs = E.layernorm(tgt, W["transformer.decoder.norm.weight"], W["transformer.decoder.norm.bias"], name="dec_norm")
+        a_hat = E.linear(hs, W["action_head.weight"], W["action_head.bias"], name="a_hat")
+        is_pad = E.linear(hs, W["is_pad_head.weight"], W["is_pad_head.bias"], name="is_pad")
+        return a_hat, is_pad, task
 
 
 class GenimaACT:
@@ -217,7 +240,7 @@ class GenimaACT:
         self.device = torch.device(device)
         self.training = False
         self.W = self.Wclip = None
-        self._engine: Optional[Engine] = None
+        self._progs = {}
         if self.device.type == "cuda" and torch.cuda.is_available():
             self.to(self.device)
 
@@ -229,7 +252,7 @@ class GenimaACT:
         self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
         self.W = pack_act(self._sd, self.device)
         self.Wclip = packing.pack_state_dict(self._clip_sd, self.device)
-        self._engine = Engine(self.device, autotune=True)  # eager engine, but the GEMM tiles are still tuned per shape
+        self._progs = {}
         return self
 
     def train(self, mode: bool = True):
@@ -249,44 +272,64 @@ class GenimaACT:
                 self._sd[k] = new[k].detach().float().cpu()
         if self.W is not None:
             self.W = pack_act(self._sd, self.device)
+            self._progs = {}
         return missing, [k for k in new if k not in self._schema]
 
+    # ---- recorded forward programs (one per input shape), replayed from C++ --------------------------------------------------
+    def _program(self, B, V, H, Wd, lang: bool):
+        if self.W is None:
+            raise GenimaHipError("GenimaACT is not on a ROCm device (no CPU fallback)")
+        key = (B, V, H, Wd, lang)
+        io = self._progs.get(key)
+        if io is None:
+            from types import SimpleNamespace
+
+            from .engine import save_tune_table
+
+            E = Engine(self.device, record=True)
+            io = SimpleNamespace(engine=E)
+            io.img = E.buf("in_img", (B, V, H, Wd, 3), dtype=torch.uint8, zero=True)
+            sdim = (self.config["state_dim"] + 7) // 8 * 8
+            io.qpos = E.buf("in_qpos", (B, sdim), zero=True)
+            io.tokens = E.buf("in_tokens", (B, 77), dtype=torch.int32, zero=True) if lang else None
+            io.a_hat, io.is_pad, io.task = emit_act_forward(E, self.W, self.Wclip, self.config, self.clip_config, io.img, io.qpos, io.tokens)
+            save_tune_table()
+            self._progs[key] = io
+        return io
+
+    def _run(self, img_u8_nhwc, qpos, tokens):
+        B, V, H, Wd, _ = img_u8_nhwc.shape
+        lang = bool(self.config.get("use_lang_cond")) and tokens is not None
+        io = self._program(B, V, H, Wd, lang)
+        io.img.copy_(img_u8_nhwc)
+        io.qpos[:, : qpos.shape[1]].copy_(qpos.to(torch.float16))
+        if lang:
+            io.tokens.copy_(tokens.reshape(B, -1, tokens.shape[-1])[:, 0].to(torch.int32))  # text does not change across frames
+        io.engine.use_stream(torch.cuda.current_stream(self.device))
+        io.engine.run()
+        return io
+
     def encode_clip_text(self, tokens: torch.Tensor):
-        """tokens int [B, fs, 77] -> (task_emb f32 [B, projection_dim], emb) (controller/method/genima_act.py:314-346)."""
-        if self._engine is None:
+        """tokens int [B, fs, 77] -> (task_emb f32 [B, projection_dim], None) (controller/method/genima_act.py:314-346)."""
+        if self.W is None:
             raise GenimaHipError("GenimaACT is not on a ROCm device")
-        E = self._engine
-        shp = tokens.shape
-        tks = tokens.reshape(-1, shp[-1]).to(self.device, torch.int32).contiguous()
+        E = Engine(self.device)
+        tks = tokens.reshape(tokens.shape[0], -1, tokens.shape[-1])[:, 0].to(self.device, torch.int32).contiguous()
         x = graphs.emit_clip_text(E, self.Wclip, self.clip_config, tks)
-        eot = tks.argmax(dim=-1).to(torch.int32)
-        pooled = E.gather_rows(x, eot)
-        proj = E.linear(pooled, self.Wclip["text_projection.weight"])
-        out = proj.view(shp[0], shp[1], -1)[:, 0].to(torch.float32)  # text does not change across frames
-        return out, x
+        pooled = E.gather_rows(x, E.argmax_rows(tks))
+        return E.linear(pooled, self.Wclip["text_projection.weight"]).to(torch.float32), x
 
     def act_tiled(self, tiled_u8: torch.Tensor, low_dim_state: torch.Tensor, lang_tokens: Optional[torch.Tensor]) -> torch.Tensor:
         """Device-resident fast path of eval_genima.py:224-247: the pipeline's uint8 tiled output [B, 2v, 2v, 3] is untiled on
         the device (crop order of controller/utils/misc.py:25-30 -> camera order of the tile) and fed straight to the policy."""
         B, H2, W2, _ = tiled_u8.shape
         v = H2 // 2
-        crops = [tiled_u8[:, y:y + v, x:x + v] for (x, y) in ((0, 0), (v, 0), (0, v), (v, v))]
-        img = torch.stack(crops, dim=1).contiguous()  # [B, 4, v, v, 3]
-        qpos = low_dim_state.to(self.device).flatten(1)
-        sdim = (qpos.shape[1] + 7) // 8 * 8
-        qp = torch.zeros(B, sdim, dtype=torch.float16, device=self.device)
-        qp[:, : qpos.shape[1]] = qpos.to(torch.float16)
-        task = None
-        if self.config.get("use_lang_cond") and lang_tokens is not None:
-            task = self.encode_clip_text(lang_tokens)[0].to(torch.float16)
-        return emit_act_forward(self._engine, self.W, self.config, img, qp, task)[0]
+        img = torch.stack([tiled_u8[:, y:y + v, x:x + v] for (x, y) in ((0, 0), (v, 0), (0, v), (v, v))], dim=1)  # layout only
+        io = self._run(img, low_dim_state.to(self.device).flatten(1), None if lang_tokens is None else lang_tokens.to(self.device))
+        return io.a_hat[..., : self.config["action_dim"]]
 
     def act(self, obs: Dict[str, torch.Tensor], step: int = 0, eval_mode: bool = True) -> torch.Tensor:
         """obs: {'<cam>_rgb': uint8/float [B, fs, 3, H, W], 'low_dim_state': f32 [B, fs, state], 'lang_tokens': int [B, fs, 77]}."""
-        if self._engine is None:
-            raise GenimaHipError("GenimaACT is not on a ROCm device")
-        E = self._engine
-        cfg = self.config
         qpos = obs["low_dim_state"].to(self.device).flatten(1)
         rgb_keys = [k for k in obs if re.match(r"rgb.*|.*_rgb$", k)]  # obs-dict key order == RoboBase camera enumeration
         image = torch.stack([obs[k].to(self.device) for k in rgb_keys], dim=1)  # [B, V, fs, 3, H, W]
@@ -294,12 +337,6 @@ class GenimaACT:
         image = image.reshape(B, -1, 3, image.shape[-2], image.shape[-1])
         img_u8 = image.round().clamp(0, 255).to(torch.uint8) if image.dtype != torch.uint8 else image
         img_u8 = img_u8.permute(0, 1, 3, 4, 2).contiguous()
-        task = None
-        if cfg.get("use_lang_cond") and "lang_tokens" in obs:
-            task, _ = self.encode_clip_text(obs["lang_tokens"])
-            task = task.to(torch.float16)
-        sdim = (qpos.shape[1] + 7) // 8 * 8
-        qp = torch.zeros(B, sdim, dtype=torch.float16, device=self.device)
-        qp[:, : qpos.shape[1]] = qpos.to(torch.float16)
-        a_hat, _ = emit_act_forward(E, self.W, cfg, img_u8, qp, task)
-        return a_hat.to(torch.float32)
+        toks = obs.get("lang_tokens") if self.config.get("use_lang_cond") else None
+        io = self._run(img_u8, qpos, None if toks is None else toks.to(self.device))
+        return io.a_hat[..., : self.config["action_dim"]].to(torch.float32)

@@ -19,7 +19,7 @@ namespace {
 
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
-  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL
+  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX
 };
 
 struct GenericArgs {  // argument block of the small ops
@@ -27,6 +27,8 @@ struct GenericArgs {  // argument block of the small ops
   int64_t n0, n1;
   int32_t i0, i1, i2, i3;
   float f0, f1;
+  int64_t m[12];  // copy4d: sizes[4], in_strides[4], out_strides[4]
+  float g[6];     // normalize: mul[3], add[3]
 };
 
 struct Op {
@@ -65,6 +67,10 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_EMBED: return gn_embedding(ctx, (const int32_t*)g.p0, g.p1, g.p2, g.p3, g.i0, g.i1, g.i2);
     case OP_SOFTMAX: return gn_softmax_rows(ctx, g.p3, g.n0, g.i0, g.i1, g.f0);
     case OP_MAXPOOL: return gn_maxpool3x3s2(ctx, g.p0, g.p3, g.i0, g.i1, g.i2, g.i3);
+    case OP_NORMALIZE_U8: return gn_image_normalize_u8(ctx, (const uint8_t*)g.p0, g.p3, g.n0, g.i0, g.g[0], g.g[1], g.g[2], g.g[3], g.g[4], g.g[5]);
+    case OP_GATHER_ROWS: return gn_gather_rows(ctx, g.p0, (const int32_t*)g.p1, g.p3, g.i0, g.i1, g.i2);
+    case OP_COPY4D: return gn_copy4d(ctx, g.p0, g.p3, g.m, g.m + 4, g.m + 8, g.i0);
+    case OP_ARGMAX: return gn_argmax_rows_i32(ctx, (const int32_t*)g.p0, (int32_t*)g.p3, g.i0, g.i1);
     default: gn_set_error("gn_program: unknown op type %d", op.type); return GN_ERR_INVALID;
   }
 }
@@ -75,7 +81,10 @@ static int32_t push_generic(gn_program* p, int type, const void* p0, const void*
   Op op;
   memset(&op, 0, sizeof(op));
   op.type = type;
-  op.g = GenericArgs{p0, p1, p2, p3, n0, n1, i0, i1, i2, i3, f0, f1};
+  op.g.p0 = p0; op.g.p1 = p1; op.g.p2 = p2; op.g.p3 = p3;
+  op.g.n0 = n0; op.g.n1 = n1;
+  op.g.i0 = i0; op.g.i1 = i1; op.g.i2 = i2; op.g.i3 = i3;
+  op.g.f0 = f0; op.g.f1 = f1;
   p->ops.push_back(op);
   return GN_OK;
 }
@@ -195,6 +204,31 @@ int32_t gn_program_add_softmax_rows(gn_program* p, void* x, int64_t rows, int32_
 }
 int32_t gn_program_add_maxpool3x3s2(gn_program* p, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C) {
   return push_generic(p, OP_MAXPOOL, x, nullptr, nullptr, y, 0, 0, B, H, W, C, 0.f, 0.f);
+}
+int32_t gn_program_add_image_normalize_u8(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float m0,
+                                          float m1, float m2, float a0, float a1, float a2) {
+  int32_t rc = push_generic(p, OP_NORMALIZE_U8, in, nullptr, nullptr, out, pixels, 0, Cpad, 0, 0, 0, 0.f, 0.f);
+  if (rc == GN_OK) {
+    float* g = p->ops.back().g.g;
+    g[0] = m0; g[1] = m1; g[2] = m2; g[3] = a0; g[4] = a1; g[5] = a2;
+  }
+  return rc;
+}
+int32_t gn_program_add_gather_rows(gn_program* p, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D) {
+  return push_generic(p, OP_GATHER_ROWS, x, idx, nullptr, out, 0, 0, B, L, D, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_copy4d(gn_program* p, const void* in, void* out, const int64_t* sizes, const int64_t* in_strides,
+                              const int64_t* out_strides, int32_t L) {
+  GN_REQUIRE(sizes && in_strides && out_strides, "gn_program_add_copy4d: null argument");
+  int32_t rc = push_generic(p, OP_COPY4D, in, nullptr, nullptr, out, 0, 0, L, 0, 0, 0, 0.f, 0.f);
+  if (rc == GN_OK) {
+    int64_t* m = p->ops.back().g.m;
+    for (int i = 0; i < 4; ++i) { m[i] = sizes[i]; m[4 + i] = in_strides[i]; m[8 + i] = out_strides[i]; }
+  }
+  return rc;
+}
+int32_t gn_program_add_argmax_rows_i32(gn_program* p, const int32_t* x, int32_t* out, int32_t rows, int32_t cols) {
+  return push_generic(p, OP_ARGMAX, x, nullptr, nullptr, out, 0, 0, rows, cols, 0, 0, 0.f, 0.f);
 }
 int64_t gn_program_num_ops(const gn_program* p) { return p ? (int64_t)p->ops.size() : 0; }
 

@@ -80,6 +80,37 @@ __global__ void gather_rows_kernel(const f16* __restrict__ x, const int32_t* __r
   *reinterpret_cast<uint4*>(out + (long)b * D + c0) = *reinterpret_cast<const uint4*>(x + ((long)b * L + idx[b]) * D + c0);
 }
 
+// generic 4-D strided copy of contiguous L-element (L % 8 == 0) runs: the layout shuffles between kernels that the host would
+// otherwise do with torch permute/cat (e.g. ACT: per-view feature maps -> views-along-width token rows inside the encoder
+// sequence buffer)
+struct Copy4 { long n[4], is[4], os[4]; };
+__global__ void copy4d_kernel(const f16* __restrict__ in, f16* __restrict__ out, Copy4 c, int L8) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = c.n[0] * c.n[1] * c.n[2] * c.n[3] * L8;
+  if (idx >= total) return;
+  const int ch = (int)(idx % L8);
+  long r = idx / L8;
+  const long i3 = r % c.n[3]; r /= c.n[3];
+  const long i2 = r % c.n[2]; r /= c.n[2];
+  const long i1 = r % c.n[1];
+  const long i0 = r / c.n[1];
+  const long io = i0 * c.is[0] + i1 * c.is[1] + i2 * c.is[2] + i3 * c.is[3] + ch * 8;
+  const long oo = i0 * c.os[0] + i1 * c.os[1] + i2 * c.os[2] + i3 * c.os[3] + ch * 8;
+  *reinterpret_cast<uint4*>(out + oo) = *reinterpret_cast<const uint4*>(in + io);
+}
+
+// first index of the row maximum of an int32 matrix (CLIP EOT token = highest id, genima_act.py:339-342)
+__global__ void argmax_rows_i32_kernel(const int32_t* __restrict__ x, int32_t* __restrict__ out, int rows, int cols) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  int best = 0, bv = x[(long)r * cols];
+  for (int j = 1; j < cols; ++j) {
+    const int v = x[(long)r * cols + j];
+    if (v > bv) { bv = v; best = j; }
+  }
+  out[r] = best;
+}
+
 __global__ void image_f16_to_u8_kernel(const f16* __restrict__ in, uint8_t* __restrict__ out, long pixels, int ld) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= pixels) return;
@@ -255,6 +286,28 @@ int32_t gn_image_normalize_u8(gn_ctx* ctx, const uint8_t* in, void* out, int64_t
 int32_t gn_gather_rows(gn_ctx* ctx, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D) {
   GN_REQUIRE(ctx && x && idx && out && B > 0 && L > 0 && D > 0 && D % 8 == 0, "gn_gather_rows: bad arguments");
   hipLaunchKernelGGL(gather_rows_kernel, dim3(nblk((long)B * (D / 8))), dim3(256), 0, ctx->stream, (const f16*)x, idx, (f16*)out, B, L, D);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_copy4d(gn_ctx* ctx, const void* in, void* out, const int64_t* sizes, const int64_t* in_strides,
+                  const int64_t* out_strides, int32_t L) {
+  GN_REQUIRE(ctx && in && out && sizes && in_strides && out_strides && L > 0 && L % 8 == 0, "gn_copy4d: bad arguments");
+  Copy4 c;
+  long total = L / 8;
+  for (int i = 0; i < 4; ++i) {
+    GN_REQUIRE(sizes[i] > 0 && in_strides[i] % 8 == 0 && out_strides[i] % 8 == 0, "gn_copy4d: sizes > 0 and strides multiples of 8");
+    c.n[i] = sizes[i]; c.is[i] = in_strides[i]; c.os[i] = out_strides[i];
+    total *= sizes[i];
+  }
+  hipLaunchKernelGGL(copy4d_kernel, dim3(nblk(total)), dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, c, L / 8);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_argmax_rows_i32(gn_ctx* ctx, const int32_t* x, int32_t* out, int32_t rows, int32_t cols) {
+  GN_REQUIRE(ctx && x && out && rows > 0 && cols > 0, "gn_argmax_rows_i32: bad arguments");
+  hipLaunchKernelGGL(argmax_rows_i32_kernel, dim3(nblk(rows, 64)), dim3(64), 0, ctx->stream, x, out, rows, cols);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -435,19 +435,33 @@ class Engine:
         return x
 
     def image_normalize_u8(self, img: torch.Tensor, mean, std, cpad: int = 8, *, name=None):
-        """uint8 [..., 3] -> f16 [..., cpad] = (v/255 - mean_c) / std_c  (eager only)."""
+        """uint8 [..., 3] -> f16 [..., cpad] = (v/255 - mean_c) / std_c."""
         out = self.buf(name, tuple(img.shape[:-1]) + (cpad,))
         m = [1.0 / (255.0 * s_) for s_ in std]
         a = [-mu / s_ for mu, s_ in zip(mean, std)]
-        check(self.lib.gn_image_normalize_u8(self._ctx, _ptr(img), _ptr(out), img.numel() // 3, cpad, *m, *a), "gn_image_normalize_u8")
+        self._small("image_normalize_u8", (img, out), _ptr(img), _ptr(out), img.numel() // 3, cpad, *m, *a)
         return out
 
     def gather_rows(self, x: torch.Tensor, idx: torch.Tensor, *, name=None):
-        """x [B, L, D], idx int32 [B] -> [B, D] (eager only)."""
+        """x [B, L, D], idx int32 [B] -> [B, D]."""
         B, L, D = x.shape
         out = self.buf(name, (B, D))
-        check(self.lib.gn_gather_rows(self._ctx, _ptr(x), _ptr(idx), _ptr(out), B, L, D), "gn_gather_rows")
+        self._small("gather_rows", (x, idx, out), _ptr(x), _ptr(idx), _ptr(out), B, L, D)
         return out
+
+    def argmax_rows(self, x: torch.Tensor, *, name=None):
+        """int32 [rows, cols] -> int32 [rows]: first index of each row's maximum."""
+        rows, cols = x.shape
+        out = self.buf(name, (rows,), dtype=torch.int32)
+        self._small("argmax_rows_i32", (x, out), _ptr(x), _ptr(out), rows, cols)
+        return out
+
+    def copy4d(self, src: torch.Tensor, dst: torch.Tensor, sizes, in_strides, out_strides, L: int):
+        """dst[i0*os0 + i1*os1 + i2*os2 + i3*os3 + :L] = src[i0*is0 + ... + :L] over the 4-D index space ``sizes`` (f16 elements)."""
+        arr = (C.c_int64 * 4)
+        s, i, o = arr(*sizes), arr(*in_strides), arr(*out_strides)
+        self._small("copy4d", (src, dst), _ptr(src), _ptr(dst), s, i, o, L)
+        return dst
 
     def maxpool3x3s2(self, x: torch.Tensor, *, name=None):
         B, H, W, Cc = x.shape

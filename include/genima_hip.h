@@ -143,6 +143,12 @@ int32_t gn_image_normalize_u8(gn_ctx* ctx, const uint8_t* in, void* out, int64_t
                               float m2, float a0, float a1, float a2);
 /* out[b, :] = x[b, idx[b], :]  (CLIP EOT-token pooling, controller/method/genima_act.py:337-343) */
 int32_t gn_gather_rows(gn_ctx* ctx, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D);
+/* out[i] = index of the first maximum of row i of an int32 [rows, cols] matrix (EOT = highest token id) */
+int32_t gn_argmax_rows_i32(gn_ctx* ctx, const int32_t* x, int32_t* out, int32_t rows, int32_t cols);
+/* strided 4-D copy of contiguous f16 runs of L elements (L % 8 == 0; strides in elements, multiples of 8): the layout shuffles
+ * between kernels (ACT: per-view feature maps -> views-along-width token rows of the encoder sequence) */
+int32_t gn_copy4d(gn_ctx* ctx, const void* in, void* out, const int64_t* sizes, const int64_t* in_strides,
+                  const int64_t* out_strides, int32_t L);
 
 /* ---- misc elementwise / gather ------------------------------------------------------------------------------------ */
 int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n);              /* f16, n % 8 == 0 */
@@ -177,6 +183,12 @@ int32_t gn_program_add_embedding(gn_program* p, const int32_t* ids, const void* 
                                  int32_t B, int32_t L, int32_t D);
 int32_t gn_program_add_softmax_rows(gn_program* p, void* x, int64_t rows, int32_t cols, int32_t ld, float scale);
 int32_t gn_program_add_maxpool3x3s2(gn_program* p, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C);
+int32_t gn_program_add_image_normalize_u8(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float m0,
+                                          float m1, float m2, float a0, float a1, float a2);
+int32_t gn_program_add_gather_rows(gn_program* p, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D);
+int32_t gn_program_add_copy4d(gn_program* p, const void* in, void* out, const int64_t* sizes, const int64_t* in_strides,
+                              const int64_t* out_strides, int32_t L);
+int32_t gn_program_add_argmax_rows_i32(gn_program* p, const int32_t* x, int32_t* out, int32_t rows, int32_t cols);
 int64_t gn_program_num_ops(const gn_program* p);
 /* first..last (exclusive) op range; last < 0 = to the end */
 int32_t gn_program_run(gn_program* p, int64_t first, int64_t last);
