@@ -10,6 +10,8 @@
 //   3. gn_apply_kernel:    y = act(x * scale + shift), one 16-byte chunk per thread; reads two virtually concatenated
 //                          sources (UNet up-block skip concat) and writes the concatenated activated tensor.
 // Algorithmic traffic is read + write once; the stats pass re-reads x (an L2 / Infinity-Cache hit for UNet-sized tensors).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -183,6 +185,66 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
   }
 }
 
+// ---- single-launch GroupNorm for small / mid tensors -------------------------------------------------------------------
+// One 512-thread workgroup per (batch, group): the group's HW x cpg slab (<= 144 KB) is read ONCE into LDS while the f32
+// statistics accumulate, then normalised (+SiLU) out of LDS.  Replaces the 3-launch path wherever a slab fits: the UNet /
+// ControlNet levels, where the three dependent launches (~6 us each of launch + ramp + tail) cost more than the data movement.
+// Deterministic: fixed thread -> element mapping and a fixed-order block reduction.
+constexpr int GNF_THREADS = 512;
+constexpr int GNF_MAX_LDS = 144 * 1024;
+
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GNParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned int slab[];  // [HW][cpg/2] packed f16 pairs
+  __shared__ float red[2 * (GNF_THREADS / 64)];
+  const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+  const int hpg = p.cpg >> 1;           // f16 pairs per pixel of this group
+  const int j = tid % hpg, p0 = tid / hpg;
+  const int pstep = GNF_THREADS / hpg;  // pixel lanes; threads >= hpg * pstep idle
+  const int c = g * p.cpg + 2 * j;      // this thread's channel pair (fixed)
+  const f16* src;
+  int cs, co;
+  if (c < p.C1) { src = p.x; cs = p.C1; co = c; } else { src = p.x2; cs = p.C2; co = c - p.C1; }
+  src += (long)b * p.HW * cs + co;
+  float s = 0.f, ss = 0.f;
+  if (p0 < pstep) {
+    for (int r = p0; r < p.HW; r += pstep) {
+      const unsigned int raw = *reinterpret_cast<const unsigned int*>(src + (long)r * cs);
+      slab[r * hpg + j] = raw;
+      const f16x2 v = *reinterpret_cast<const f16x2*>(&raw);
+      const float a = (float)v[0], bb = (float)v[1];
+      s += a + bb;
+      ss += a * a + bb * bb;
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { red[wave] = s; red[GNF_THREADS / 64 + wave] = ss; }
+  __syncthreads();
+  float ts = 0.f, tss = 0.f;
+#pragma unroll
+  for (int w = 0; w < GNF_THREADS / 64; ++w) { ts += red[w]; tss += red[GNF_THREADS / 64 + w]; }
+  const float n = (float)p.HW * (float)p.cpg;
+  const float mean = ts / n;
+  const float var = fmaxf(tss / n - mean * mean, 0.0f);
+  const float rstd = rsqrtf(var + p.eps);
+  if (p0 < pstep) {
+    const float a0 = rstd * (float)p.gamma[c], a1 = rstd * (float)p.gamma[c + 1];
+    const float s0 = (float)p.beta[c] - mean * a0, s1 = (float)p.beta[c + 1] - mean * a1;
+    f16* dst = p.y + (long)b * p.HW * p.C + c;
+    for (int r = p0; r < p.HW; r += pstep) {
+      const unsigned int raw = slab[r * hpg + j];
+      const f16x2 v = *reinterpret_cast<const f16x2*>(&raw);
+      float y0 = (float)v[0] * a0 + s0, y1 = (float)v[1] * a1 + s1;
+      if (p.act == GN_ACT_SILU) { y0 = act_silu(y0); y1 = act_silu(y1); }
+      f16x2 o;
+      o[0] = (f16)y0;
+      o[1] = (f16)y1;
+      *reinterpret_cast<f16x2*>(dst + (long)r * p.C) = o;
+    }
+  }
+}
+
 int gn_pick_chunks(int B, int HW) {
   long c = cdiv64(1024, B);
   const long maxc = cdiv64(HW, 16);
@@ -270,6 +332,22 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.act = d->act; p.eps = d->eps;
   p.partials = (float*)d->workspace;
   p.scsh = p.partials + (long)d->B * gn_pick_chunks(d->B, d->HW) * d->groups * 2;
+  {  // single-launch path when a (batch, group) slab fits in LDS
+    static int fused_ok = -1;
+    if (fused_ok < 0) {
+      const char* e = getenv("GN_GROUPNORM_FUSED");
+      fused_ok = (e && e[0] == '0') ? 0 : 1;
+      if (fused_ok)
+        GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GNF_MAX_LDS));
+    }
+    const long slab = (long)d->HW * p.cpg * 2;
+    if (fused_ok && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= GNF_MAX_LDS &&
+        (long)d->B * d->groups >= 64) {
+      hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups, d->B), dim3(GNF_THREADS), (size_t)slab, ctx->stream, p);
+      GN_LAUNCH_CHECK();
+      return GN_OK;
+    }
+  }
   const int cc = C >> 3, tx = cc < 256 ? cc : 256, pyn = 256 / tx;
   {  // apply slabs: ~4096 blocks over the chip, at least 4 rows per pixel lane
     long ac = cdiv64(4096, d->B);
