@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
 // ControlNet levels, where the three dependent launches (~6 us each of launch + ramp + tail) cost more than the data movement.
 // Deterministic: fixed thread -> element mapping and a fixed-order block reduction.
 constexpr int GNF_THREADS = 512;
-constexpr int GNF_MAX_LDS = 144 * 1024;
+constexpr int GNF_MAX_LDS = 48 * 1024;  // measured: an 82 KB slab per CU (320 ch @ 64x64) is latency-bound and loses to the 3-launch path
 
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GNParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned int slab[];  // [HW][cpg/2] packed f16 pairs
