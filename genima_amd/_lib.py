@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(HERE, "libgenima_hip.so")
 
 # enums of genima_hip.h
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_GEGLU = 0, 1, 2, 3, 4, 5
-OUT_ROWMAJOR, OUT_BATCH_TRANSPOSED = 0, 1
+OUT_ROWMAJOR, OUT_BATCH_TRANSPOSED, OUT_F32 = 0, 1, 2
 
 
 class GenimaHipError(RuntimeError):
@@ -31,6 +31,10 @@ class GemmDesc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("upsample2x", C.c_int32), ("act", C.c_int32), ("out_mode", C.c_int32),
         ("rows_per_batch", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32), ("residual_before_act", C.c_int32),
         ("out_scale", C.c_float),
+        ("batch", C.c_int32), ("batch_inner", C.c_int32),
+        ("a_bs", C.c_int64), ("a_bs2", C.c_int64), ("w_bs", C.c_int64), ("w_bs2", C.c_int64),
+        ("out_bs", C.c_int64), ("out_bs2", C.c_int64), ("res_bs", C.c_int64), ("res_bs2", C.c_int64),
+        ("accumulate", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -50,6 +54,7 @@ class GroupNormDesc(C.Structure):
         ("workspace", C.c_void_p),
         ("B", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("act", C.c_int32), ("eps", C.c_float),
+        ("save_stats", C.c_void_p), ("save_scsh", C.c_void_p),
     ]
 
 
@@ -88,6 +93,27 @@ SIGNATURES = {
     "gn_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_softmax_rows": (_I32, [_P, _P, _I64, _I32, _I32, _F]),
     "gn_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
+    "gn_transpose2d": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
+    "gn_im2col_t": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "gn_colsum_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "gn_colsum_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I64, _P, _I32]),
+    "gn_reduce_rows_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
+    "gn_act_bwd": (_I32, [_P, _P, _P, _P, _I64, _I32]),
+    "gn_geglu_fwd": (_I32, [_P, _P, _P, _I64, _I32]),
+    "gn_geglu_bwd": (_I32, [_P, _P, _P, _P, _I64, _I32]),
+    "gn_softmax_bwd": (_I32, [_P, _P, _P, _I64, _I32, _I64, _F]),
+    "gn_layernorm_bwd_workspace_bytes": (_I64, [_I64, _I32]),
+    "gn_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F]),
+    "gn_groupnorm_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32]),
+    "gn_groupnorm_bwd": (_I32, [_P, C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gn_zero_upsample2x": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
+    "gn_sumpool2x2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
+    "gn_mse_loss": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F]),
+    "gn_sumsq_f32": (_I32, [_P, _P, _I64, _P, _P]),
+    "gn_clip_coef": (_I32, [_P, _P, _P, _F]),
+    "gn_adamw_flat": (_I32, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _P, _F]),
+    "gn_cast_f32_f16": (_I32, [_P, _P, _P, _I64]),
+    "gn_fill_f32": (_I32, [_P, _P, _I64, _F]),
     "gn_program_create": (_I32, [_P, C.POINTER(_P)]),
     "gn_program_destroy": (_I32, [_P]),
     "gn_program_add_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),

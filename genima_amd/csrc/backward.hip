@@ -1,0 +1,656 @@
+// Training-side kernels of the ControlNet fine-tune step (reference
+// diffusion/train_controlnet_genima.py:1317-1408).  The matrix products of the backward pass reuse the forward MFMA GEMM
+// (gemm.hip: dX = dY . W via a transposed weight copy, dW = dY^T . X via transposed activations with f32 output and split-K
+// over the pixel dimension, conv dgrad = conv with rotated weights, conv wgrad = GEMM over an im2col^T image); this file holds
+// the HBM-bound glue: tiled transposes (plain and im2col-gathering), column sums (bias / shift gradients), activation /
+// GEGLU / softmax / LayerNorm / GroupNorm backward, zero-insertion and 2x2 sum pooling (strided / upsampled conv dgrad),
+// MSE loss, and the flat-buffer optimizer kernels (fused AdamW, sum of squares, scale, f32 -> f16 cast).
+// f16 storage, f32 math, f32 parameter gradients, deterministic reductions (no float atomics).
+#include "common.h"
+
+namespace {
+
+inline unsigned nblk(long n, int t = 256) { return (unsigned)((n + t - 1) / t); }
+
+// ---- tiled transpose: out[b][c][r] = in[b][r][c] -----------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose2d_kernel(const f16* __restrict__ in, f16* __restrict__ out, int rows, int cols,
+                                                          long ld_in, long ld_out, long in_bs, long out_bs) {
+  __shared__ f16 tile[64][66];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  in += (long)b * in_bs;
+  out += (long)b * out_bs;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? in[(long)r * ld_in + c] : (f16)0.0f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) out[(long)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// ---- im2col^T: out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c]  (0 in the padding) ---------------------
+struct Im2colP { const f16* x; f16* out; int B, H, W, C, KH, KW, stride, pad, Ho, Wo; long M; };
+__global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colP p) {
+  __shared__ f16 tile[64][66];
+  const int tap = blockIdx.z, dy = tap / p.KW, dx = tap - dy * p.KW;
+  const long m0 = (long)blockIdx.y * 64;
+  const int c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int hw = p.Ho * p.Wo;
+  for (int i = ty; i < 64; i += 4) {
+    const long m = m0 + i;
+    f16 v = (f16)0.0f;
+    const int c = c0 + tx;
+    if (m < p.M && c < p.C) {
+      const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
+      const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+      const int iy = oy * p.stride - p.pad + dy, ix = ox * p.stride - p.pad + dx;
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = p.x[(((long)b * p.H + iy) * p.W + ix) * p.C + c];
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i;
+    const long m = m0 + tx;
+    if (c < p.C && m < p.M) p.out[((long)tap * p.C + c) * p.M + m] = tile[tx][i];
+  }
+}
+
+// ---- column sums: out[nb][cols] (+)= sum over each batch's rows; two deterministic stages ----------------------------------------
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const f16* __restrict__ x, float* __restrict__ part, int rpb, int cols,
+                                                             long ld, int chunks) {
+  // grid: (ceil(cols/64), chunks, nb); 4 waves walk 4 rows at a time, lanes own columns
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  const int chunk = blockIdx.y, b = blockIdx.z;
+  const int rows_per = (rpb + chunks - 1) / chunks;
+  const int r0 = chunk * rows_per, r1 = min(rpb, r0 + rows_per);
+  float s = 0.f;
+  if (c < cols)
+    for (int r = r0 + w; r < r1; r += 4) s += (float)x[((long)b * rpb + r) * ld + c];
+  red[w][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (w == 0 && c < cols)
+    part[((long)b * chunks + chunk) * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+__global__ void reduce_rows_f32_kernel(const float* __restrict__ part, float* __restrict__ out, int groups, int R, int cols, int accumulate) {
+  // out[g][c] (+)= sum_{r < R} part[(g*R + r)][c]
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)groups * cols) return;
+  const int g = (int)(idx / cols), c = (int)(idx - (long)g * cols);
+  float s = 0.f;
+  for (int r = 0; r < R; ++r) s += part[((long)g * R + r) * cols + c];
+  out[idx] = accumulate ? out[idx] + s : s;
+}
+
+// ---- activation backward: dz = dy * act'(z) ---------------------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case GN_ACT_SILU: { const float s = 1.0f / (1.0f + __expf(-z)); return s * (1.0f + z * (1.0f - s)); }
+    case GN_ACT_GELU: return 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+    case GN_ACT_QUICK_GELU: { const float s = 1.0f / (1.0f + __expf(-1.702f * z)); return s * (1.0f + 1.702f * z * (1.0f - s)); }
+    case GN_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
+    default: return 1.0f;
+  }
+}
+__global__ void act_bwd_kernel(const uint4* __restrict__ dy, const uint4* __restrict__ z, uint4* __restrict__ dz, long n8, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const uint4 a = dy[i], b = z[i];
+  const f16x8 va = *reinterpret_cast<const f16x8*>(&a), vb = *reinterpret_cast<const f16x8*>(&b);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)((float)va[e] * act_grad((float)vb[e], act));
+  dz[i] = *reinterpret_cast<uint4*>(&o);
+}
+
+// ---- GEGLU (unfused form used in training): out = hidden * gelu(gate), hg = [hidden | gate] ---------------------------------------
+__global__ void geglu_fwd_kernel(const f16* __restrict__ hg, f16* __restrict__ out, long M, int Hd) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * Hd) return;
+  const long m = idx / Hd;
+  const int j = (int)(idx - m * Hd);
+  const float h = (float)hg[m * 2 * Hd + j], g = (float)hg[m * 2 * Hd + Hd + j];
+  out[idx] = (f16)(h * act_gelu(g));
+}
+__global__ void geglu_bwd_kernel(const f16* __restrict__ dy, const f16* __restrict__ hg, f16* __restrict__ dhg, long M, int Hd) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * Hd) return;
+  const long m = idx / Hd;
+  const int j = (int)(idx - m * Hd);
+  const float h = (float)hg[m * 2 * Hd + j], g = (float)hg[m * 2 * Hd + Hd + j], d = (float)dy[idx];
+  dhg[m * 2 * Hd + j] = (f16)(d * act_gelu(g));
+  dhg[m * 2 * Hd + Hd + j] = (f16)(d * h * act_grad(g, GN_ACT_GELU));
+}
+
+// ---- softmax backward (attention): ds = scale * p * (dp - sum_j p*dp), in place over dp ----------------------------------------
+constexpr int SB_MAXCH = 8;
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const f16* __restrict__ p, f16* __restrict__ dp, long rows, int cols, long ld, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const f16* pr = p + row * ld;
+  f16* dr = dp + row * ld;
+  const int CC = cols >> 3;
+  float pv[SB_MAXCH][8], dv[SB_MAXCH][8];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < SB_MAXCH; ++i) {
+    const int cx = lane + 64 * i;
+    if (cx < CC) {
+      const uint4 a = *reinterpret_cast<const uint4*>(pr + cx * 8), b = *reinterpret_cast<const uint4*>(dr + cx * 8);
+      const f16x8 ha = *reinterpret_cast<const f16x8*>(&a), hb = *reinterpret_cast<const f16x8*>(&b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { pv[i][e] = (float)ha[e]; dv[i][e] = (float)hb[e]; dot += pv[i][e] * dv[i][e]; }
+    }
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int i = 0; i < SB_MAXCH; ++i) {
+    const int cx = lane + 64 * i;
+    if (cx < CC) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)(scale * pv[i][e] * (dv[i][e] - dot));
+      *reinterpret_cast<uint4*>(dr + cx * 8) = *reinterpret_cast<uint4*>(&o);
+    }
+  }
+}
+
+// ---- LayerNorm backward: wave per row; per-block f32 partials of dgamma / dbeta ----------------------------------------------
+constexpr int LNB_MAXCH = 4;  // C <= 2048
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ dy,
+                                                            f16* __restrict__ dx, float* __restrict__ part, long M, int C, float eps,
+                                                            int rows_per_block) {
+  // block = 4 waves; each wave walks rows_per_block/4 rows; lanes own fixed column chunks so dgamma/dbeta accumulate in registers
+  __shared__ float red[4][2];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int CC = C >> 3;
+  float dg[LNB_MAXCH][8], db[LNB_MAXCH][8];
+#pragma unroll
+  for (int i = 0; i < LNB_MAXCH; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
+  const long r0 = (long)blockIdx.x * rows_per_block;
+  for (long row = r0 + w; row < min(M, r0 + rows_per_block); row += 4) {
+    float xv[LNB_MAXCH][8], gv[LNB_MAXCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXCH; ++i) {
+      const int cx = lane + 64 * i;
+      if (cx < CC) {
+        const uint4 a = *reinterpret_cast<const uint4*>(x + row * C + cx * 8);
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[i][e] = (float)h[e]; s += xv[i][e]; }
+      }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXCH; ++i) {
+      const int cx = lane + 64 * i;
+      if (cx < CC)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXCH; ++i) {
+      const int cx = lane + 64 * i;
+      if (cx < CC) {
+        const uint4 a = *reinterpret_cast<const uint4*>(dy + row * C + cx * 8), g4 = *reinterpret_cast<const uint4*>(gamma + cx * 8);
+        const f16x8 hd = *reinterpret_cast<const f16x8*>(&a), hg = *reinterpret_cast<const f16x8*>(&g4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (xv[i][e] - mean) * rstd, d = (float)hd[e];
+          xv[i][e] = xh;
+          dg[i][e] += d * xh;
+          db[i][e] += d;
+          gv[i][e] = d * (float)hg[e];
+          m1 += gv[i][e];
+          m2 += gv[i][e] * xh;
+        }
+      }
+    }
+    m1 = wave_sum(m1) / (float)C;
+    m2 = wave_sum(m2) / (float)C;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXCH; ++i) {
+      const int cx = lane + 64 * i;
+      if (cx < CC) {
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (f16)(rstd * (gv[i][e] - m1 - xv[i][e] * m2));
+        *reinterpret_cast<uint4*>(dx + row * C + cx * 8) = *reinterpret_cast<uint4*>(&o);
+      }
+    }
+  }
+  (void)red;
+  if (part) {  // per-wave partial rows: part[(block*4 + wave)][2][C]
+    float* o = part + ((long)blockIdx.x * 4 + w) * 2 * C;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXCH; ++i) {
+      const int cx = lane + 64 * i;
+      if (cx < CC)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[cx * 8 + e] = dg[i][e]; o[C + cx * 8 + e] = db[i][e]; }
+    }
+  }
+}
+
+// ---- GroupNorm(+SiLU) backward, NHWC: per-channel sums -> per-(b, c) affine coefficients -> apply ------------------------------
+struct GNBParams {
+  const f16* x; const f16* x2; const f16* dy; const f16* gamma; const f16* beta;
+  f16* dx; f16* dx2;
+  float* part;    // [B][chunks][2][C] per-channel partial sums of dyh and dyh*x
+  float* coef;    // [B][C][3]: dx = a1*dyh + a2*x + a3
+  float* dgamma; float* dbeta;  // f32 [C] accumulated (nullable)
+  int B, HW, C1, C2, C, G, cpg, chunks, rows, act;
+  float eps;
+};
+__device__ __forceinline__ float gnb_dyh(float dy, float x, float a, float s, int act) {
+  // y = act(x*a + s): gradient w.r.t. the normalised-affine value
+  return act == GN_ACT_SILU ? dy * act_grad(x * a + s, GN_ACT_SILU) : dy;
+}
+__global__ __launch_bounds__(256) void gnb_partial_kernel(const GNBParams p, const float* __restrict__ scsh) {
+  // thread owns one channel (fixed) and walks the slab's rows: sums of dyh and dyh*x per channel
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int r0 = chunk * p.rows, r1 = min(p.HW, r0 + p.rows);
+  for (int c = threadIdx.x; c < p.C; c += 256) {
+    const f16* src; int cs, co;
+    if (c < p.C1) { src = p.x; cs = p.C1; co = c; } else { src = p.x2; cs = p.C2; co = c - p.C1; }
+    const float a = scsh[((long)b * p.C + c) * 2], s = scsh[((long)b * p.C + c) * 2 + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = r0; r < r1; ++r) {
+      const long pix = (long)b * p.HW + r;
+      const float xv = (float)src[pix * cs + co];
+      const float d = gnb_dyh((float)p.dy[pix * p.C + c], xv, a, s, p.act);
+      s1 += d;
+      s2 += d * xv;
+    }
+    float* o = p.part + (((long)b * p.chunks + chunk) * 2) * p.C;
+    o[c] = s1;
+    o[p.C + c] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void gnb_finalize_kernel(const GNBParams p, const float* __restrict__ stats) {
+  // stats[b][g] = (mean, rstd) from the forward.  Per channel: S1 = sum dyh, S2 = sum dyh*x.
+  // per group: c2 = mean(dyh*gamma), c1 = mean(dyh*gamma*xhat);  dx = r*gamma*dyh - r*c2 - r*xhat*c1
+  //          = (r*gamma) dyh + (-r^2 c1) x + (r^2 c1 mu - r c2)
+  __shared__ float S1[4096], S2[4096];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < p.C; c += 256) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = 0; ch < p.chunks; ++ch) {
+      const float* o = p.part + (((long)b * p.chunks + ch) * 2) * p.C;
+      s1 += o[c];
+      s2 += o[p.C + c];
+    }
+    S1[c] = s1;
+    S2[c] = s2;
+  }
+  __syncthreads();
+  for (int c = tid; c < p.C; c += 256) {
+    const int g = c / p.cpg;
+    const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
+    float t1 = 0.f, t2 = 0.f;  // sum over the group's channels of gamma*S1 and gamma*(S2 - mu*S1)*r
+    for (int cc = g * p.cpg; cc < (g + 1) * p.cpg; ++cc) {
+      const float gm = (float)p.gamma[cc];
+      t2 += gm * S1[cc];
+      t1 += gm * (S2[cc] - mu * S1[cc]) * r;
+    }
+    const float n = (float)p.HW * (float)p.cpg;
+    const float c1 = t1 / n, c2 = t2 / n;
+    float* o = p.coef + ((long)b * p.C + c) * 3;
+    o[0] = r * (float)p.gamma[c];
+    o[1] = -r * r * c1;
+    o[2] = r * r * c1 * mu - r * c2;
+  }
+}
+__global__ void gnb_param_kernel(const GNBParams p, const float* __restrict__ stats) {
+  // dgamma[c] += sum_b (S2 - mu*S1)*r ; dbeta[c] += sum_b S1   (fixed order over b and chunks)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  const int g = c / p.cpg;
+  float dg = 0.f, db = 0.f;
+  for (int b = 0; b < p.B; ++b) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int ch = 0; ch < p.chunks; ++ch) {
+      const float* o = p.part + (((long)b * p.chunks + ch) * 2) * p.C;
+      s1 += o[c];
+      s2 += o[p.C + c];
+    }
+    const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
+    dg += (s2 - mu * s1) * r;
+    db += s1;
+  }
+  p.dgamma[c] += dg;
+  p.dbeta[c] += db;
+}
+__global__ __launch_bounds__(256) void gnb_apply_kernel(const GNBParams p, const float* __restrict__ scsh) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (idx >= (long)p.HW * p.C) return;
+  const int r = (int)(idx / p.C), c = (int)(idx - (long)r * p.C);
+  const long pix = (long)b * p.HW + r;
+  const f16* src; f16* dst; int cs, co;
+  if (c < p.C1) { src = p.x; dst = p.dx; cs = p.C1; co = c; } else { src = p.x2; dst = p.dx2; cs = p.C2; co = c - p.C1; }
+  const float xv = (float)src[pix * cs + co];
+  const float a = scsh[((long)b * p.C + c) * 2], s = scsh[((long)b * p.C + c) * 2 + 1];
+  const float d = gnb_dyh((float)p.dy[pix * p.C + c], xv, a, s, p.act);
+  const float* k = p.coef + ((long)b * p.C + c) * 3;
+  if (dst) dst[pix * cs + co] = (f16)(k[0] * d + k[1] * xv + k[2]);
+}
+
+// ---- strided / upsampled conv dgrad helpers ------------------------------------------------------------------------------
+__global__ void zero_upsample2x_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int B, int H, int W, int C8) {
+  // out[b, 2y, 2x, :] = x[b, y, x, :], zeros elsewhere (out is [B, 2H, 2W, C])
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * 2 * H * 2 * W * C8;
+  if (idx >= total) return;
+  const int c = (int)(idx % C8);
+  long r = idx / C8;
+  const int ox = (int)(r % (2 * W)); r /= 2 * W;
+  const int oy = (int)(r % (2 * H));
+  const int b = (int)(r / (2 * H));
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (!(ox & 1) && !(oy & 1)) v = x[(((long)b * H + (oy >> 1)) * W + (ox >> 1)) * C8 + c];
+  out[idx] = v;
+}
+__global__ void sumpool2x2_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int B, int H, int W, int C8) {
+  // out[b, y, x, :] = sum of the 2x2 block of x [B, 2H, 2W, C]
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)B * H * W * C8;
+  if (idx >= total) return;
+  const int c = (int)(idx % C8);
+  long r = idx / C8;
+  const int ox = (int)(r % W); r /= W;
+  const int oy = (int)(r % H);
+  const int b = (int)(r / H);
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int dy = 0; dy < 2; ++dy)
+    for (int dx = 0; dx < 2; ++dx) {
+      const uint4 raw = x[(((long)b * 2 * H + 2 * oy + dy) * 2 * W + 2 * ox + dx) * C8 + c];
+      const f16x8 v = *reinterpret_cast<const f16x8*>(&raw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)v[e];
+    }
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)s[e];
+  out[idx] = *reinterpret_cast<uint4*>(&o);
+}
+
+// ---- loss + optimizer ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mse_partial_kernel(const f16* __restrict__ pred, const f16* __restrict__ target, f16* __restrict__ dpred,
+                                                          float* __restrict__ part, long pixels, int C, int ldp, int ldt, float gscale) {
+  // loss = mean((pred - target)^2) over pixels*C (f32, diffusion/train_controlnet_genima.py:1400); dpred = gscale*(pred - target)
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < pixels * ldp; i += (long)gridDim.x * 256) {
+    const long px = i / ldp;
+    const int c = (int)(i - px * ldp);
+    float d = 0.f;
+    if (c < C) { d = (float)pred[i] - (float)target[px * ldt + c]; s += d * d; }
+    if (dpred) dpred[i] = (f16)(gscale * d);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void sum_small_kernel(const float* __restrict__ part, float* __restrict__ out, int n, float scale) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += (double)part[i];
+    out[0] = (float)(s * (double)scale);
+  }
+}
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                             float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ gscale_dev, float gscale) {
+  // torch.optim.AdamW (diffusion/train_controlnet_genima.py:1178-1185): decoupled weight decay, bias-corrected moments.
+  // gscale_dev (optional, device scalar): the global-norm clip coefficient computed on the device (no host sync).
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.0f);
+  const float gi = g[i] * gs;
+  float pi = p[i] * (1.0f - lr * wd);
+  const float mi = b1 * m[i] + (1.0f - b1) * gi;
+  const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+  p[i] = pi - (lr / bc1) * (mi / denom);
+}
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float* __restrict__ out, float max_norm) {
+  // out[0] = min(1, max_norm / (norm + 1e-6)), out[1] = norm   (torch.nn.utils.clip_grad_norm_)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    const float norm = sqrtf(sumsq[0]);
+    out[1] = norm;
+    out[0] = fminf(1.0f, max_norm / (norm + 1e-6f));
+  }
+}
+__global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (f16)x[i];
+}
+__global__ void fill_f32_kernel(float* __restrict__ x, long n, float v) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
+                       int64_t in_bs, int64_t out_bs) {
+  GN_REQUIRE(ctx && in && out && rows > 0 && cols > 0 && batch > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d: bad arguments");
+  hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out,
+                     rows, cols, (long)ld_in, (long)ld_out, (long)in_bs, (long)out_bs);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize, int32_t stride,
+                    int32_t pad) {
+  GN_REQUIRE(ctx && x && out && B > 0 && H > 0 && W > 0 && C > 0 && ksize > 0 && stride > 0, "gn_im2col_t: bad arguments");
+  Im2colP p;
+  p.x = (const f16*)x; p.out = (f16*)out; p.B = B; p.H = H; p.W = W; p.C = C; p.KH = ksize; p.KW = ksize; p.stride = stride; p.pad = pad;
+  p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
+  p.M = (long)B * p.Ho * p.Wo;
+  hipLaunchKernelGGL(im2col_t_kernel, dim3((C + 63) / 64, (unsigned)((p.M + 63) / 64), ksize * ksize), dim3(256), 0, ctx->stream, p);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int64_t gn_colsum_workspace_bytes(int32_t nb, int32_t rows_per_batch, int32_t cols) {
+  int chunks = rows_per_batch / 256; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  return (int64_t)nb * chunks * cols * 4;
+}
+int32_t gn_colsum_f32(gn_ctx* ctx, const void* x, float* out, int32_t nb, int32_t rows_per_batch, int32_t cols, int64_t ld, void* workspace,
+                      int32_t accumulate) {
+  GN_REQUIRE(ctx && x && out && workspace && nb > 0 && rows_per_batch > 0 && cols > 0 && ld >= cols, "gn_colsum_f32: bad arguments");
+  int chunks = rows_per_batch / 256; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, chunks, nb), dim3(256), 0, ctx->stream, (const f16*)x, (float*)workspace,
+                     rows_per_batch, cols, (long)ld, chunks);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)nb * cols)), dim3(256), 0, ctx->stream, (const float*)workspace, out, nb, chunks, cols, accumulate);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_reduce_rows_f32(gn_ctx* ctx, const float* part, float* out, int32_t groups, int32_t R, int32_t cols, int32_t accumulate) {
+  GN_REQUIRE(ctx && part && out && groups > 0 && R > 0 && cols > 0, "gn_reduce_rows_f32: bad arguments");
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups * cols)), dim3(256), 0, ctx->stream, part, out, groups, R, cols, accumulate);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_act_bwd(gn_ctx* ctx, const void* dy, const void* z, void* dz, int64_t n, int32_t act) {
+  GN_REQUIRE(ctx && dy && z && dz && n > 0 && n % 8 == 0, "gn_act_bwd: n must be a positive multiple of 8");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(nblk(n / 8)), dim3(256), 0, ctx->stream, (const uint4*)dy, (const uint4*)z, (uint4*)dz, (long)(n / 8), act);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd) {
+  GN_REQUIRE(ctx && hg && out && M > 0 && Hd > 0, "gn_geglu_fwd: bad arguments");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)hg, (f16*)out, (long)M, Hd);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd) {
+  GN_REQUIRE(ctx && dy && hg && dhg && M > 0 && Hd > 0, "gn_geglu_bwd: bad arguments");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)dy, (const f16*)hg, (f16*)dhg, (long)M, Hd);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_softmax_bwd(gn_ctx* ctx, const void* p, void* dp, int64_t rows, int32_t cols, int64_t ld, float scale) {
+  GN_REQUIRE(ctx && p && dp && rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SB_MAXCH && ld % 8 == 0, "gn_softmax_bwd: bad arguments");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(nblk(rows, 4)), dim3(256), 0, ctx->stream, (const f16*)p, (f16*)dp, (long)rows, cols, (long)ld, scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int64_t gn_layernorm_bwd_workspace_bytes(int64_t M, int32_t C) {
+  const int64_t blocks = (M + 63) / 64;
+  return blocks * 4 * 2 * C * 4;
+}
+int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const void* dy, void* dx, float* dgamma, float* dbeta, void* workspace,
+                         int64_t M, int32_t C, float eps) {
+  GN_REQUIRE(ctx && x && gamma && dy && dx && M > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LNB_MAXCH, "gn_layernorm_bwd: C must be a multiple of 8, <= %d", 64 * 8 * LNB_MAXCH);
+  GN_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || workspace), "gn_layernorm_bwd: dgamma/dbeta come together and need a workspace");
+  const int rpb = 64;
+  const long blocks = (M + rpb - 1) / rpb;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const f16*)x, (const f16*)gamma, (const f16*)dy, (f16*)dx,
+                     dgamma ? (float*)workspace : nullptr, (long)M, C, eps, rpb);
+  GN_LAUNCH_CHECK();
+  if (dgamma) {
+    // partial rows are [blocks*4][2][C]: view as R = blocks*4 rows of 2C columns -> [2C] sums
+    GN_REQUIRE(dbeta == dgamma + C, "gn_layernorm_bwd: dbeta must follow dgamma contiguously (flat gradient buffer layout)");
+    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk(2L * C)), dim3(256), 0, ctx->stream, (const float*)workspace, dgamma, 1, (int)(blocks * 4), 2 * C, 1);
+    GN_LAUNCH_CHECK();
+  }
+  return GN_OK;
+}
+
+int64_t gn_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
+  int chunks = HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  return ((int64_t)B * chunks * 2 * C + (int64_t)B * C * 3) * 4;
+}
+/* fwd_ws: the forward's workspace (gn_groupnorm_workspace_bytes) still holding scsh[B][C][2]; stats: [B][G][2] (mean, rstd) */
+int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy, void* dx, void* dx2, const float* scsh, const float* stats,
+                         float* dgamma, float* dbeta, void* workspace) {
+  GN_REQUIRE(ctx && d && d->x && dy && scsh && stats && workspace && (dx || dx2), "gn_groupnorm_bwd: null pointer");
+  GNBParams p;
+  p.x = (const f16*)d->x; p.x2 = (const f16*)d->x2; p.dy = (const f16*)dy; p.gamma = (const f16*)d->gamma; p.beta = (const f16*)d->beta;
+  p.dx = (f16*)dx; p.dx2 = (f16*)dx2; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.B = d->B; p.HW = d->HW; p.C1 = d->C1; p.C2 = d->C2; p.C = d->C1 + d->C2; p.G = d->groups; p.cpg = p.C / p.G; p.act = d->act; p.eps = d->eps;
+  GN_REQUIRE(p.C <= 4096, "gn_groupnorm_bwd: C <= 4096");
+  int chunks = p.HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  p.rows = (p.HW + chunks - 1) / chunks;
+  p.chunks = (p.HW + p.rows - 1) / p.rows;
+  p.part = (float*)workspace;
+  p.coef = p.part + (long)p.B * chunks * 2 * p.C;
+  hipLaunchKernelGGL(gnb_partial_kernel, dim3(p.chunks, p.B), dim3(256), 0, ctx->stream, p, scsh);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gnb_finalize_kernel, dim3(p.B), dim3(256), 0, ctx->stream, p, stats);
+  GN_LAUNCH_CHECK();
+  if (dgamma) {
+    hipLaunchKernelGGL(gnb_param_kernel, dim3(nblk(p.C)), dim3(256), 0, ctx->stream, p, stats);
+    GN_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(gnb_apply_kernel, dim3(nblk((long)p.HW * p.C), p.B), dim3(256), 0, ctx->stream, p, scsh);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_zero_upsample2x(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C) {
+  GN_REQUIRE(ctx && x && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gn_zero_upsample2x: bad arguments");
+  hipLaunchKernelGGL(zero_upsample2x_kernel, dim3(nblk((long)B * 4 * H * W * (C / 8))), dim3(256), 0, ctx->stream, (const uint4*)x, (uint4*)out, B, H, W, C / 8);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+int32_t gn_sumpool2x2(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C) {
+  GN_REQUIRE(ctx && x && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gn_sumpool2x2: bad arguments (H, W are the OUTPUT size)");
+  hipLaunchKernelGGL(sumpool2x2_kernel, dim3(nblk((long)B * H * W * (C / 8))), dim3(256), 0, ctx->stream, (const uint4*)x, (uint4*)out, B, H, W, C / 8);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+/* loss_out[0] = mean((pred[:, :C] - target)^2) in f32; dpred = grad_scale * 2/(pixels*C) * (pred - target) (0 in padded channels) */
+int32_t gn_mse_loss(gn_ctx* ctx, const void* pred, const void* target, void* dpred, float* loss_out, void* workspace, int64_t pixels, int32_t C,
+                    int32_t ld_pred, int32_t ld_target, float grad_scale) {
+  GN_REQUIRE(ctx && pred && target && loss_out && workspace && pixels > 0 && C > 0 && ld_pred >= C && ld_target >= C, "gn_mse_loss: bad arguments");
+  const int blocks = 256;
+  const float gs = grad_scale * 2.0f / (float)((double)pixels * C);
+  hipLaunchKernelGGL(mse_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, (const f16*)pred, (const f16*)target, (f16*)dpred, (float*)workspace,
+                     (long)pixels, C, ld_pred, ld_target, gs);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)workspace, loss_out, blocks, 1.0f / (float)((double)pixels * C));
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+/* out[0] = sum(x^2) (deterministic two-stage); workspace >= 1024 floats */
+int32_t gn_sumsq_f32(gn_ctx* ctx, const float* x, int64_t n, float* out, void* workspace) {
+  GN_REQUIRE(ctx && x && out && workspace && n > 0, "gn_sumsq_f32: bad arguments");
+  const int blocks = 1024;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, ctx->stream, x, (float*)workspace, (long)n);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, ctx->stream, (const float*)workspace, out, blocks, 1.0f);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+/* clip[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)), clip[1] = the norm */
+int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm) {
+  GN_REQUIRE(ctx && sumsq && clip && max_norm > 0.f, "gn_clip_coef: bad arguments");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, sumsq, clip, max_norm);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+/* fused AdamW over flat f32 buffers; step >= 1; grad is multiplied by grad_scale * (clip_dev ? clip_dev[0] : 1) */
+int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, const float* clip_dev, float grad_scale) {
+  GN_REQUIRE(ctx && param && grad && m && v && n > 0 && step >= 1, "gn_adamw_flat: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+  hipLaunchKernelGGL(adamw_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, param, grad, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                     clip_dev, grad_scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n) {
+  GN_REQUIRE(ctx && x && out && n > 0, "gn_cast_f32_f16: bad arguments");
+  hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, x, (f16*)out, (long)n);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+int32_t gn_fill_f32(gn_ctx* ctx, float* x, int64_t n, float v) {
+  GN_REQUIRE(ctx && x && n > 0, "gn_fill_f32: bad arguments");
+  hipLaunchKernelGGL(fill_f32_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, x, (long)n, v);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+}  // extern "C"

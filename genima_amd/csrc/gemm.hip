@@ -44,7 +44,25 @@ struct GemmParams {
   int splitk, kper;
   int tiles_m, tiles_n;
   unsigned a_bytes, a2_bytes, w_bytes;  // LDS-DMA variant: buffer-descriptor extents (everything else reads as zero)
+  int accumulate;                        // GN_OUT_F32: out += result
+  int nbatch, binner;                    // batched GEMM: blockIdx.z in [0, nbatch) = outer * binner + inner
+  long a_bs, a_bs2, w_bs, w_bs2, o_bs, o_bs2, r_bs, r_bs2;  // batch strides (elements; o_* in output elements)
 };
+
+// batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
+__device__ __forceinline__ GemmParams batch_offset(const GemmParams& pin) {
+  GemmParams p = pin;
+  if (pin.binner > 0) {
+    const int bz = blockIdx.z;
+    const long bo = bz / pin.binner, bi = bz - bo * pin.binner;
+    p.a += bo * pin.a_bs + bi * pin.a_bs2;
+    p.w += bo * pin.w_bs + bi * pin.w_bs2;
+    if (pin.res) p.res += bo * pin.r_bs + bi * pin.r_bs2;
+    const long oo = bo * pin.o_bs + bi * pin.o_bs2;
+    p.out = pin.out_mode == GN_OUT_F32 ? reinterpret_cast<f16*>(reinterpret_cast<float*>(pin.out) + oo) : pin.out + oo;
+  }
+  return p;
+}
 
 // erf via Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below f16 resolution): ~12 VALU instead of ocml erff's ~50, which
 // matters because the GEGLU / GELU epilogues run on K = 320..1280 GEMMs where the epilogue is a visible share of the tile time.
@@ -104,6 +122,11 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
     f16* o = p.out + ((long)bidx * p.N + nb) * p.ldo + ml;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[(long)i * p.ldo] = (f16)v[i];
+  } else if (p.out_mode == GN_OUT_F32) {  // f32 result (weight gradients: fp32 like the reference's master grads)
+    f32x4 o = {v[0], v[1], v[2], v[3]};
+    float* op = reinterpret_cast<float*>(p.out) + (long)m * p.ldo + nb;
+    if (p.accumulate) o += *reinterpret_cast<const f32x4*>(op);
+    *reinterpret_cast<f32x4*>(op) = o;
   } else {
     f16x4 o;
 #pragma unroll
@@ -179,7 +202,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
 }
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams pin) {
+  const GemmParams p = batch_offset(pin);
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;  // tile rows staged per pass (8 lanes x 16 B cover one 128-byte row)
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -375,7 +399,8 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr unsigned kOOB = 0xFFFFFFF0u;
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams pin) {
+  const GemmParams p = batch_offset(pin);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -565,7 +590,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
 
 template <int BM, int BN, int WM, int WN>
 void launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
-  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, 1);
+  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1);
   if (conv)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
@@ -574,7 +599,7 @@ void launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
 
 template <int BM, int BN, int WM, int WN>
 void launch_dma(const GemmParams& p, bool conv, hipStream_t st) {
-  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, 1);
+  dim3 grid(p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1);
   if (conv)
     hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
@@ -665,7 +690,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   int sk = d->splitk;
   if (sk <= 0) {
     sk = 1;
-    if (d->act != GN_ACT_GEGLU && d->out_mode == GN_OUT_ROWMAJOR && blocks < 192 && K >= 1024) {
+    if (d->act != GN_ACT_GEGLU && d->out_mode != GN_OUT_BATCH_TRANSPOSED && d->batch <= 1 && blocks < 192 && K >= 1024) {
       sk = (int)cdiv64(384, blocks);
       const int maxsk = (int)(K / 512);
       if (sk > maxsk) sk = maxsk;
@@ -673,7 +698,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
       if (sk < 1) sk = 1;
     }
   }
-  if (d->act == GN_ACT_GEGLU || d->out_mode != GN_OUT_ROWMAJOR) sk = 1;
+  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1) sk = 1;
   int kper = (int)(cdiv64(cdiv64(K, sk), BK) * BK);
   sk = (int)cdiv64(K, kper);
   pl.splitk = sk;
@@ -718,6 +743,19 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.H = d->H; p.W = d->W; p.C1 = d->C1; p.C2 = d->C2; p.KH = d->KH; p.KW = d->KW; p.stride = d->stride;
   p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Ho = d->Ho; p.Wo = d->Wo; p.ups = d->upsample2x;
   p.act = d->act; p.out_mode = d->out_mode; p.res_first = d->residual_before_act;
+  p.accumulate = d->accumulate;
+  p.nbatch = d->batch > 1 ? d->batch : 0;
+  p.binner = p.nbatch ? (d->batch_inner > 0 ? d->batch_inner : 1) : 0;
+  p.a_bs = d->a_bs; p.a_bs2 = d->a_bs2; p.w_bs = d->w_bs; p.w_bs2 = d->w_bs2;
+  p.o_bs = d->out_bs; p.o_bs2 = d->out_bs2; p.r_bs = d->res_bs; p.r_bs2 = d->res_bs2;
+  if (p.nbatch) {
+    GN_REQUIRE(!d->conv && !d->shift && d->out_mode != GN_OUT_BATCH_TRANSPOSED, "gn_gemm: batched mode is dense GEMM only (no conv/shift/transposed out)");
+    GN_REQUIRE(d->a_bs % 8 == 0 && d->a_bs2 % 8 == 0 && d->w_bs % 8 == 0 && d->w_bs2 % 8 == 0 && d->out_bs % 4 == 0 && d->out_bs2 % 4 == 0 &&
+               d->res_bs % 4 == 0 && d->res_bs2 % 4 == 0, "gn_gemm: batch strides must keep 16-byte (a/w) and 8-byte (out/res) alignment");
+    GN_REQUIRE(d->batch % p.binner == 0, "gn_gemm: batch (%d) must be a multiple of batch_inner (%d)", d->batch, p.binner);
+  }
+  if (d->out_mode == GN_OUT_F32) GN_REQUIRE(d->act != GN_ACT_GEGLU && ((uintptr_t)d->out & 15) == 0, "gn_gemm: f32 output needs a 16-byte aligned out and no GEGLU");
+  if (d->accumulate) GN_REQUIRE(d->out_mode == GN_OUT_F32, "gn_gemm: accumulate needs GN_OUT_F32");
   p.rpb = d->rows_per_batch > 0 ? d->rows_per_batch : (int)d->M;
   p.out_scale = d->out_scale;
   if (d->conv) {
@@ -731,7 +769,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     GN_REQUIRE(d->lda % 8 == 0 && d->lda >= d->K, "gn_gemm: lda (%ld) must be a multiple of 8 and >= K", (long)d->lda);
   }
   if (d->residual) GN_REQUIRE(d->ldr % 4 == 0 && ((uintptr_t)d->residual & 7) == 0, "gn_gemm: residual stride/alignment");
-  if (d->out_mode == GN_OUT_ROWMAJOR) GN_REQUIRE(d->ldo % 4 == 0, "gn_gemm: ldo (%ld) must be a multiple of 4", (long)d->ldo);
+  if (d->out_mode != GN_OUT_BATCH_TRANSPOSED) GN_REQUIRE(d->ldo % 4 == 0, "gn_gemm: ldo (%ld) must be a multiple of 4", (long)d->ldo);
   if (d->out_mode == GN_OUT_BATCH_TRANSPOSED) GN_REQUIRE(d->rows_per_batch > 0 && d->M % d->rows_per_batch == 0, "gn_gemm: transposed output needs rows_per_batch | M");
   if (d->shift) GN_REQUIRE(d->rows_per_batch > 0 && p.ldshift % 4 == 0 && ((uintptr_t)d->shift & 7) == 0, "gn_gemm: shift needs rows_per_batch and 8-byte aligned rows");
 

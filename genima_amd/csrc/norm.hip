@@ -20,6 +20,7 @@ struct GNParams {
   const f16* x; const f16* x2; const f16* gamma; const f16* beta; f16* y;
   float* partials;  // [B][chunks][G][2]
   float* scsh;      // [B][C][2]
+  float* stats;     // optional [B][G][2] (mean, rstd) saved for the backward pass
   int B, HW, C1, C2, C, G, cpg, chunks, rows, achunks, arows, act;
   float eps;
 };
@@ -122,6 +123,10 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GNParams p) {
     if (var < 0.0) var = 0.0;
     mean_s[tid] = (float)mean;
     rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+    if (p.stats) {  // training: keep (mean, rstd) per (batch, group) for the backward pass
+      p.stats[((long)b * p.G + tid) * 2] = mean_s[tid];
+      p.stats[((long)b * p.G + tid) * 2 + 1] = rstd_s[tid];
+    }
   }
   __syncthreads();
   for (int c = tid; c < p.C; c += 256) {
@@ -332,6 +337,9 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.act = d->act; p.eps = d->eps;
   p.partials = (float*)d->workspace;
   p.scsh = p.partials + (long)d->B * gn_pick_chunks(d->B, d->HW) * d->groups * 2;
+  p.stats = (float*)d->save_stats;
+  if (d->save_scsh) p.scsh = (float*)d->save_scsh;  // training: persistent per-(b, c) scale/shift for the backward pass
+  const bool saving = d->save_stats || d->save_scsh;
   {  // single-launch path when a (batch, group) slab fits in LDS
     static int fused_ok = -1;
     if (fused_ok < 0) {
@@ -341,7 +349,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
         GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GNF_MAX_LDS));
     }
     const long slab = (long)d->HW * p.cpg * 2;
-    if (fused_ok && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= GNF_MAX_LDS &&
+    if (fused_ok && !saving && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= GNF_MAX_LDS &&
         (long)d->B * d->groups >= 64) {
       hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups, d->B), dim3(GNF_THREADS), (size_t)slab, ctx->stream, p);
       GN_LAUNCH_CHECK();

@@ -1,0 +1,184 @@
+"""Eager wrappers of the training-side C ABI entry points (include/genima_hip.h "training-side kernels") on torch CUDA tensors.
+
+Used by genima_amd/training.py (the ControlNet fine-tune step).  Like engine.py: torch is memory/stream plumbing only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from ._lib import OUT_F32, OUT_ROWMAJOR, GemmDesc, GroupNormDesc, check
+from .engine import Engine, _ptr
+
+F16, F32 = torch.float16, torch.float32
+
+
+def gemm(E: Engine, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int, ldw: int, ldo: int, *,
+         bias=None, residual=None, ldr: int = 0, f32_out: bool = False, accumulate: bool = False, batch: int = 0, batch_inner: int = 1,
+         a_bs=(0, 0), w_bs=(0, 0), out_bs=(0, 0), act: int = 0):
+    """Raw dense GEMM out[m, n] = sum_k a[m*lda + k] * w[n*ldw + k] (+ epilogue), optionally batched / f32 / accumulating."""
+    d = GemmDesc()
+    d.a, d.w, d.out, d.bias, d.residual = _ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual)
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, lda, ldw, ldo, ldr
+    d.out_mode = OUT_F32 if f32_out else OUT_ROWMAJOR
+    d.accumulate, d.act, d.out_scale = int(accumulate), act, 1.0
+    if batch > 1:
+        d.batch, d.batch_inner = batch, batch_inner
+        d.a_bs, d.a_bs2 = a_bs
+        d.w_bs, d.w_bs2 = w_bs
+        d.out_bs, d.out_bs2 = out_bs
+    nb = int(E.lib.gn_gemm_workspace_bytes(C.byref(d)))
+    if nb > 0:
+        d.workspace = E._workspace(nb).data_ptr()
+    check(E.lib.gn_gemm(E._ctx, C.byref(d)), "gn_gemm")
+    return out
+
+
+def transpose2d(E: Engine, x: torch.Tensor, rows: int, cols: int, *, ld_in: Optional[int] = None, batch: int = 1, in_bs: int = 0,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x viewed as [batch][rows, cols] (row stride ld_in) -> [batch][cols, rows] contiguous."""
+    ld_in = cols if ld_in is None else ld_in
+    if out is None:
+        out = torch.empty((batch, cols, rows) if batch > 1 else (cols, rows), dtype=F16, device=E.device)
+    check(E.lib.gn_transpose2d(E._ctx, _ptr(x), _ptr(out), rows, cols, ld_in, rows, batch, in_bs, cols * rows), "gn_transpose2d")
+    return out
+
+
+def im2col_t(E: Engine, x: torch.Tensor, ksize: int, stride: int, pad: int) -> torch.Tensor:
+    B, H, W, Cc = x.shape
+    Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+    out = torch.empty((ksize * ksize * Cc, B * Ho * Wo), dtype=F16, device=E.device)
+    check(E.lib.gn_im2col_t(E._ctx, _ptr(x), _ptr(out), B, H, W, Cc, ksize, stride, pad), "gn_im2col_t")
+    return out
+
+
+def colsum(E: Engine, x: torch.Tensor, out: torch.Tensor, nb: int, rows_per_batch: int, cols: int, ld: int, accumulate: bool = True):
+    ws = E._workspace(int(E.lib.gn_colsum_workspace_bytes(nb, rows_per_batch, cols)))
+    check(E.lib.gn_colsum_f32(E._ctx, _ptr(x), _ptr(out), nb, rows_per_batch, cols, ld, _ptr(ws), int(accumulate)), "gn_colsum_f32")
+    return out
+
+
+def act_bwd(E: Engine, dy: torch.Tensor, z: torch.Tensor, act: int) -> torch.Tensor:
+    dz = torch.empty_like(dy)
+    check(E.lib.gn_act_bwd(E._ctx, _ptr(dy), _ptr(z), _ptr(dz), dy.numel(), act), "gn_act_bwd")
+    return dz
+
+
+def geglu_fwd(E: Engine, hg: torch.Tensor) -> torch.Tensor:
+    Hd = hg.shape[-1] // 2
+    out = torch.empty(tuple(hg.shape[:-1]) + (Hd,), dtype=F16, device=E.device)
+    check(E.lib.gn_geglu_fwd(E._ctx, _ptr(hg), _ptr(out), hg.numel() // (2 * Hd), Hd), "gn_geglu_fwd")
+    return out
+
+
+def geglu_bwd(E: Engine, dy: torch.Tensor, hg: torch.Tensor) -> torch.Tensor:
+    Hd = hg.shape[-1] // 2
+    dhg = torch.empty_like(hg)
+    check(E.lib.gn_geglu_bwd(E._ctx, _ptr(dy), _ptr(hg), _ptr(dhg), hg.numel() // (2 * Hd), Hd), "gn_geglu_bwd")
+    return dhg
+
+
+def softmax_bwd(E: Engine, p: torch.Tensor, dp: torch.Tensor, scale: float):
+    cols = p.shape[-1]
+    check(E.lib.gn_softmax_bwd(E._ctx, _ptr(p), _ptr(dp), p.numel() // cols, cols, p.stride(-2), float(scale)), "gn_softmax_bwd")
+    return dp
+
+
+def layernorm_bwd(E: Engine, x, gamma, dy, dgamma: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """dgamma: f32 view of [2*C] = (dgamma | dbeta) inside the flat gradient buffer (accumulated), or None."""
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    dx = torch.empty_like(x)
+    ws = E._workspace(int(E.lib.gn_layernorm_bwd_workspace_bytes(M, Cc))) if dgamma is not None else None
+    dg = _ptr(dgamma)
+    db = None if dgamma is None else dgamma.data_ptr() + 4 * Cc
+    check(E.lib.gn_layernorm_bwd(E._ctx, _ptr(x), _ptr(gamma), _ptr(dy), _ptr(dx), dg, db, _ptr(ws), M, Cc, eps), "gn_layernorm_bwd")
+    return dx
+
+
+class GNSaved:
+    """What a training-mode GroupNorm keeps for its backward."""
+    __slots__ = ("desc", "x", "x2", "gamma", "beta", "stats", "scsh", "keep")
+
+
+def groupnorm_fwd_train(E: Engine, x, gamma, beta, groups: int, eps: float, act: int, x2=None):
+    B, C1 = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C1)
+    C2 = x2.shape[-1] if x2 is not None else 0
+    out = torch.empty(tuple(x.shape[:-1]) + (C1 + C2,), dtype=F16, device=E.device)
+    s = GNSaved()
+    s.stats = torch.empty((B, groups, 2), dtype=F32, device=E.device)
+    s.scsh = torch.empty((B, C1 + C2, 2), dtype=F32, device=E.device)
+    d = GroupNormDesc()
+    d.x, d.x2, d.gamma, d.beta, d.y = _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out)
+    d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, C1, C2, groups, act, eps
+    d.save_stats, d.save_scsh = s.stats.data_ptr(), s.scsh.data_ptr()
+    d.workspace = E._workspace(int(E.lib.gn_groupnorm_workspace_bytes(C.byref(d)))).data_ptr()
+    check(E.lib.gn_groupnorm_fwd(E._ctx, C.byref(d)), "gn_groupnorm_fwd")
+    s.desc, s.x, s.x2, s.gamma, s.beta = d, x, x2, gamma, beta
+    return out, s
+
+
+def groupnorm_bwd(E: Engine, s: GNSaved, dy, need_dx2: bool = True, dgamma: Optional[torch.Tensor] = None):
+    """-> (dx, dx2).  dgamma: f32 view [2*C] = (dgamma | dbeta), accumulated, or None."""
+    d = s.desc
+    dx = torch.empty_like(s.x)
+    dx2 = torch.empty_like(s.x2) if (s.x2 is not None and need_dx2) else None
+    Cc = d.C1 + d.C2
+    ws = E._workspace(int(E.lib.gn_groupnorm_bwd_workspace_bytes(d.B, d.HW, Cc)))
+    dg = _ptr(dgamma)
+    db = None if dgamma is None else dgamma.data_ptr() + 4 * Cc
+    check(E.lib.gn_groupnorm_bwd(E._ctx, C.byref(d), _ptr(dy), _ptr(dx), _ptr(dx2), _ptr(s.scsh), _ptr(s.stats), dg, db, _ptr(ws)), "gn_groupnorm_bwd")
+    return dx, dx2
+
+
+def zero_upsample2x(E: Engine, x: torch.Tensor) -> torch.Tensor:
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, 2 * H, 2 * W, Cc), dtype=F16, device=E.device)
+    check(E.lib.gn_zero_upsample2x(E._ctx, _ptr(x), _ptr(out), B, H, W, Cc), "gn_zero_upsample2x")
+    return out
+
+
+def sumpool2x2(E: Engine, x: torch.Tensor) -> torch.Tensor:
+    B, H2, W2, Cc = x.shape
+    out = torch.empty((B, H2 // 2, W2 // 2, Cc), dtype=F16, device=E.device)
+    check(E.lib.gn_sumpool2x2(E._ctx, _ptr(x), _ptr(out), B, H2 // 2, W2 // 2, Cc), "gn_sumpool2x2")
+    return out
+
+
+def mse_loss(E: Engine, pred: torch.Tensor, target: torch.Tensor, C_valid: int, grad_scale: float = 1.0):
+    """pred [..., ldp] (first C_valid channels valid), target [..., ldt] -> (loss f32 [1] device tensor, dpred like pred)."""
+    ldp, ldt = pred.shape[-1], target.shape[-1]
+    pixels = pred.numel() // ldp
+    dpred = torch.empty_like(pred)
+    loss = torch.empty(1, dtype=F32, device=E.device)
+    ws = E._workspace(4096)
+    check(E.lib.gn_mse_loss(E._ctx, _ptr(pred), _ptr(target), _ptr(dpred), _ptr(loss), _ptr(ws), pixels, C_valid, ldp, ldt, float(grad_scale)), "gn_mse_loss")
+    return loss, dpred
+
+
+def sumsq(E: Engine, x: torch.Tensor, out: torch.Tensor):
+    ws = E._workspace(8192)
+    check(E.lib.gn_sumsq_f32(E._ctx, _ptr(x), x.numel(), _ptr(out), _ptr(ws)), "gn_sumsq_f32")
+    return out
+
+
+def clip_coef(E: Engine, sumsq_t: torch.Tensor, clip: torch.Tensor, max_norm: float):
+    check(E.lib.gn_clip_coef(E._ctx, _ptr(sumsq_t), _ptr(clip), float(max_norm)), "gn_clip_coef")
+    return clip
+
+
+def adamw(E: Engine, param, grad, m, v, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
+    check(E.lib.gn_adamw_flat(E._ctx, _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps, wd, step, _ptr(clip), grad_scale), "gn_adamw_flat")
+
+
+def cast_f32_f16(E: Engine, x: torch.Tensor, out: torch.Tensor):
+    check(E.lib.gn_cast_f32_f16(E._ctx, _ptr(x), _ptr(out), x.numel()), "gn_cast_f32_f16")
+    return out
+
+
+def fill_f32(E: Engine, x: torch.Tensor, v: float = 0.0):
+    check(E.lib.gn_fill_f32(E._ctx, _ptr(x), x.numel(), float(v)), "gn_fill_f32")
+    return x

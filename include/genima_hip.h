@@ -31,7 +31,7 @@ extern "C" {
 /* epilogue activations */
 enum { GN_ACT_NONE = 0, GN_ACT_SILU = 1, GN_ACT_GELU = 2, GN_ACT_QUICK_GELU = 3, GN_ACT_RELU = 4, GN_ACT_GEGLU = 5 };
 /* output modes of the GEMM epilogue */
-enum { GN_OUT_ROWMAJOR = 0, GN_OUT_BATCH_TRANSPOSED = 1 };
+enum { GN_OUT_ROWMAJOR = 0, GN_OUT_BATCH_TRANSPOSED = 1, GN_OUT_F32 = 2 /* row-major float output, ldo in floats */ };
 
 typedef struct gn_ctx gn_ctx;
 typedef struct gn_program gn_program;
@@ -76,6 +76,13 @@ typedef struct gn_gemm_desc {
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */
+  /* batched GEMM (attention backward, per-sample products): `batch` independent problems of the same shape; problem z uses
+   * operand + (z / batch_inner) * *_bs + (z % batch_inner) * *_bs2 (strides in elements of that operand; batch_inner >= 1).
+   * batch <= 1 = a single problem.  Split-K is disabled when batch > 1. */
+  int32_t batch, batch_inner;
+  int64_t a_bs, a_bs2, w_bs, w_bs2, out_bs, out_bs2, res_bs, res_bs2;
+  int32_t accumulate;     /* GN_OUT_F32 only: out += result (gradient accumulation) */
+  int32_t reserved;
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
@@ -109,6 +116,8 @@ typedef struct gn_groupnorm_desc {
   int32_t B, HW, C1, C2, groups;
   int32_t act;                       /* GN_ACT_NONE or GN_ACT_SILU */
   float eps;
+  void* save_stats;                  /* training: optional f32 [B][groups][2] (mean, rstd) kept for gn_groupnorm_bwd */
+  void* save_scsh;                   /* training: optional f32 [B][C][2] per-(b, c) scale/shift kept for gn_groupnorm_bwd */
 } gn_groupnorm_desc;
 int64_t gn_groupnorm_workspace_bytes(const gn_groupnorm_desc* d);
 int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d);
@@ -157,6 +166,44 @@ int32_t gn_embedding(gn_ctx* ctx, const int32_t* ids, const void* tok, const voi
                      int32_t L, int32_t D);                                                   /* CLIP token + position */
 int32_t gn_softmax_rows(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale); /* in place, f16 */
 int32_t gn_maxpool3x3s2(gn_ctx* ctx, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C);
+
+/* ---- training-side kernels (ControlNet fine-tune step, diffusion/train_controlnet_genima.py:1317-1408) ----------
+ * The backward matrix products reuse gn_gemm: dX = dY.W through a transposed weight copy, dW = dY^T.X through transposed
+ * activations with GN_OUT_F32 + split-K, conv dgrad = conv with rotated weights, conv wgrad = GEMM over gn_im2col_t's image.
+ * Parameter gradients are f32 and accumulate; all reductions are deterministic. */
+int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
+                       int32_t batch, int64_t in_bs, int64_t out_bs);                 /* out[b][c][r] = in[b][r][c] (f16) */
+/* out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c] (0 in the padding); M = B*Ho*Wo contiguous */
+int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize,
+                    int32_t stride, int32_t pad);
+int64_t gn_colsum_workspace_bytes(int32_t nb, int32_t rows_per_batch, int32_t cols);
+/* out[b][c] (+)= sum_r x[b*rows_per_batch + r][c]  (bias gradients nb = 1; time-shift gradients nb = batch) */
+int32_t gn_colsum_f32(gn_ctx* ctx, const void* x, float* out, int32_t nb, int32_t rows_per_batch, int32_t cols, int64_t ld,
+                      void* workspace, int32_t accumulate);
+int32_t gn_reduce_rows_f32(gn_ctx* ctx, const float* part, float* out, int32_t groups, int32_t R, int32_t cols, int32_t accumulate);
+int32_t gn_act_bwd(gn_ctx* ctx, const void* dy, const void* z, void* dz, int64_t n, int32_t act);   /* dz = dy * act'(z) */
+int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd);   /* hg = [hidden | gate] (unfused form) */
+int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd);
+/* attention backward softmax step, in place over dp: ds = scale * p * (dp - rowsum(p * dp)) */
+int32_t gn_softmax_bwd(gn_ctx* ctx, const void* p, void* dp, int64_t rows, int32_t cols, int64_t ld, float scale);
+int64_t gn_layernorm_bwd_workspace_bytes(int64_t M, int32_t C);
+/* dx from (x, gamma, dy); dgamma/dbeta (f32, dbeta == dgamma + C, accumulated) optional */
+int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const void* dy, void* dx, float* dgamma, float* dbeta,
+                         void* workspace, int64_t M, int32_t C, float eps);
+int64_t gn_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C);
+/* backward of gn_groupnorm_fwd(d) run with save_stats/save_scsh; dx / dx2 follow d->x / d->x2 (either may be NULL) */
+int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy, void* dx, void* dx2, const float* scsh,
+                         const float* stats, float* dgamma, float* dbeta, void* workspace);
+int32_t gn_zero_upsample2x(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C); /* stride-2 dgrad */
+int32_t gn_sumpool2x2(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C);       /* upsample dgrad */
+int32_t gn_mse_loss(gn_ctx* ctx, const void* pred, const void* target, void* dpred, float* loss_out, void* workspace,
+                    int64_t pixels, int32_t C, int32_t ld_pred, int32_t ld_target, float grad_scale);
+int32_t gn_sumsq_f32(gn_ctx* ctx, const float* x, int64_t n, float* out, void* workspace);
+int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm);
+int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t step, const float* clip_dev, float grad_scale);
+int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n);
+int32_t gn_fill_f32(gn_ctx* ctx, float* x, int64_t n, float v);
 
 /* ---- op programs: record once, replay on the stream (eagerly or as a captured hipGraph) ---------------------------
  * The host classes (UNet2DConditionModel / ControlNetModel / AutoencoderKL / pipeline) lower a forward pass to a flat list of

@@ -1,0 +1,196 @@
+"""-m gpu: backward / optimizer kernels of the ControlNet fine-tune step against torch autograd on CPU (fp32, same f16 inputs)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from genima_amd import train_ops as T
+from genima_amd.packing import pack_conv_weight
+from util import assert_close, q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def h(t):
+    return t.half().cuda()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------- GEMM extensions
+def test_gemm_f32_out_accumulate_and_batched(engine):
+    M, N, K = 200, 192, 256
+    a, w = q16(torch.randn(M, K, generator=g(1))), q16(torch.randn(N, K, generator=g(2)) * K ** -0.5)
+    out = torch.full((M, N), 0.5, dtype=torch.float32, device="cuda")
+    T.gemm(engine, h(a), h(w), out, M, N, K, K, K, N, f32_out=True, accumulate=True)
+    assert_close(out, a @ w.t() + 0.5, what="f32 accumulate gemm")
+    # batched, two-level strides: [Bo, Bi] problems
+    Bo, Bi = 3, 2
+    ab = q16(torch.randn(Bo, Bi, M, K, generator=g(3)))
+    wb = q16(torch.randn(Bo, Bi, N, K, generator=g(4)) * K ** -0.5)
+    ob = torch.empty(Bo, Bi, M, N, dtype=torch.float16, device="cuda")
+    T.gemm(engine, h(ab), h(wb), ob, M, N, K, K, K, N, batch=Bo * Bi, batch_inner=Bi, a_bs=(Bi * M * K, M * K), w_bs=(Bi * N * K, N * K),
+           out_bs=(Bi * M * N, M * N))
+    assert_close(ob, ab @ wb.transpose(-1, -2), what="batched gemm")
+
+
+def test_linear_backward(engine):
+    M, K, N = 1000, 320, 640
+    x = q16(torch.randn(M, K, generator=g(1)))
+    w = q16(torch.randn(N, K, generator=g(2)) * K ** -0.5)
+    dy = q16(torch.randn(M, N, generator=g(3)))
+    # dX = dY . W  through the transposed weight copy
+    wt = T.transpose2d(engine, h(w), N, K)                       # [K, N]
+    dx = torch.empty(M, K, dtype=torch.float16, device="cuda")
+    T.gemm(engine, h(dy), wt, dx, M, K, N, N, N, K)
+    assert_close(dx, dy @ w, what="linear dX")
+    # dW = dY^T . X  (f32, split-K over M) ; db = colsum(dY)
+    dyt, xt = T.transpose2d(engine, h(dy), M, N), T.transpose2d(engine, h(x), M, K)
+    dw = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+    T.gemm(engine, dyt, xt, dw, N, K, (M + 7) // 8 * 8, dyt.stride(0), xt.stride(0), K, f32_out=True, accumulate=True)
+    assert_close(dw, dy.t() @ x, what="linear dW")
+    db = torch.zeros(N, dtype=torch.float32, device="cuda")
+    T.colsum(engine, h(dy), db, 1, M, N, N)
+    assert_close(db, dy.sum(0), what="bias grad")
+    sh = torch.zeros(4, N, dtype=torch.float32, device="cuda")
+    T.colsum(engine, h(dy), sh, 4, M // 4, N, N)
+    assert_close(sh, dy.view(4, M // 4, N).sum(1), what="per-batch shift grad")
+
+
+# ---------------------------------------------------------------------------------------------------- conv backward
+def _conv_ref(x, w, stride, pad, up):
+    x = x.clone().requires_grad_(True)
+    w = w.clone().requires_grad_(True)
+    xi = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    return x, w, F.conv2d(xi, w, None, stride, pad)
+
+
+@pytest.mark.parametrize("stride,up", [(1, False), (2, False), (1, True)])
+def test_conv_backward(engine, stride, up):
+    B, Cin, Cout, H = 2, 64, 128, 16
+    x0 = q16(torch.randn(B, Cin, H, H, generator=g(1)))
+    w0 = q16(torch.randn(Cout, Cin, 3, 3, generator=g(2)) * (9 * Cin) ** -0.5)
+    x, w, y = _conv_ref(x0, w0, stride, 1, up)
+    dy = q16(torch.randn(y.shape, generator=g(3)))
+    y.backward(dy)
+    dyn = h(nhwc(dy))
+    # dgrad: conv of dY with the 180-degree-rotated, in/out-swapped weights (stride 2: zero-insertion first; upsample: 2x2 sum after)
+    wd = pack_conv_weight(w0.flip(2, 3).permute(1, 0, 2, 3).contiguous()).cuda()
+    src = T.zero_upsample2x(engine, dyn) if stride == 2 else dyn
+    dxi = engine.conv2d(src, wd, None)
+    if stride == 2:
+        dxi = dxi[:, :H, :H].contiguous()  # the zero-upsampled map is 2*Ho = H here (even H)
+    dx = T.sumpool2x2(engine, dxi) if up else dxi
+    assert_close(dx, nhwc(x.grad), what=f"conv dgrad s{stride} up{up}")
+    # wgrad: dW[co][tap*Cin + ci] = sum_m dY^T[co][m] * im2col^T[tap*Cin + ci][m]
+    xin = h(nhwc(F.interpolate(x0, scale_factor=2.0, mode="nearest") if up else x0))
+    cols = T.im2col_t(engine, xin, 3, stride, 1)
+    M = cols.shape[1]
+    dyt = T.transpose2d(engine, dyn.view(M, Cout), M, Cout)
+    dw = torch.zeros(Cout, 9 * Cin, dtype=torch.float32, device="cuda")
+    T.gemm(engine, dyt, cols, dw, Cout, 9 * Cin, M, M, M, 9 * Cin, f32_out=True, accumulate=True)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin)
+    assert_close(dw, ref, what=f"conv wgrad s{stride} up{up}")
+
+
+# ---------------------------------------------------------------------------------------------------- elementwise / norms
+def test_act_geglu_softmax_backward(engine):
+    z = q16(torch.randn(64, 128, generator=g(1)) * 2)
+    dy = q16(torch.randn(64, 128, generator=g(2)))
+    for act, fn in ((1, F.silu), (2, F.gelu), (4, F.relu)):
+        zz = z.clone().requires_grad_(True)
+        fn(zz).backward(dy)
+        assert_close(T.act_bwd(engine, h(dy), h(z), act), zz.grad, what=f"act bwd {act}")
+    hg = q16(torch.randn(50, 256, generator=g(3))).requires_grad_(True)
+    hid, gate = hg.chunk(2, -1)
+    out = hid * F.gelu(gate)
+    assert_close(T.geglu_fwd(engine, h(hg.detach())), out.detach(), what="geglu fwd")
+    d2 = q16(torch.randn(50, 128, generator=g(4)))
+    out.backward(d2)
+    assert_close(T.geglu_bwd(engine, h(d2), h(hg.detach())), hg.grad, what="geglu bwd")
+    s = (torch.randn(33, 256, generator=g(5)) * 2).requires_grad_(True)
+    p = torch.softmax(s * 0.125, -1)
+    dp = q16(torch.randn(33, 256, generator=g(6)))
+    p16 = q16(p.detach())
+    ref = 0.125 * p16 * (dp - (p16 * dp).sum(-1, keepdim=True))
+    dpd = h(dp)
+    T.softmax_bwd(engine, h(p16), dpd, 0.125)
+    assert_close(dpd, ref, what="softmax bwd")
+
+
+def test_layernorm_backward(engine):
+    M, C = 300, 320
+    x = q16(torch.randn(M, C, generator=g(1)) * 2 + 0.5).requires_grad_(True)
+    gm = q16(1 + 0.1 * torch.randn(C, generator=g(2))).requires_grad_(True)
+    bt = q16(0.1 * torch.randn(C, generator=g(3))).requires_grad_(True)
+    dy = q16(torch.randn(M, C, generator=g(4)))
+    F.layer_norm(x, (C,), gm, bt, 1e-5).backward(dy)
+    dgb = torch.zeros(2 * C, dtype=torch.float32, device="cuda")
+    dx = T.layernorm_bwd(engine, h(x.detach()), h(gm.detach()), h(dy), dgb)
+    assert_close(dx, x.grad, what="layernorm dx")
+    assert_close(dgb[:C], gm.grad, what="layernorm dgamma")
+    assert_close(dgb[C:], bt.grad, what="layernorm dbeta")
+
+
+@pytest.mark.parametrize("act,concat", [(1, False), (0, False), (1, True)])
+def test_groupnorm_backward(engine, act, concat):
+    B, C1, C2, H = 2, 64, (128 if concat else 0), 12
+    x1 = q16(torch.randn(B, C1, H, H, generator=g(1)) * 2 + 0.3).requires_grad_(True)
+    x2 = q16(torch.randn(B, C2, H, H, generator=g(2))).requires_grad_(True) if concat else None
+    C = C1 + C2
+    gm = q16(1 + 0.1 * torch.randn(C, generator=g(3))).requires_grad_(True)
+    bt = q16(0.1 * torch.randn(C, generator=g(4))).requires_grad_(True)
+    xin = torch.cat([x1, x2], 1) if concat else x1
+    y = F.group_norm(xin, 32, gm, bt, 1e-5)
+    y = F.silu(y) if act else y
+    dy = q16(torch.randn(y.shape, generator=g(5)))
+    y.backward(dy)
+    out, saved = T.groupnorm_fwd_train(engine, h(nhwc(x1.detach())), h(gm.detach()), h(bt.detach()), 32, 1e-5, act,
+                                       x2=h(nhwc(x2.detach())) if concat else None)
+    assert_close(out, nhwc(y.detach()), what="groupnorm fwd (train)")
+    dgb = torch.zeros(2 * C, dtype=torch.float32, device="cuda")
+    dx1, dx2 = T.groupnorm_bwd(engine, saved, h(nhwc(dy)), dgamma=dgb)
+    assert_close(dx1, nhwc(x1.grad), rel=2e-3, what="groupnorm dx")
+    if concat:
+        assert_close(dx2, nhwc(x2.grad), rel=2e-3, what="groupnorm dx2")
+    assert_close(dgb[:C], gm.grad, rel=2e-3, what="groupnorm dgamma")
+    assert_close(dgb[C:], bt.grad, rel=2e-3, what="groupnorm dbeta")
+
+
+# ---------------------------------------------------------------------------------------------------- loss + optimizer
+def test_mse_adamw_clip(engine):
+    pred = q16(torch.randn(2, 8, 8, 8, generator=g(1)))
+    tgt = q16(torch.randn(2, 8, 8, 4, generator=g(2)))
+    p = pred[..., :4].clone().requires_grad_(True)
+    loss_ref = F.mse_loss(p, tgt)
+    loss_ref.backward()
+    loss, dpred = T.mse_loss(engine, h(pred), h(tgt), 4)
+    assert abs(float(loss.cpu()) - float(loss_ref)) < 1e-5 * max(1, float(loss_ref))
+    assert_close(dpred[..., :4], p.grad, what="mse grad")
+    assert float(dpred[..., 4:].abs().max()) == 0.0
+    # AdamW, 3 steps, with global-norm clipping computed on the device
+    n = 5000
+    w = torch.randn(n, generator=g(3)).requires_grad_(True)
+    opt = torch.optim.AdamW([w], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    wd = w.detach().clone().cuda()
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ss, clip = torch.zeros(1, device="cuda"), torch.zeros(2, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(n, generator=g(10 + step)) * 3
+        w.grad = gr.clone()
+        norm = torch.nn.utils.clip_grad_norm_([w], 1.0)
+        opt.step()
+        gd = gr.cuda()
+        T.sumsq(engine, gd, ss)
+        T.clip_coef(engine, ss, clip, 1.0)
+        assert abs(float(clip[1].cpu()) - float(norm)) < 1e-3 * float(norm)
+        T.adamw(engine, wd, gd, m, v, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step, clip)
+    assert rel_l2(wd.cpu(), w.detach()) < 1e-5
+    out16 = torch.empty(n, dtype=torch.float16, device="cuda")
+    T.cast_f32_f16(engine, wd, out16)
+    assert torch.equal(out16.cpu(), wd.cpu().half())
