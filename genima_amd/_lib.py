@@ -92,6 +92,7 @@ SIGNATURES = {
     "gn_act": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_softmax_rows": (_I32, [_P, _P, _I64, _I32, _I32, _F]),
+    "gn_softmax_rows_masked": (_I32, [_P, _P, _I64, _I32, _I32, _F, _I32]),
     "gn_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_transpose2d": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
     "gn_im2col_t": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
@@ -99,8 +100,8 @@ SIGNATURES = {
     "gn_colsum_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I64, _P, _I32]),
     "gn_reduce_rows_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_act_bwd": (_I32, [_P, _P, _P, _P, _I64, _I32]),
-    "gn_geglu_fwd": (_I32, [_P, _P, _P, _I64, _I32]),
-    "gn_geglu_bwd": (_I32, [_P, _P, _P, _P, _I64, _I32]),
+    "gn_geglu_fwd": (_I32, [_P, _P, _P, _I64, _I32, _I32]),
+    "gn_geglu_bwd": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32]),
     "gn_softmax_bwd": (_I32, [_P, _P, _P, _I64, _I32, _I64, _F]),
     "gn_layernorm_bwd_workspace_bytes": (_I64, [_I64, _I32]),
     "gn_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F]),
@@ -110,7 +111,7 @@ SIGNATURES = {
     "gn_sumpool2x2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_mse_loss": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F]),
     "gn_sumsq_f32": (_I32, [_P, _P, _I64, _P, _P]),
-    "gn_clip_coef": (_I32, [_P, _P, _P, _F]),
+    "gn_clip_coef": (_I32, [_P, _P, _P, _F, _F]),
     "gn_adamw_flat": (_I32, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _P, _F]),
     "gn_cast_f32_f16": (_I32, [_P, _P, _P, _I64]),
     "gn_fill_f32": (_I32, [_P, _P, _I64, _F]),

@@ -109,23 +109,35 @@ __global__ void act_bwd_kernel(const uint4* __restrict__ dy, const uint4* __rest
   dz[i] = *reinterpret_cast<uint4*>(&o);
 }
 
-// ---- GEGLU (unfused form used in training): out = hidden * gelu(gate), hg = [hidden | gate] ---------------------------------------
-__global__ void geglu_fwd_kernel(const f16* __restrict__ hg, f16* __restrict__ out, long M, int Hd) {
+// ---- GEGLU (unfused form used in training): out = hidden * gelu(gate) -------------------------------------------------------------
+// blk == 0: hg = [hidden | gate] halves;  blk > 0: alternating blk-column blocks [hidden | gate] (the packed ff.net.0.proj layout of
+// the fused GN_ACT_GEGLU GEMM, packing.pack_geglu), so the training path shares the inference weight layout.
+__device__ __forceinline__ long geglu_hidden_col(int j, int Hd, int blk, int* gate_off) {
+  if (blk > 0) {
+    *gate_off = blk;
+    return (long)(j / blk) * 2 * blk + (j % blk);
+  }
+  *gate_off = Hd;
+  return j;
+}
+__global__ void geglu_fwd_kernel(const f16* __restrict__ hg, f16* __restrict__ out, long M, int Hd, int blk) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * Hd) return;
   const long m = idx / Hd;
-  const int j = (int)(idx - m * Hd);
-  const float h = (float)hg[m * 2 * Hd + j], g = (float)hg[m * 2 * Hd + Hd + j];
+  int go;
+  const long hc = m * 2 * Hd + geglu_hidden_col((int)(idx - m * Hd), Hd, blk, &go);
+  const float h = (float)hg[hc], g = (float)hg[hc + go];
   out[idx] = (f16)(h * act_gelu(g));
 }
-__global__ void geglu_bwd_kernel(const f16* __restrict__ dy, const f16* __restrict__ hg, f16* __restrict__ dhg, long M, int Hd) {
+__global__ void geglu_bwd_kernel(const f16* __restrict__ dy, const f16* __restrict__ hg, f16* __restrict__ dhg, long M, int Hd, int blk) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * Hd) return;
   const long m = idx / Hd;
-  const int j = (int)(idx - m * Hd);
-  const float h = (float)hg[m * 2 * Hd + j], g = (float)hg[m * 2 * Hd + Hd + j], d = (float)dy[idx];
-  dhg[m * 2 * Hd + j] = (f16)(d * act_gelu(g));
-  dhg[m * 2 * Hd + Hd + j] = (f16)(d * h * act_grad(g, GN_ACT_GELU));
+  int go;
+  const long hc = m * 2 * Hd + geglu_hidden_col((int)(idx - m * Hd), Hd, blk, &go);
+  const float h = (float)hg[hc], g = (float)hg[hc + go], d = (float)dy[idx];
+  dhg[hc] = (f16)(d * act_gelu(g));
+  dhg[hc + go] = (f16)(d * h * act_grad(g, GN_ACT_GELU));
 }
 
 // ---- softmax backward (attention): ds = scale * p * (dp - sum_j p*dp), in place over dp ----------------------------------------
@@ -428,6 +440,7 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   // gscale_dev (optional, device scalar): the global-norm clip coefficient computed on the device (no host sync).
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (gscale_dev && gscale_dev[2] != 0.0f) return;  // non-finite gradients: skip the step (torch.cuda.amp.GradScaler.step)
   const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.0f);
   const float gi = g[i] * gs;
   float pi = p[i] * (1.0f - lr * wd);
@@ -438,12 +451,15 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
   p[i] = pi - (lr / bc1) * (mi / denom);
 }
-__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float* __restrict__ out, float max_norm) {
-  // out[0] = min(1, max_norm / (norm + 1e-6)), out[1] = norm   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* __restrict__ sumsq, float* __restrict__ out, float max_norm, float inv_scale) {
+  // out[0] = min(1, max_norm / (norm + 1e-6)), out[1] = norm of the unscaled gradients (torch.nn.utils.clip_grad_norm_ after
+  // GradScaler.unscale_), out[2] = 1 when the gradients hold inf/nan (the optimizer step is then skipped).
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    const float norm = sqrtf(sumsq[0]);
+    const float norm = sqrtf(sumsq[0]) * inv_scale;
+    const bool bad = !(norm == norm) || norm > 3.0e38f;
     out[1] = norm;
-    out[0] = fminf(1.0f, max_norm / (norm + 1e-6f));
+    out[2] = bad ? 1.0f : 0.0f;
+    out[0] = bad ? 0.0f : fminf(1.0f, max_norm / (norm + 1e-6f));
   }
 }
 __global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ out, long n) {
@@ -510,15 +526,15 @@ int32_t gn_act_bwd(gn_ctx* ctx, const void* dy, const void* z, void* dz, int64_t
   return GN_OK;
 }
 
-int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd) {
-  GN_REQUIRE(ctx && hg && out && M > 0 && Hd > 0, "gn_geglu_fwd: bad arguments");
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)hg, (f16*)out, (long)M, Hd);
+int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd, int32_t block) {
+  GN_REQUIRE(ctx && hg && out && M > 0 && Hd > 0 && block >= 0 && (block == 0 || Hd % block == 0), "gn_geglu_fwd: bad arguments");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)hg, (f16*)out, (long)M, Hd, block);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
-int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd) {
-  GN_REQUIRE(ctx && dy && hg && dhg && M > 0 && Hd > 0, "gn_geglu_bwd: bad arguments");
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)dy, (const f16*)hg, (f16*)dhg, (long)M, Hd);
+int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd, int32_t block) {
+  GN_REQUIRE(ctx && dy && hg && dhg && M > 0 && Hd > 0 && block >= 0 && (block == 0 || Hd % block == 0), "gn_geglu_bwd: bad arguments");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)dy, (const f16*)hg, (f16*)dhg, (long)M, Hd, block);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
@@ -621,10 +637,10 @@ int32_t gn_sumsq_f32(gn_ctx* ctx, const float* x, int64_t n, float* out, void* w
   return GN_OK;
 }
 
-/* clip[0] = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)), clip[1] = the norm */
-int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm) {
-  GN_REQUIRE(ctx && sumsq && clip && max_norm > 0.f, "gn_clip_coef: bad arguments");
-  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, sumsq, clip, max_norm);
+/* norm = sqrt(sumsq[0]) * inv_scale;  clip[0] = min(1, max_norm / (norm + 1e-6)), clip[1] = norm, clip[2] = 1 if non-finite */
+int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm, float inv_scale) {
+  GN_REQUIRE(ctx && sumsq && clip && max_norm > 0.f && inv_scale > 0.f, "gn_clip_coef: bad arguments");
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(64), 0, ctx->stream, sumsq, clip, max_norm, inv_scale);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -164,7 +164,8 @@ __global__ void embedding_kernel(const int32_t* __restrict__ ids, const f16* __r
 }
 
 constexpr int SM_MAXCH = 8;  // cols <= 4096
-__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ x, long rows, int cols, int ld, float scale) {
+// columns >= valid (key padding up to the 8-column granule) take no probability mass and are written as zeros
+__global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ x, long rows, int cols, int ld, float scale, int valid) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -179,7 +180,10 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(f16* __restrict__ x, 
       const uint4 raw = *reinterpret_cast<const uint4*>(xr + cx * 8);
       const f16x8 h = *reinterpret_cast<const f16x8*>(&raw);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { v[i][e] = (float)h[e] * scale; mx = fmaxf(mx, v[i][e]); }
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (cx * 8 + e < valid) ? (float)h[e] * scale : -INFINITY;
+        mx = fmaxf(mx, v[i][e]);
+      }
     }
   }
   mx = wave_max(mx);
@@ -342,7 +346,15 @@ int32_t gn_embedding(gn_ctx* ctx, const int32_t* ids, const void* tok, const voi
 
 int32_t gn_softmax_rows(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale) {
   GN_REQUIRE(ctx && x && rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_MAXCH && ld % 8 == 0 && ld >= cols, "gn_softmax_rows: cols must be a multiple of 8, <= %d", 64 * 8 * SM_MAXCH);
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, ctx->stream, (f16*)x, (long)rows, cols, ld, scale);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, ctx->stream, (f16*)x, (long)rows, cols, ld, scale, cols);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_softmax_rows_masked(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale, int32_t valid) {
+  GN_REQUIRE(ctx && x && rows > 0 && cols > 0 && cols % 8 == 0 && cols <= 64 * 8 * SM_MAXCH && ld % 8 == 0 && ld >= cols && valid > 0 && valid <= cols,
+             "gn_softmax_rows_masked: cols must be a multiple of 8, <= %d, 0 < valid <= cols", 64 * 8 * SM_MAXCH);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(nblk(rows, 4)), dim3(256), 0, ctx->stream, (f16*)x, (long)rows, cols, ld, scale, valid);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

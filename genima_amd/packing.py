@@ -21,23 +21,23 @@ def _rup(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
 
-def pack_conv_weight(w: torch.Tensor, cin_splits=None) -> torch.Tensor:
+def pack_conv_weight(w: torch.Tensor, cin_splits=None, dtype=torch.float16) -> torch.Tensor:
     """OIHW fp32 -> [Cout_pad8, KH*KW*Cin_pad8] f16.  ``cin_splits=(C1, C2)`` keeps a virtual-concat boundary (each part
     must already be a multiple of 8)."""
     O, I, KH, KW = w.shape
     Ip, Op = _rup(I, 8), _rup(O, 8)
     p = torch.zeros((Op, KH, KW, Ip), dtype=torch.float32, device=w.device)
     p[:O, :, :, :I] = w.permute(0, 2, 3, 1)
-    return p.reshape(Op, KH * KW * Ip).to(torch.float16).contiguous()
+    return p.reshape(Op, KH * KW * Ip).to(dtype).contiguous()
 
 
-def pack_vec(b: torch.Tensor, n_pad: int) -> torch.Tensor:
+def pack_vec(b: torch.Tensor, n_pad: int, dtype=torch.float16) -> torch.Tensor:
     out = torch.zeros((n_pad,), dtype=torch.float32, device=b.device)
     out[: b.numel()] = b
-    return out.to(torch.float16).contiguous()
+    return out.to(dtype).contiguous()
 
 
-def pack_geglu(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def pack_geglu(w: torch.Tensor, b: torch.Tensor, dtype=torch.float16) -> Tuple[torch.Tensor, torch.Tensor]:
     n2 = w.shape[0]
     half = n2 // 2
     assert half % 32 == 0
@@ -45,24 +45,25 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Te
     wp = torch.stack([wh, wg], dim=1).reshape(n2, -1)
     bh, bg = b[:half].reshape(half // 32, 32), b[half:].reshape(half // 32, 32)
     bp = torch.stack([bh, bg], dim=1).reshape(n2)
-    return wp.to(torch.float16).contiguous(), bp.to(torch.float16).contiguous()
+    return wp.to(dtype).contiguous(), bp.to(dtype).contiguous()
 
 
-def pack_state_dict(sd: Dict[str, torch.Tensor], device) -> "OrderedDict[str, torch.Tensor]":
-    """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries)."""
+def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
+    """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries).
+    ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams)."""
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     temb_w, temb_b, temb_slices, off = [], [], OrderedDict(), 0
     for name, t in sd.items():
         t = t.detach().to(torch.float32)
         if t.dim() == 4:
-            out[name] = pack_conv_weight(t)
+            out[name] = pack_conv_weight(t, dtype=dtype)
             bn = name[: -len("weight")] + "bias"
             if bn in sd:
-                out[bn] = pack_vec(sd[bn].detach().float(), out[name].shape[0])
+                out[bn] = pack_vec(sd[bn].detach().float(), out[name].shape[0], dtype=dtype)
         elif t.dim() == 2:
             if name.endswith("ff.net.0.proj.weight"):
                 bn = name[: -len("weight")] + "bias"
-                wp, bp = pack_geglu(t, sd[bn].detach().float())
+                wp, bp = pack_geglu(t, sd[bn].detach().float(), dtype=dtype)
                 out[name], out[bn] = wp, bp
                 continue
             if name.endswith("time_emb_proj.weight"):
@@ -75,26 +76,26 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device) -> "OrderedDict[str, to
                 tp = torch.zeros((t.shape[0], _rup(t.shape[1], 8)), device=t.device)
                 tp[:, : t.shape[1]] = t
                 t = tp
-            out[name] = t.to(torch.float16).contiguous()
+            out[name] = t.to(dtype).contiguous()
         elif t.dim() == 1:
             if name not in out:  # conv / geglu biases were handled with their weights
-                out[name] = t.to(torch.float16).contiguous()
+                out[name] = t.to(dtype).contiguous()
         else:
-            out[name] = t.to(torch.float16).contiguous()
+            out[name] = t.to(dtype).contiguous()
     # fused self-attention q|k projections
     for name in list(sd.keys()):
         for qn, kn, fused in ((".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_qk.weight"),
                               (".self_attn.q_proj.weight", ".self_attn.k_proj.weight", ".self_attn.qk_proj.weight")):
             if name.endswith(qn):
                 base = name[: -len(qn)]
-                out[base + fused] = torch.cat([sd[name], sd[base + kn]], dim=0).to(torch.float16).contiguous()
+                out[base + fused] = torch.cat([sd[name], sd[base + kn]], dim=0).to(dtype).contiguous()
                 qb, kb = name[: -len("weight")] + "bias", (base + kn)[: -len("weight")] + "bias"
                 if qb in sd:
-                    out[(base + fused)[: -len("weight")] + "bias"] = torch.cat([sd[qb], sd[kb]]).to(torch.float16).contiguous()
+                    out[(base + fused)[: -len("weight")] + "bias"] = torch.cat([sd[qb], sd[kb]]).to(dtype).contiguous()
     meta = {}
     if temb_w:
-        out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(torch.float16).contiguous()
-        out["time_emb_proj_all.bias"] = torch.cat(temb_b, dim=0).to(torch.float16).contiguous()
+        out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(dtype).contiguous()
+        out["time_emb_proj_all.bias"] = torch.cat(temb_b, dim=0).to(dtype).contiguous()
         meta["temb_slices"] = temb_slices
         meta["temb_total"] = off
     dev = OrderedDict((k, v.to(device)) for k, v in out.items())

@@ -15,12 +15,18 @@ from .engine import Engine, _ptr
 F16, F32 = torch.float16, torch.float32
 
 
-def gemm(E: Engine, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int, N: int, K: int, lda: int, ldw: int, ldo: int, *,
-         bias=None, residual=None, ldr: int = 0, f32_out: bool = False, accumulate: bool = False, batch: int = 0, batch_inner: int = 1,
-         a_bs=(0, 0), w_bs=(0, 0), out_bs=(0, 0), act: int = 0):
-    """Raw dense GEMM out[m, n] = sum_k a[m*lda + k] * w[n*ldw + k] (+ epilogue), optionally batched / f32 / accumulating."""
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+def gemm(E: Engine, a, w, out, M: int, N: int, K: int, lda: int, ldw: int, ldo: int, *, bias=None, residual=None, ldr: int = 0,
+         f32_out: bool = False, accumulate: bool = False, batch: int = 0, batch_inner: int = 1, a_bs=(0, 0), w_bs=(0, 0), out_bs=(0, 0),
+         act: int = 0, a_off: int = 0, w_off: int = 0, out_off: int = 0):
+    """Raw dense GEMM out[m, n] = sum_k a[m*lda + k] * w[n*ldw + k] (+ epilogue), optionally batched / f32 / accumulating.
+    a_off / w_off / out_off: element offsets added to the base pointers (column slices of wider matrices)."""
     d = GemmDesc()
-    d.a, d.w, d.out, d.bias, d.residual = _ptr(a), _ptr(w), _ptr(out), _ptr(bias), _ptr(residual)
+    d.a, d.w, d.out = a.data_ptr() + 2 * a_off, w.data_ptr() + 2 * w_off, out.data_ptr() + out_off * out.element_size()
+    d.bias, d.residual = _ptr(bias), _ptr(residual)
     d.M, d.N, d.K, d.lda, d.ldw, d.ldo, d.ldr = M, N, K, lda, ldw, ldo, ldr
     d.out_mode = OUT_F32 if f32_out else OUT_ROWMAJOR
     d.accumulate, d.act, d.out_scale = int(accumulate), act, 1.0
@@ -37,12 +43,27 @@ def gemm(E: Engine, a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, M: int,
 
 
 def transpose2d(E: Engine, x: torch.Tensor, rows: int, cols: int, *, ld_in: Optional[int] = None, batch: int = 1, in_bs: int = 0,
-                out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x viewed as [batch][rows, cols] (row stride ld_in) -> [batch][cols, rows] contiguous."""
+                in_off: int = 0, pad_to: int = 8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x viewed as [batch][rows, cols] (row stride ld_in, element offset in_off) -> [batch][cols, rup(rows, pad_to)], zero padded
+    (the pad keeps the transposed matrix usable as a GEMM operand whose reduction length must be a multiple of 8)."""
     ld_in = cols if ld_in is None else ld_in
+    ld_out = _rup(rows, pad_to)
     if out is None:
-        out = torch.empty((batch, cols, rows) if batch > 1 else (cols, rows), dtype=F16, device=E.device)
-    check(E.lib.gn_transpose2d(E._ctx, _ptr(x), _ptr(out), rows, cols, ld_in, rows, batch, in_bs, cols * rows), "gn_transpose2d")
+        shape = (batch, cols, ld_out) if batch > 1 else (cols, ld_out)
+        out = (torch.zeros if ld_out != rows else torch.empty)(shape, dtype=F16, device=E.device)
+    check(E.lib.gn_transpose2d(E._ctx, x.data_ptr() + 2 * in_off, _ptr(out), rows, cols, ld_in, ld_out, batch, in_bs, cols * ld_out), "gn_transpose2d")
+    return out
+
+
+def conv_weight_dgrad(E: Engine, w: torch.Tensor, taps: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Packed conv weight [Cout, taps*Cin] -> the data-gradient conv's weight [Cin, taps*Cout]: in/out channels swapped and the
+    taps rotated by 180 degrees (out[ci][taps-1-t][co] = w[co][t][ci]); one batched tile transpose, batch = taps."""
+    Cout, K = w.shape
+    Cin = K // taps
+    if out is None:
+        out = torch.empty((Cin, taps * Cout), dtype=F16, device=E.device)
+    check(E.lib.gn_transpose2d(E._ctx, _ptr(w), out.data_ptr() + 2 * (taps - 1) * Cout, Cout, Cin, taps * Cin, taps * Cout, taps, Cin, -Cout),
+          "gn_transpose2d(conv weight)")
     return out
 
 
@@ -66,18 +87,24 @@ def act_bwd(E: Engine, dy: torch.Tensor, z: torch.Tensor, act: int) -> torch.Ten
     return dz
 
 
-def geglu_fwd(E: Engine, hg: torch.Tensor) -> torch.Tensor:
+def geglu_fwd(E: Engine, hg: torch.Tensor, block: int = 0) -> torch.Tensor:
     Hd = hg.shape[-1] // 2
     out = torch.empty(tuple(hg.shape[:-1]) + (Hd,), dtype=F16, device=E.device)
-    check(E.lib.gn_geglu_fwd(E._ctx, _ptr(hg), _ptr(out), hg.numel() // (2 * Hd), Hd), "gn_geglu_fwd")
+    check(E.lib.gn_geglu_fwd(E._ctx, _ptr(hg), _ptr(out), hg.numel() // (2 * Hd), Hd, block), "gn_geglu_fwd")
     return out
 
 
-def geglu_bwd(E: Engine, dy: torch.Tensor, hg: torch.Tensor) -> torch.Tensor:
+def geglu_bwd(E: Engine, dy: torch.Tensor, hg: torch.Tensor, block: int = 0) -> torch.Tensor:
     Hd = hg.shape[-1] // 2
     dhg = torch.empty_like(hg)
-    check(E.lib.gn_geglu_bwd(E._ctx, _ptr(dy), _ptr(hg), _ptr(dhg), hg.numel() // (2 * Hd), Hd), "gn_geglu_bwd")
+    check(E.lib.gn_geglu_bwd(E._ctx, _ptr(dy), _ptr(hg), _ptr(dhg), hg.numel() // (2 * Hd), Hd, block), "gn_geglu_bwd")
     return dhg
+
+
+def softmax_rows_masked(E: Engine, s: torch.Tensor, scale: float, valid: int):
+    cols = s.shape[-1]
+    check(E.lib.gn_softmax_rows_masked(E._ctx, _ptr(s), s.numel() // cols, cols, cols, float(scale), valid), "gn_softmax_rows_masked")
+    return s
 
 
 def softmax_bwd(E: Engine, p: torch.Tensor, dp: torch.Tensor, scale: float):
@@ -86,15 +113,14 @@ def softmax_bwd(E: Engine, p: torch.Tensor, dp: torch.Tensor, scale: float):
     return dp
 
 
-def layernorm_bwd(E: Engine, x, gamma, dy, dgamma: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
-    """dgamma: f32 view of [2*C] = (dgamma | dbeta) inside the flat gradient buffer (accumulated), or None."""
+def layernorm_bwd(E: Engine, x, gamma, dy, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
+                  eps: float = 1e-5) -> torch.Tensor:
+    """dgamma / dbeta: f32 [C] views inside the flat gradient buffer (accumulated), or None."""
     Cc = x.shape[-1]
     M = x.numel() // Cc
     dx = torch.empty_like(x)
     ws = E._workspace(int(E.lib.gn_layernorm_bwd_workspace_bytes(M, Cc))) if dgamma is not None else None
-    dg = _ptr(dgamma)
-    db = None if dgamma is None else dgamma.data_ptr() + 4 * Cc
-    check(E.lib.gn_layernorm_bwd(E._ctx, _ptr(x), _ptr(gamma), _ptr(dy), _ptr(dx), dg, db, _ptr(ws), M, Cc, eps), "gn_layernorm_bwd")
+    check(E.lib.gn_layernorm_bwd(E._ctx, _ptr(x), _ptr(gamma), _ptr(dy), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), M, Cc, eps), "gn_layernorm_bwd")
     return dx
 
 
@@ -121,16 +147,16 @@ def groupnorm_fwd_train(E: Engine, x, gamma, beta, groups: int, eps: float, act:
     return out, s
 
 
-def groupnorm_bwd(E: Engine, s: GNSaved, dy, need_dx2: bool = True, dgamma: Optional[torch.Tensor] = None):
-    """-> (dx, dx2).  dgamma: f32 view [2*C] = (dgamma | dbeta), accumulated, or None."""
+def groupnorm_bwd(E: Engine, s: GNSaved, dy, need_dx: bool = True, need_dx2: bool = True, dgamma: Optional[torch.Tensor] = None,
+                  dbeta: Optional[torch.Tensor] = None):
+    """-> (dx, dx2).  dgamma / dbeta: f32 [C] views (accumulated), or None."""
     d = s.desc
-    dx = torch.empty_like(s.x)
+    dx = torch.empty_like(s.x) if need_dx else None
     dx2 = torch.empty_like(s.x2) if (s.x2 is not None and need_dx2) else None
     Cc = d.C1 + d.C2
     ws = E._workspace(int(E.lib.gn_groupnorm_bwd_workspace_bytes(d.B, d.HW, Cc)))
-    dg = _ptr(dgamma)
-    db = None if dgamma is None else dgamma.data_ptr() + 4 * Cc
-    check(E.lib.gn_groupnorm_bwd(E._ctx, C.byref(d), _ptr(dy), _ptr(dx), _ptr(dx2), _ptr(s.scsh), _ptr(s.stats), dg, db, _ptr(ws)), "gn_groupnorm_bwd")
+    check(E.lib.gn_groupnorm_bwd(E._ctx, C.byref(d), _ptr(dy), _ptr(dx), _ptr(dx2), _ptr(s.scsh), _ptr(s.stats), _ptr(dgamma), _ptr(dbeta), _ptr(ws)),
+          "gn_groupnorm_bwd")
     return dx, dx2
 
 
@@ -149,7 +175,8 @@ def sumpool2x2(E: Engine, x: torch.Tensor) -> torch.Tensor:
 
 
 def mse_loss(E: Engine, pred: torch.Tensor, target: torch.Tensor, C_valid: int, grad_scale: float = 1.0):
-    """pred [..., ldp] (first C_valid channels valid), target [..., ldt] -> (loss f32 [1] device tensor, dpred like pred)."""
+    """pred [..., ldp] (first C_valid channels valid), target [..., ldt] -> (loss f32 [1] device tensor, dpred like pred).
+    dpred = grad_scale * d(mean squared error)/dpred (grad_scale = the loss scale)."""
     ldp, ldt = pred.shape[-1], target.shape[-1]
     pixels = pred.numel() // ldp
     dpred = torch.empty_like(pred)
@@ -165,8 +192,9 @@ def sumsq(E: Engine, x: torch.Tensor, out: torch.Tensor):
     return out
 
 
-def clip_coef(E: Engine, sumsq_t: torch.Tensor, clip: torch.Tensor, max_norm: float):
-    check(E.lib.gn_clip_coef(E._ctx, _ptr(sumsq_t), _ptr(clip), float(max_norm)), "gn_clip_coef")
+def clip_coef(E: Engine, sumsq_t: torch.Tensor, clip: torch.Tensor, max_norm: float, inv_scale: float = 1.0):
+    """clip: f32 [3] = (coefficient, unscaled norm, found_inf)."""
+    check(E.lib.gn_clip_coef(E._ctx, _ptr(sumsq_t), _ptr(clip), float(max_norm), float(inv_scale)), "gn_clip_coef")
     return clip
 
 

@@ -1,0 +1,564 @@
+"""ControlNet fine-tune step on libgenima_hip.so: forward with saved activations, hand-scheduled backward, global-norm clip, AdamW.
+
+Replaces the train-step body of the reference (diffusion/train_controlnet_genima.py:1317-1408):
+
+    noisy = add_noise(latents, noise, t)                                   (:1359)
+    down, mid = controlnet(noisy, t, ctx, cond)      trainable, fp32 master weights, fp16 compute      (:1368-1374)
+    pred = unet(noisy, t, ctx, down, mid)            frozen fp16                                        (:1377-1388)
+    loss = mse(pred.float(), noise.float())                                                            (:1400)
+    backward; clip_grad_norm_(1.0); AdamW; zero_grad                                                   (:1402-1408)
+
+Design (MI355X-first, not an autograd port):
+  * Every backward matrix product is the forward MFMA GEMM kernel (gn_gemm) on re-laid-out operands: dX = dY.W through a
+    transposed / tap-rotated weight copy made once per optimizer step, dW = dY^T.X in f32 straight into the flat gradient buffer
+    (split-K over the pixel dimension), conv wgrad over gn_im2col_t's matrix.  Attention backward recomputes P from the saved
+    q/k with batched GEMMs around the row-softmax kernels.
+  * The frozen UNet encoder + mid block run through the fused inference lowering (graphs.py); only its decoder keeps activations,
+    and only data gradients are propagated through it (no dW for frozen weights).
+  * Parameters live in ONE flat fp32 master buffer in the packed kernel layout, with flat fp32 grad / Adam-moment buffers beside it
+    and one flat f16 working copy: the optimizer, the clip norm and the data-parallel all-reduce (dist.allreduce_mean_flat, RCCL)
+    each touch one contiguous 1.46 GB range instead of ~700 tensors.
+  * Gradients of activations are f16 with a loss scale (the reference's GradScaler under accelerate mixed_precision="fp16"); the
+    scale is removed inside the AdamW kernel, non-finite steps are skipped on the device and the scale adapted on the host.
+The tape below is a plain list of closures in forward order -- there is no graph tracing; each op pushes its own backward.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import graphs
+from . import train_ops as T
+from ._lib import ACT_NONE, ACT_SILU
+from .engine import Engine
+from .packing import pack_state_dict
+
+F16, F32 = torch.float16, torch.float32
+_DUP_SUFFIXES = (".attn1.to_q.weight", ".attn1.to_k.weight", ".time_emb_proj.weight", ".time_emb_proj.bias")
+CTX_PAD = 8  # prompt-token rows are zero-padded to a multiple of this (GEMM reduction granule)
+
+
+def _rup(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# =============================================================================================================== parameters
+class FrozenParams:
+    """Packed f16 weights of a frozen network plus lazily built transposed / rotated copies for data gradients."""
+
+    def __init__(self, E: Engine, W):
+        self.E, self.W, self.G = E, W, None
+        self._wt: Dict[Tuple[str, int], torch.Tensor] = {}
+
+    def wt(self, name: str, taps: int = 0) -> torch.Tensor:
+        """taps == 0: Linear / 1x1 weight [N, K] -> [K, N];  taps == 9: packed 3x3 weight -> data-gradient conv weight."""
+        key = (name, taps)
+        t = self._wt.get(key)
+        if t is None:
+            w = self.W[name]
+            t = T.conv_weight_dgrad(self.E, w, taps) if taps > 1 else T.transpose2d(self.E, w, w.shape[0], w.shape[1])
+            self._wt[key] = t
+        return t
+
+
+class TrainParams(FrozenParams):
+    """Flat fp32 master / gradient / Adam-moment buffers + flat f16 working copy of one trainable network (packed layout)."""
+
+    def __init__(self, E: Engine, state_dict: Dict[str, torch.Tensor]):
+        packed = pack_state_dict(state_dict, E.device, dtype=F32)
+        meta = packed.pop("__meta__")
+        self.layout: "OrderedDict[str, Tuple[int, Tuple[int, ...]]]" = OrderedDict()
+        off = 0
+        for name, t in packed.items():
+            if name.endswith(_DUP_SUFFIXES):
+                continue  # covered by attn1.to_qk / time_emb_proj_all
+            self.layout[name] = (off, tuple(t.shape))
+            off += _rup(t.numel(), 8)
+        self.numel = off
+        dev = E.device
+        self.master = torch.zeros(off, dtype=F32, device=dev)
+        self.grad = torch.zeros(off, dtype=F32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=F32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=F32, device=dev)
+        self.half = torch.zeros(off, dtype=F16, device=dev)
+        W, G = OrderedDict(), OrderedDict()
+        for name, (o, shape) in self.layout.items():
+            n = 1
+            for s in shape:
+                n *= s
+            self.master[o:o + n].view(shape).copy_(packed[name])
+            W[name] = self.half[o:o + n].view(shape)
+            G[name] = self.grad[o:o + n].view(shape)
+        W["__meta__"] = meta
+        super().__init__(E, W)
+        self.G = G
+        self.temb_slices = meta.get("temb_slices", {})
+        self.sync_half()
+
+    def sync_half(self):
+        """Refresh the f16 working copy from the fp32 master (after an optimizer step) and drop the derived weight copies."""
+        T.cast_f32_f16(self.E, self.master, self.half)
+        self._wt.clear()
+
+    def zero_grad(self):
+        T.fill_f32(self.E, self.grad, 0.0)
+
+    def packed_master(self) -> "OrderedDict[str, torch.Tensor]":
+        out = OrderedDict()
+        for name, (o, shape) in self.layout.items():
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = self.master[o:o + n].view(shape)
+        return out
+
+
+# =============================================================================================================== the tape
+class Var:
+    """A forward activation with a slot for its (f16, loss-scaled) gradient; views share the slot."""
+    __slots__ = ("t", "cell", "needs")
+
+    def __init__(self, t: torch.Tensor, needs: bool = True, cell=None):
+        self.t, self.needs, self.cell = t, needs, ([None] if cell is None else cell)
+
+    def view(self, *shape) -> "Var":
+        return Var(self.t.view(*shape), self.needs, self.cell)
+
+    @property
+    def grad(self) -> Optional[torch.Tensor]:
+        g = self.cell[0]
+        return None if g is None else g.view(self.t.shape)
+
+
+class Graph:
+    def __init__(self, E: Engine):
+        self.E = E
+        self.tape: List = []
+
+    # ---- gradient plumbing
+    def acc(self, v: Optional[Var], g: torch.Tensor):
+        if v is None or not v.needs:
+            return
+        cur = v.cell[0]
+        v.cell[0] = g if cur is None else self.E.add(cur, g.view(cur.shape))
+
+    def backward(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape.clear()
+
+    def _push(self, out: Var, fn):
+        def run():
+            dy = out.grad
+            if dy is not None:
+                fn(dy)
+                out.cell[0] = None  # consumed
+        self.tape.append(run)
+        return out
+
+    # ---- elementwise
+    def add(self, a: Var, b: Var) -> Var:
+        out = Var(self.E.add(a.t, b.t), a.needs or b.needs)
+
+        def bw(dy):
+            self.acc(a, dy)
+            self.acc(b, dy)
+        return self._push(out, bw)
+
+    def act(self, x: Var, kind: int) -> Var:
+        out = Var(self.E.act(x.t, kind), x.needs)
+        return self._push(out, lambda dy: self.acc(x, T.act_bwd(self.E, dy, x.t, kind)))
+
+    def geglu(self, hg: Var) -> Var:
+        out = Var(T.geglu_fwd(self.E, hg.t, 32), hg.needs)
+        return self._push(out, lambda dy: self.acc(hg, T.geglu_bwd(self.E, dy, hg.t, 32)))
+
+    # ---- Linear
+    def linear(self, net: FrozenParams, x: Var, wn: str, bn: Optional[str] = None, residual: Optional[Var] = None) -> Var:
+        E, W = self.E, net.W
+        w = W[wn]
+        N, K = w.shape
+        assert x.t.shape[-1] == K and x.t.is_contiguous(), (wn, x.t.shape, w.shape)
+        y = E.linear(x.t, w, W[bn] if bn else None, residual=residual.t if residual is not None else None)
+        out = Var(y, x.needs or net.G is not None or (residual is not None and residual.needs))
+
+        def bw(dy):
+            M = x.t.numel() // K
+            dy2 = dy.view(M, N)
+            self.acc(residual, dy)
+            if net.G is not None:
+                dyt = T.transpose2d(E, dy2, M, N)
+                xt = T.transpose2d(E, x.t.view(M, K), M, K)
+                Mp = dyt.shape[1]
+                T.gemm(E, dyt, xt, net.G[wn], N, K, Mp, Mp, Mp, K, f32_out=True, accumulate=True)
+                if bn:
+                    T.colsum(E, dy2, net.G[bn], 1, M, N, N)
+            if x.needs:
+                self.acc(x, E.linear(dy2, net.wt(wn)).view(x.t.shape))
+        return self._push(out, bw)
+
+    # ---- Conv2d (NHWC implicit GEMM), optional virtual concat / time shift / residual / fused nearest-2x upsample
+    def conv(self, net: FrozenParams, x: Var, wn: str, bn: str, *, ksize: int = 3, stride: int = 1, x2: Optional[Var] = None,
+             shift=None, residual: Optional[Var] = None, upsample2x: bool = False) -> Var:
+        """shift: (shifts [B, total] tensor or Var, resnet prefix) -- the per-batch time-embedding channel shift."""
+        E, W = self.E, net.W
+        w = W[wn]
+        sh, ld, sh_var, prefix = None, 0, None, None
+        if shift is not None:
+            sh_src, prefix = shift
+            sh_var = sh_src if isinstance(sh_src, Var) else None
+            full = sh_src.t if sh_var is not None else sh_src
+            o, n = W["__meta__"]["temb_slices"][prefix]
+            sh, ld = full[:, o:o + n], full.shape[1]
+        y = E.conv2d(x.t, w, W[bn], ksize=ksize, stride=stride, x2=x2.t if x2 is not None else None, shift=sh, ldshift=ld,
+                     residual=residual.t if residual is not None else None, upsample2x=upsample2x)
+        needs_in = x.needs or (x2 is not None and x2.needs)
+        out = Var(y, needs_in or net.G is not None or (residual is not None and residual.needs))
+        C1 = x.t.shape[-1]
+        C2 = x2.t.shape[-1] if x2 is not None else 0
+
+        def bw(dy):
+            B, Ho, Wo, Cout = dy.shape
+            M = B * Ho * Wo
+            dy2 = dy.view(M, Cout)
+            self.acc(residual, dy)
+            if net.G is not None:
+                assert x2 is None and not upsample2x, "weight gradients of concat / upsample convs are not needed by the ControlNet"
+                assert M % 8 == 0, "conv wgrad needs B*Ho*Wo to be a multiple of 8"
+                if sh_var is not None:
+                    T.colsum(E, dy2, net.dshift[prefix], B, Ho * Wo, Cout, Cout)
+                T.colsum(E, dy2, net.G[bn], 1, M, Cout, Cout)
+                dyt = T.transpose2d(E, dy2, M, Cout)
+                cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)
+                Kw = ksize * ksize * C1
+                T.gemm(E, dyt, cols, net.G[wn], Cout, Kw, M, M, M, Kw, f32_out=True, accumulate=True)
+            if needs_in:
+                parts = ((x, 0, C1),) + (((x2, C1, C1 + C2),) if x2 is not None else ())
+                if ksize == 1:
+                    wt = net.wt(wn)
+                    for src, r0, r1 in parts:
+                        if src.needs:
+                            self.acc(src, E.linear(dy2, wt[r0:r1]).view(src.t.shape))
+                else:
+                    wd = net.wt(wn, ksize * ksize)
+                    src_dy = T.zero_upsample2x(E, dy) if stride == 2 else dy
+                    for src, r0, r1 in parts:
+                        if src.needs:
+                            dxi = E.conv2d(src_dy, wd[r0:r1], None, ksize=ksize)
+                            self.acc(src, T.sumpool2x2(E, dxi) if upsample2x else dxi)
+        return self._push(out, bw)
+
+    # ---- norms
+    def groupnorm(self, net: FrozenParams, x: Var, wn: str, bn: str, groups: int, eps: float, act: int = ACT_NONE,
+                  x2: Optional[Var] = None) -> Var:
+        E, W = self.E, net.W
+        y, saved = T.groupnorm_fwd_train(E, x.t, W[wn], W[bn], groups, eps, act, x2=x2.t if x2 is not None else None)
+        needs_in = x.needs or (x2 is not None and x2.needs)
+        out = Var(y, needs_in or net.G is not None)
+
+        def bw(dy):
+            tr = net.G is not None
+            dx, dx2 = T.groupnorm_bwd(E, saved, dy, need_dx=True, need_dx2=x2 is not None and x2.needs,
+                                      dgamma=net.G[wn] if tr else None, dbeta=net.G[bn] if tr else None)
+            self.acc(x, dx)
+            if x2 is not None:
+                self.acc(x2, dx2)
+        return self._push(out, bw)
+
+    def layernorm(self, net: FrozenParams, x: Var, wn: str, bn: str, eps: float = 1e-5) -> Var:
+        E, W = self.E, net.W
+        out = Var(E.layernorm(x.t, W[wn], W[bn], eps), x.needs or net.G is not None)
+
+        def bw(dy):
+            tr = net.G is not None
+            self.acc(x, T.layernorm_bwd(E, x.t, W[wn], dy, net.G[wn] if tr else None, net.G[bn] if tr else None, eps))
+        return self._push(out, bw)
+
+    # ---- attention: flash forward, materialised batched-GEMM backward (P recomputed from q, k)
+    def attention(self, q: Var, q_off: int, k: Var, k_off: int, v: Var, heads: int, nk_valid: int) -> Var:
+        """q.t [B, N, ldq] (queries = columns q_off..q_off+C), k.t [B, Nkr, ldk] (keys = columns k_off..), v.t [B, Nkr, C]; rows
+        >= nk_valid of k / v are zero padding (Nkr % 8 == 0).  q and k may be the same Var (fused self-attention q|k projection)."""
+        E = self.E
+        B, N, ldq = q.t.shape
+        Nkr, ldk = k.t.shape[1], k.t.shape[2]
+        Cc = v.t.shape[-1]
+        D = Cc // heads
+        assert Nkr % 8 == 0 and N % 8 == 0 and v.t.shape[1] == Nkr
+        vt = T.transpose2d(E, v.t, Nkr, Cc, batch=B, in_bs=Nkr * Cc, pad_to=64).view(B, Cc, -1)
+        o = E.attention(q.t[:, :, q_off:q_off + Cc], k.t[:, :, k_off:k_off + Cc], vt, heads, Nk=nk_valid)
+        out = Var(o, q.needs or k.needs or v.needs)
+
+        def bw(dO):
+            BH, scale = B * heads, float(D) ** -0.5
+            sbs = (heads * N * Nkr, N * Nkr)
+            P = torch.empty((BH, N, Nkr), dtype=F16, device=E.device)
+            T.gemm(E, q.t, k.t, P, N, Nkr, D, ldq, ldk, Nkr, batch=BH, batch_inner=heads, a_bs=(N * ldq, D), w_bs=(Nkr * ldk, D),
+                   out_bs=sbs, a_off=q_off, w_off=k_off)
+            T.softmax_rows_masked(E, P, scale, nk_valid)
+            dS = torch.empty((BH, N, Nkr), dtype=F16, device=E.device)
+            T.gemm(E, dO, v.t, dS, N, Nkr, D, Cc, Cc, Nkr, batch=BH, batch_inner=heads, a_bs=(N * Cc, D), w_bs=(Nkr * Cc, D), out_bs=sbs)
+            T.softmax_bwd(E, P, dS, scale)
+            tbs = (heads * Nkr * N, Nkr * N)
+            if v.needs:
+                PT = T.transpose2d(E, P, N, Nkr, batch=BH, in_bs=N * Nkr)
+                dOT = T.transpose2d(E, dO, N, Cc, batch=B, in_bs=N * Cc)
+                dV = torch.empty((B, Nkr, Cc), dtype=F16, device=E.device)
+                T.gemm(E, PT, dOT, dV, Nkr, D, N, N, N, Cc, batch=BH, batch_inner=heads, a_bs=tbs, w_bs=(Cc * N, D * N), out_bs=(Nkr * Cc, D))
+                self.acc(v, dV)
+                del PT, dOT
+            del P
+            fused = q is k or q.cell is k.cell
+            dq = torch.empty_like(q.t) if q.needs else None
+            dk = dq if fused else (torch.empty_like(k.t) if k.needs else None)
+            if dq is not None:
+                KT = T.transpose2d(E, k.t, Nkr, Cc, ld_in=ldk, batch=B, in_bs=Nkr * ldk, in_off=k_off)
+                T.gemm(E, dS, KT, dq, N, D, Nkr, Nkr, Nkr, ldq, batch=BH, batch_inner=heads, a_bs=sbs, w_bs=(Cc * Nkr, D * Nkr),
+                       out_bs=(N * ldq, D), out_off=q_off)
+            if dk is not None:
+                dST = T.transpose2d(E, dS, N, Nkr, batch=BH, in_bs=N * Nkr)
+                QT = T.transpose2d(E, q.t, N, Cc, ld_in=ldq, batch=B, in_bs=N * ldq, in_off=q_off)
+                T.gemm(E, dST, QT, dk, Nkr, D, N, N, N, ldk, batch=BH, batch_inner=heads, a_bs=tbs, w_bs=(Cc * N, D * N),
+                       out_bs=(Nkr * ldk, D), out_off=k_off)
+            if dq is not None:
+                self.acc(q, dq)
+            if dk is not None and not fused:
+                self.acc(k, dk)
+        return self._push(out, bw)
+
+
+# =============================================================================================================== network blocks
+def _heads(cfg, i):
+    return graphs._heads(cfg, i)
+
+
+def t_resnet(g: Graph, net, p: str, x: Var, x2: Optional[Var], shifts, groups: int, eps: float) -> Var:
+    """ResnetBlock2D with saved activations (graphs.emit_resnet is the fused inference form)."""
+    W = net.W
+    h = g.groupnorm(net, x, p + ".norm1.weight", p + ".norm1.bias", groups, eps, ACT_SILU, x2=x2)
+    has_t = shifts is not None and p in W["__meta__"].get("temb_slices", {})
+    h = g.conv(net, h, p + ".conv1.weight", p + ".conv1.bias", shift=(shifts, p) if has_t else None)
+    h = g.groupnorm(net, h, p + ".norm2.weight", p + ".norm2.bias", groups, eps, ACT_SILU)
+    if (p + ".conv_shortcut.weight") in W:
+        sc = g.conv(net, x, p + ".conv_shortcut.weight", p + ".conv_shortcut.bias", ksize=1, x2=x2)
+    else:
+        assert x2 is None
+        sc = x
+    return g.conv(net, h, p + ".conv2.weight", p + ".conv2.bias", residual=sc)
+
+
+def t_cross_kv(g: Graph, net, ctx: Var, prefixes: Sequence[str]):
+    """K / V projections of the zero-row-padded prompt states for the listed attn2 layers."""
+    return {p: (g.linear(net, ctx, p + ".to_k.weight"), g.linear(net, ctx, p + ".to_v.weight")) for p in prefixes}
+
+
+def _attn2_prefixes(W, under: Sequence[str]) -> List[str]:
+    out = []
+    for name in W:
+        if name.endswith(".attn2.to_k.weight") and name.startswith(tuple(under)):
+            out.append(name[: -len(".to_k.weight")])
+    return out
+
+
+def t_transformer(g: Graph, net, p: str, x: Var, kv, heads: int, groups: int, nk_valid: int) -> Var:
+    W = net.W
+    B, H, Wd, Cc = x.t.shape
+    N = H * Wd
+    h = g.groupnorm(net, x, p + ".norm.weight", p + ".norm.bias", groups, 1e-6)
+    h = g.linear(net, h.view(B, N, Cc), p + ".proj_in.weight", p + ".proj_in.bias")
+    k = 0
+    while f"{p}.transformer_blocks.{k}.norm1.weight" in W:
+        b = f"{p}.transformer_blocks.{k}"
+        n = g.layernorm(net, h, b + ".norm1.weight", b + ".norm1.bias")
+        qk = g.linear(net, n, b + ".attn1.to_qk.weight")
+        v = g.linear(net, n, b + ".attn1.to_v.weight")
+        a = g.attention(qk, 0, qk, Cc, v, heads, N)
+        h = g.linear(net, a, b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", residual=h)
+        n = g.layernorm(net, h, b + ".norm2.weight", b + ".norm2.bias")
+        q = g.linear(net, n, b + ".attn2.to_q.weight")
+        ck, cv = kv[b + ".attn2"]
+        a = g.attention(q, 0, ck, 0, cv, heads, nk_valid)
+        h = g.linear(net, a, b + ".attn2.to_out.0.weight", b + ".attn2.to_out.0.bias", residual=h)
+        n = g.layernorm(net, h, b + ".norm3.weight", b + ".norm3.bias")
+        hg = g.linear(net, n, b + ".ff.net.0.proj.weight", b + ".ff.net.0.proj.bias")
+        h = g.linear(net, g.geglu(hg), b + ".ff.net.2.weight", b + ".ff.net.2.bias", residual=h)
+        k += 1
+    out = g.linear(net, h, p + ".proj_out.weight", p + ".proj_out.bias", residual=x.view(B, N, Cc))
+    return out.view(B, H, Wd, Cc)
+
+
+def t_time_shifts(g: Graph, net: TrainParams, cfg, t_dev: torch.Tensor, B: int) -> Var:
+    """Timestep MLP + every ResNet's time_emb_proj as one GEMM, with saved pre-activations (graphs.emit_time_shifts)."""
+    E = g.E
+    c0 = cfg["block_out_channels"][0]
+    e = Var(E.timestep_embedding(t_dev, c0, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0)), needs=False)
+    z = g.act(g.linear(net, e, "time_embedding.linear_1.weight", "time_embedding.linear_1.bias"), ACT_SILU)
+    z = g.act(g.linear(net, z, "time_embedding.linear_2.weight", "time_embedding.linear_2.bias"), ACT_SILU)
+    shifts = g.linear(net, z, "time_emb_proj_all.weight", "time_emb_proj_all.bias")
+    # per-ResNet f32 accumulators of d(shift) = per-batch column sums of the conv1 output gradients, gathered once every ResNet ran
+    net.dshift = {p: torch.zeros((B, n), dtype=F32, device=E.device) for p, (o, n) in net.temb_slices.items()}
+
+    def gather():
+        shifts.cell[0] = torch.cat([net.dshift[p] for p in net.temb_slices], dim=1).to(F16)
+    g.tape.append(gather)
+    return shifts
+
+
+def t_encoder(g: Graph, net, cfg, h: Var, shifts, kv, nk_valid: int):
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    skips = [h]
+    nlev = len(cfg["block_out_channels"])
+    for i, btype in enumerate(cfg["down_block_types"]):
+        for j in range(cfg["layers_per_block"]):
+            h = t_resnet(g, net, f"down_blocks.{i}.resnets.{j}", h, None, shifts, G, eps)
+            if btype == "CrossAttnDownBlock2D":
+                h = t_transformer(g, net, f"down_blocks.{i}.attentions.{j}", h, kv, _heads(cfg, i), G, nk_valid)
+            skips.append(h)
+        if i != nlev - 1:
+            p = f"down_blocks.{i}.downsamplers.0.conv"
+            h = g.conv(net, h, p + ".weight", p + ".bias", stride=2)
+            skips.append(h)
+    return h, skips
+
+
+def t_mid(g: Graph, net, cfg, h: Var, shifts, kv, nk_valid: int) -> Var:
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    h = t_resnet(g, net, "mid_block.resnets.0", h, None, shifts, G, eps)
+    h = t_transformer(g, net, "mid_block.attentions.0", h, kv, _heads(cfg, len(cfg["block_out_channels"]) - 1), G, nk_valid)
+    return t_resnet(g, net, "mid_block.resnets.1", h, None, shifts, G, eps)
+
+
+def t_controlnet(g: Graph, net: TrainParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx_pad: torch.Tensor, nk_valid: int,
+                 cond8: torch.Tensor):
+    """Trainable ControlNet forward (graphs.emit_controlnet_cond + emit_controlnet with every activation kept)."""
+    W = net.W
+    B = x8.shape[0]
+    shifts = t_time_shifts(g, net, cfg, t_dev, B)
+    kv = t_cross_kv(g, net, Var(ctx_pad, needs=False), _attn2_prefixes(W, ("down_blocks.", "mid_block.")))
+    p = "controlnet_cond_embedding"
+    h = g.act(g.conv(net, Var(cond8, needs=False), p + ".conv_in.weight", p + ".conv_in.bias"), ACT_SILU)
+    for i in range(len(cfg["conditioning_embedding_out_channels"]) - 1):
+        h = g.act(g.conv(net, h, f"{p}.blocks.{2 * i}.weight", f"{p}.blocks.{2 * i}.bias"), ACT_SILU)
+        h = g.act(g.conv(net, h, f"{p}.blocks.{2 * i + 1}.weight", f"{p}.blocks.{2 * i + 1}.bias", stride=2), ACT_SILU)
+    cond_emb = g.conv(net, h, p + ".conv_out.weight", p + ".conv_out.bias")
+    h = g.conv(net, Var(x8, needs=False), "conv_in.weight", "conv_in.bias", residual=cond_emb)
+    h, skips = t_encoder(g, net, cfg, h, shifts, kv, nk_valid)
+    h = t_mid(g, net, cfg, h, shifts, kv, nk_valid)
+    outs = [g.conv(net, s, f"controlnet_down_blocks.{i}.weight", f"controlnet_down_blocks.{i}.bias", ksize=1) for i, s in enumerate(skips)]
+    mid = g.conv(net, h, "controlnet_mid_block.weight", "controlnet_mid_block.bias", ksize=1)
+    return outs, mid
+
+
+def t_unet(g: Graph, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx: torch.Tensor, ctx_pad: torch.Tensor,
+           nk_valid: int, down_res: Sequence[Var], mid_res: Var) -> Var:
+    """Frozen UNet: encoder + mid through the fused inference lowering (no gradient flows there), decoder with activations kept
+    so that d(loss)/d(residuals) reaches the ControlNet (diffusion/train_controlnet_genima.py:1377-1388)."""
+    E, W = g.E, net.W
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    shifts = graphs.emit_time_shifts(E, W, cfg, t_dev)
+    kv_inf = graphs.emit_cross_kv(E, W, ctx, "unet_train")
+    h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"])
+    h, skips = graphs._emit_encoder(E, W, cfg, h, shifts, kv_inf)
+    h = graphs._emit_mid(E, W, cfg, h, shifts, kv_inf)
+    del kv_inf
+    skips = [g.add(Var(s, needs=False), r) for s, r in zip(skips, down_res)]
+    hv = g.add(Var(h, needs=False), mid_res)
+    kv = t_cross_kv(g, net, Var(ctx_pad, needs=False), _attn2_prefixes(W, ("up_blocks.",)))
+    nlev = len(cfg["block_out_channels"])
+    for i, btype in enumerate(cfg["up_block_types"]):
+        for j in range(cfg["layers_per_block"] + 1):
+            hv = t_resnet(g, net, f"up_blocks.{i}.resnets.{j}", hv, skips.pop(), shifts, G, eps)
+            if btype == "CrossAttnUpBlock2D":
+                hv = t_transformer(g, net, f"up_blocks.{i}.attentions.{j}", hv, kv, _heads(cfg, nlev - 1 - i), G, nk_valid)
+        if i != nlev - 1:
+            p = f"up_blocks.{i}.upsamplers.0.conv"
+            hv = g.conv(net, hv, p + ".weight", p + ".bias", upsample2x=True)
+    hv = g.groupnorm(net, hv, "conv_norm_out.weight", "conv_norm_out.bias", G, eps, ACT_SILU)
+    return g.conv(net, hv, "conv_out.weight", "conv_out.bias")
+
+
+# =============================================================================================================== the step
+def pad_context(ctx: torch.Tensor) -> torch.Tensor:
+    """[B, L, D] prompt states -> [B, rup(L, 8), D] with zero rows (their keys get zero attention weight, gn_softmax_rows_masked)."""
+    B, L, D = ctx.shape
+    Lp = _rup(L, CTX_PAD)
+    if Lp == L:
+        return ctx.contiguous()
+    out = torch.zeros((B, Lp, D), dtype=ctx.dtype, device=ctx.device)
+    out[:, :L] = ctx
+    return out
+
+
+class ControlNetTrainer:
+    """The optimisation step of diffusion/train_controlnet_genima.py on one GPU (one rank of the data-parallel job).
+
+    ``unet_W`` -- packed f16 weights of the frozen UNet (packing.pack_state_dict); ``controlnet_sd`` -- fp32 diffusers-named
+    ControlNet state dict (ControlNetModel.from_unet initialisation or a checkpoint).  Hyper-parameters default to the reference's
+    (AdamW lr 1e-5 README / betas (0.9, 0.999) / weight_decay 1e-2 / eps 1e-8, :1178-1185; max_grad_norm 1.0, :1403-1405;
+    GradScaler defaults: initial scale 65536, growth x2 every 2000 clean steps, backoff x0.5)."""
+
+    def __init__(self, E: Engine, unet_cfg, controlnet_cfg, unet_W, controlnet_sd, *, lr: float = 1e-5, betas=(0.9, 0.999),
+                 weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, loss_scale: float = 65536.0,
+                 growth_interval: int = 2000, allreduce=None):
+        self.E, self.unet_cfg, self.cn_cfg = E, unet_cfg, controlnet_cfg
+        self.unet = FrozenParams(E, unet_W)
+        self.cn = TrainParams(E, controlnet_sd)
+        self.lr, self.betas, self.wd, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
+        self.loss_scale, self.growth_interval, self._clean = float(loss_scale), growth_interval, 0
+        self.opt_step = 0
+        self.allreduce = allreduce  # callable(flat f32 grad buffer) -> None: mean over ranks (dist.allreduce_mean_flat)
+        self._ss = torch.zeros(1, dtype=F32, device=E.device)
+        self._clip = torch.zeros(3, dtype=F32, device=E.device)
+        self.last = {}
+
+    # ---- forward + backward: fills self.cn.grad (loss-scaled) and returns the device loss scalar
+    def forward_backward(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, c_valid: int = 4):
+        """latents8 / noise8: f16 [B, h, w, 8] (channels >= c_valid zero); t_dev f32 [B] timesteps; sqrt_ac / sqrt_1mac f32 [B]
+        (DDPMScheduler.add_noise coefficients); ctx f16 [B, L, D] prompt states; cond8 f16 [B, H, W, 8] conditioning image in [0, 1]."""
+        E = self.E
+        g = Graph(E)
+        noisy = E.add_noise(latents8, noise8, sqrt_ac, sqrt_1mac)
+        ctx_pad, L = pad_context(ctx), ctx.shape[1]
+        down, mid = t_controlnet(g, self.cn, self.cn_cfg, noisy, t_dev, ctx_pad, L, cond8)
+        pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid)
+        loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale)
+        pred.cell[0] = dpred
+        g.backward()
+        self.last["pred"] = pred.t
+        return loss
+
+    def optimizer_step(self):
+        """all-reduce (data parallel) -> unscale + global-norm clip -> AdamW -> refresh f16 weights -> zero grads."""
+        E, cn = self.E, self.cn
+        if self.allreduce is not None:
+            self.allreduce(cn.grad)
+        inv = 1.0 / self.loss_scale
+        T.sumsq(E, cn.grad, self._ss)
+        T.clip_coef(E, self._ss, self._clip, self.max_grad_norm, inv)
+        self.opt_step += 1
+        T.adamw(E, cn.master, cn.grad, cn.exp_avg, cn.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
+                self._clip, inv)
+        cn.sync_half()
+        cn.zero_grad()
+
+    def update_scale(self) -> bool:
+        """GradScaler.update(): one host read of the found-inf flag.  Returns True when the step was applied."""
+        coef, norm, bad = self._clip.tolist()
+        self.last["grad_norm"] = norm
+        if bad:
+            self.loss_scale *= 0.5
+            self._clean = 0
+            self.opt_step -= 1  # the skipped step does not advance Adam's bias correction
+            return False
+        self._clean += 1
+        if self._clean >= self.growth_interval:
+            self.loss_scale *= 2.0
+            self._clean = 0
+        return True
+
+    def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8) -> torch.Tensor:
+        loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8)
+        self.optimizer_step()
+        self.update_scale()
+        return loss

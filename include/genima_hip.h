@@ -165,6 +165,8 @@ int32_t gn_act(gn_ctx* ctx, const void* x, void* out, int64_t n, int32_t act);  
 int32_t gn_embedding(gn_ctx* ctx, const int32_t* ids, const void* tok, const void* pos, void* out, int32_t B,
                      int32_t L, int32_t D);                                                   /* CLIP token + position */
 int32_t gn_softmax_rows(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale); /* in place, f16 */
+/* same with key padding: columns >= valid get probability 0 (cols stays a multiple of 8) */
+int32_t gn_softmax_rows_masked(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale, int32_t valid);
 int32_t gn_maxpool3x3s2(gn_ctx* ctx, const void* x, void* y, int32_t B, int32_t H, int32_t W, int32_t C);
 
 /* ---- training-side kernels (ControlNet fine-tune step, diffusion/train_controlnet_genima.py:1317-1408) ----------
@@ -182,8 +184,10 @@ int32_t gn_colsum_f32(gn_ctx* ctx, const void* x, float* out, int32_t nb, int32_
                       void* workspace, int32_t accumulate);
 int32_t gn_reduce_rows_f32(gn_ctx* ctx, const float* part, float* out, int32_t groups, int32_t R, int32_t cols, int32_t accumulate);
 int32_t gn_act_bwd(gn_ctx* ctx, const void* dy, const void* z, void* dz, int64_t n, int32_t act);   /* dz = dy * act'(z) */
-int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd);   /* hg = [hidden | gate] (unfused form) */
-int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd);
+/* unfused GEGLU out = hidden * gelu(gate); hg [M, 2*Hd]: block == 0 -> [hidden | gate] halves, block > 0 -> alternating
+ * block-column groups [hidden | gate] (the packed ff.net.0.proj layout of GN_ACT_GEGLU, block = 32) */
+int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd, int32_t block);
+int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd, int32_t block);
 /* attention backward softmax step, in place over dp: ds = scale * p * (dp - rowsum(p * dp)) */
 int32_t gn_softmax_bwd(gn_ctx* ctx, const void* p, void* dp, int64_t rows, int32_t cols, int64_t ld, float scale);
 int64_t gn_layernorm_bwd_workspace_bytes(int64_t M, int32_t C);
@@ -199,7 +203,10 @@ int32_t gn_sumpool2x2(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t 
 int32_t gn_mse_loss(gn_ctx* ctx, const void* pred, const void* target, void* dpred, float* loss_out, void* workspace,
                     int64_t pixels, int32_t C, int32_t ld_pred, int32_t ld_target, float grad_scale);
 int32_t gn_sumsq_f32(gn_ctx* ctx, const float* x, int64_t n, float* out, void* workspace);
-int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm);
+/* global-norm clipping after loss-scale removal (accelerator.clip_grad_norm_, diffusion/train_controlnet_genima.py:1403-1405):
+ * norm = sqrt(sumsq[0]) * inv_scale; clip[0] = min(1, max_norm / (norm + 1e-6)); clip[1] = norm; clip[2] = 1 when non-finite
+ * (gn_adamw_flat given this clip buffer then leaves the parameters untouched, as GradScaler.step does) */
+int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm, float inv_scale);
 int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int32_t step, const float* clip_dev, float grad_scale);
 int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n);

@@ -29,6 +29,12 @@ def test_gemm_f32_out_accumulate_and_batched(engine):
     out = torch.full((M, N), 0.5, dtype=torch.float32, device="cuda")
     T.gemm(engine, h(a), h(w), out, M, N, K, K, K, N, f32_out=True, accumulate=True)
     assert_close(out, a @ w.t() + 0.5, what="f32 accumulate gemm")
+    # long reduction, few tiles -> the planner picks split-K; the accumulate must still add onto the existing f32 values
+    Ml, Kl = 64, 16384
+    al, wl = q16(torch.randn(Ml, Kl, generator=g(5))), q16(torch.randn(Ml, Kl, generator=g(6)) * Kl ** -0.5)
+    outl = torch.full((Ml, Ml), -2.0, dtype=torch.float32, device="cuda")
+    T.gemm(engine, h(al), h(wl), outl, Ml, Ml, Kl, Kl, Kl, Ml, f32_out=True, accumulate=True)
+    assert_close(outl, al @ wl.t() - 2.0, what="f32 accumulate gemm (split-K)")
     # batched, two-level strides: [Bo, Bi] problems
     Bo, Bi = 3, 2
     ab = q16(torch.randn(Bo, Bi, M, K, generator=g(3)))
@@ -123,6 +129,35 @@ def test_act_geglu_softmax_backward(engine):
     assert_close(dpd, ref, what="softmax bwd")
 
 
+def test_geglu_block_layout_masked_softmax_weight_rotation(engine):
+    # packed (32-column interleaved) GEGLU layout == plain layout after un-interleaving
+    M, Hd = 40, 128
+    hg = q16(torch.randn(M, 2 * Hd, generator=g(1)))
+    dy = q16(torch.randn(M, Hd, generator=g(2)))
+    inter = torch.stack([hg[:, :Hd].reshape(M, Hd // 32, 32), hg[:, Hd:].reshape(M, Hd // 32, 32)], 2).reshape(M, 2 * Hd)
+    assert torch.equal(T.geglu_fwd(engine, h(inter), 32), T.geglu_fwd(engine, h(hg), 0))
+    d_plain = T.geglu_bwd(engine, h(dy), h(hg), 0).cpu()
+    d_int = T.geglu_bwd(engine, h(dy), h(inter), 32).cpu().reshape(M, Hd // 32, 2, 32)
+    assert torch.equal(d_int[:, :, 0].reshape(M, Hd), d_plain[:, :Hd]) and torch.equal(d_int[:, :, 1].reshape(M, Hd), d_plain[:, Hd:])
+    # masked softmax: 77 valid keys in an 80-column row
+    s = q16(torch.randn(3, 50, 80, generator=g(3)) * 3)
+    ref = torch.zeros_like(s)
+    ref[..., :77] = torch.softmax(s[..., :77] * 0.125, -1)
+    out = T.softmax_rows_masked(engine, h(s), 0.125, 77)
+    assert_close(out, ref, what="masked softmax")
+    assert float(out[..., 77:].abs().max()) == 0.0
+    # data-gradient weights: channel swap + 180-degree tap rotation of a packed 3x3 weight, and the 1x1 case
+    w = q16(torch.randn(24, 16, 3, 3, generator=g(4)))
+    ref = pack_conv_weight(w.flip(2, 3).permute(1, 0, 2, 3).contiguous())
+    assert torch.equal(T.conv_weight_dgrad(engine, pack_conv_weight(w).cuda(), 9).cpu(), ref)
+    w1 = q16(torch.randn(24, 16, 1, 1, generator=g(5)))
+    assert torch.equal(T.conv_weight_dgrad(engine, pack_conv_weight(w1).cuda(), 1).cpu(), w1[:, :, 0, 0].t().half())
+    # padded transpose (GEMM reduction length must be a multiple of 8)
+    x = q16(torch.randn(3, 40, generator=g(6)))
+    xt = T.transpose2d(engine, h(x), 3, 40)
+    assert xt.shape == (40, 8) and torch.equal(xt[:, :3].cpu(), x.t().half()) and float(xt[:, 3:].abs().max()) == 0.0
+
+
 def test_layernorm_backward(engine):
     M, C = 300, 320
     x = q16(torch.randn(M, C, generator=g(1)) * 2 + 0.5).requires_grad_(True)
@@ -131,7 +166,7 @@ def test_layernorm_backward(engine):
     dy = q16(torch.randn(M, C, generator=g(4)))
     F.layer_norm(x, (C,), gm, bt, 1e-5).backward(dy)
     dgb = torch.zeros(2 * C, dtype=torch.float32, device="cuda")
-    dx = T.layernorm_bwd(engine, h(x.detach()), h(gm.detach()), h(dy), dgb)
+    dx = T.layernorm_bwd(engine, h(x.detach()), h(gm.detach()), h(dy), dgb[:C], dgb[C:])
     assert_close(dx, x.grad, what="layernorm dx")
     assert_close(dgb[:C], gm.grad, what="layernorm dgamma")
     assert_close(dgb[C:], bt.grad, what="layernorm dbeta")
@@ -154,7 +189,7 @@ def test_groupnorm_backward(engine, act, concat):
                                        x2=h(nhwc(x2.detach())) if concat else None)
     assert_close(out, nhwc(y.detach()), what="groupnorm fwd (train)")
     dgb = torch.zeros(2 * C, dtype=torch.float32, device="cuda")
-    dx1, dx2 = T.groupnorm_bwd(engine, saved, h(nhwc(dy)), dgamma=dgb)
+    dx1, dx2 = T.groupnorm_bwd(engine, saved, h(nhwc(dy)), dgamma=dgb[:C], dbeta=dgb[C:])
     assert_close(dx1, nhwc(x1.grad), rel=2e-3, what="groupnorm dx")
     if concat:
         assert_close(dx2, nhwc(x2.grad), rel=2e-3, what="groupnorm dx2")
@@ -179,18 +214,28 @@ def test_mse_adamw_clip(engine):
     opt = torch.optim.AdamW([w], lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
     wd = w.detach().clone().cuda()
     m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    ss, clip = torch.zeros(1, device="cuda"), torch.zeros(2, device="cuda")
+    ss, clip = torch.zeros(1, device="cuda"), torch.zeros(3, device="cuda")
+    S = 1024.0  # loss scale carried by the gradients
     for step in range(1, 4):
         gr = torch.randn(n, generator=g(10 + step)) * 3
         w.grad = gr.clone()
         norm = torch.nn.utils.clip_grad_norm_([w], 1.0)
         opt.step()
-        gd = gr.cuda()
+        gd = (gr * S).cuda()
         T.sumsq(engine, gd, ss)
-        T.clip_coef(engine, ss, clip, 1.0)
+        T.clip_coef(engine, ss, clip, 1.0, 1.0 / S)
         assert abs(float(clip[1].cpu()) - float(norm)) < 1e-3 * float(norm)
-        T.adamw(engine, wd, gd, m, v, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step, clip)
+        assert float(clip[2].cpu()) == 0.0
+        T.adamw(engine, wd, gd, m, v, 1e-2, 0.9, 0.999, 1e-8, 1e-2, step, clip, 1.0 / S)
     assert rel_l2(wd.cpu(), w.detach()) < 1e-5
+    # non-finite gradients: flagged, and the step leaves parameters and moments untouched
+    before = (wd.clone(), m.clone(), v.clone())
+    gd[7] = float("inf")
+    T.sumsq(engine, gd, ss)
+    T.clip_coef(engine, ss, clip, 1.0, 1.0 / S)
+    T.adamw(engine, wd, gd, m, v, 1e-2, 0.9, 0.999, 1e-8, 1e-2, 4, clip, 1.0 / S)
+    assert float(clip[2].cpu()) == 1.0
+    assert torch.equal(wd, before[0]) and torch.equal(m, before[1]) and torch.equal(v, before[2])
     out16 = torch.empty(n, dtype=torch.float16, device="cuda")
     T.cast_f32_f16(engine, wd, out16)
     assert torch.equal(out16.cpu(), wd.cpu().half())

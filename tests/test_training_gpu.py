@@ -1,0 +1,102 @@
+"""-m gpu: the ControlNet fine-tune step (genima_amd/training.py) against torch autograd over the CPU oracle (oracle/train_torch.py)
+on the tiny family (same topology as SD-Turbo): loss, model prediction, every parameter gradient, then clip + AdamW.
+
+Tolerances (stated here, as the task asks for floating point): the forward is held to the network bar of test_models_gpu.py; parameter
+gradients pass through ~200 f16-stored backward layers, so the bar is relative L2 <= 2e-2 per tensor (tensors whose gradient carries
+>= 0.1 % of the global norm), <= 1e-2 over the whole flat gradient, and <= 1.5x the f16-storage oracle's own distance from fp32."""
+import pytest
+import torch
+
+from genima_amd import configs, schema, weights
+from genima_amd.engine import Engine
+from genima_amd.host import nchw_to_nhwc
+from genima_amd.packing import pack_state_dict
+from genima_amd.scheduler import DDPMScheduler
+from genima_amd.training import ControlNetTrainer
+from oracle import train_torch as OT
+from util import q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FAM = configs.family("tiny")
+
+
+def _setup(B=2, seed=0):
+    ucfg, ccfg = FAM["unet"], FAM["controlnet"]
+    usd = weights.round_to(weights.synth_state_dict(schema.unet_schema(ucfg), 1), torch.float16)
+    csd = weights.round_to(weights.synth_state_dict(schema.controlnet_schema(ccfg), 2), torch.float16)
+    g = torch.Generator().manual_seed(seed)
+    lat = q16(torch.randn(B, 4, 16, 16, generator=g))
+    noise = q16(torch.randn(B, 4, 16, 16, generator=g))
+    ctx = q16(torch.randn(B, 77, 128, generator=g))
+    cond = q16(torch.rand(B, 3, 128, 128, generator=g))
+    t = torch.tensor([801, 399][:B])
+    sa, s1 = DDPMScheduler().add_noise_coeffs(t)
+    return ucfg, ccfg, usd, csd, lat, noise, ctx, cond, t, sa, s1
+
+
+def _flat(packed, layout):
+    return torch.cat([packed[n].reshape(-1).float().cpu() for n in layout])
+
+
+def test_controlnet_train_step_tiny():
+    ucfg, ccfg, usd, csd, lat, noise, ctx, cond, t, sa, s1 = _setup()
+    E = Engine("cuda:0")
+    S = 4096.0
+    tr = ControlNetTrainer(E, ucfg, ccfg, pack_state_dict(usd, "cuda"), csd, lr=1e-4, loss_scale=S)
+    dev = lambda x: x.cuda()  # noqa: E731
+    args = (dev(nchw_to_nhwc(lat, 8).half()), dev(nchw_to_nhwc(noise, 8).half()), dev(t.float()), dev(sa), dev(s1), dev(ctx.half()),
+            dev(nchw_to_nhwc(cond, 8).half()))
+    loss = float(tr.forward_backward(*args).cpu())
+    pred = tr.last["pred"][..., :4].permute(0, 3, 1, 2).float().cpu()
+    layout = list(tr.cn.layout)
+    g_hip = {n: (tr.cn.G[n].float() / S).cpu() for n in layout}
+
+    tf = t.float()
+    l32, g32, p32 = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, tf, sa, s1, ctx, cond)
+    l16, g16, p16 = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, tf, sa, s1, ctx, cond, q=q16)
+    print(f"loss hip {loss:.6f}  oracle fp32 {float(l32):.6f}  oracle f16-storage {float(l16):.6f}")
+    assert abs(loss - float(l32)) <= 2e-3 * float(l32)
+    e_pred, e_ref = rel_l2(pred, p32), rel_l2(p16, p32)
+    print(f"model_pred rel-L2 vs fp32 oracle {e_pred:.2e} (f16-storage oracle: {e_ref:.2e})")
+    assert e_pred <= min(1e-2, 1.5 * e_ref + 5e-4)
+
+    P32, P16 = pack_state_dict(g32, "cpu", dtype=torch.float32), pack_state_dict(g16, "cpu", dtype=torch.float32)
+    f_hip, f32_, f16_ = _flat(g_hip, layout), _flat(P32, layout), _flat(P16, layout)
+    gnorm = float(f32_.norm())
+    e_all, e_all_ref = rel_l2(f_hip, f32_), rel_l2(f16_, f32_)
+    print(f"flat gradient: |g| = {gnorm:.4e}, rel-L2 vs fp32 oracle {e_all:.2e} (f16-storage oracle: {e_all_ref:.2e})")
+    worst = []
+    for n in layout:
+        ref = P32[n].float()
+        if float(ref.norm()) < 1e-3 * gnorm:
+            # small tensors: bounded in absolute terms relative to the global norm
+            assert float((g_hip[n] - ref).norm()) <= 1e-4 * gnorm, n
+            continue
+        worst.append((rel_l2(g_hip[n], ref), n))
+    worst.sort(reverse=True)
+    print("worst per-tensor gradient errors:", [(f"{e:.2e}", n) for e, n in worst[:5]])
+    assert torch.isfinite(f_hip).all()
+    assert e_all <= min(1e-2, 1.5 * e_all_ref + 2e-3)
+    assert worst[0][0] <= 2e-2, worst[:5]
+    # every trainable tensor received a gradient (no dead branch in the hand-written backward)
+    dead = [n for n in layout if float(P32[n].abs().max()) > 1e-7 * gnorm and float(g_hip[n].abs().max()) == 0.0]
+    assert not dead, dead
+
+    # ---- clip + AdamW on the flat buffers vs torch.optim.AdamW on the same (HIP) gradient
+    m0 = tr.cn.master.clone().cpu()
+    gflat = (tr.cn.grad.clone() / S).cpu()
+    tr.optimizer_step()
+    assert tr.update_scale()
+    w = torch.nn.Parameter(m0.clone())
+    w.grad = gflat.clone()
+    norm = float(torch.nn.utils.clip_grad_norm_([w], 1.0))
+    torch.optim.AdamW([w], lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8).step()
+    assert abs(tr.last["grad_norm"] - norm) <= 1e-4 * norm
+    assert float((tr.cn.master.cpu() - w.detach()).abs().max()) <= 1e-7 + 1e-3 * 1e-4
+    assert float(tr.cn.grad.abs().max()) == 0.0
+    assert torch.equal(tr.cn.half.cpu(), tr.cn.master.cpu().half())
+    # a second step runs from the refreshed f16 weights and changes the loss
+    loss2 = float(tr.step(*args).cpu())
+    assert loss2 == loss2 and loss2 != loss
+    print(f"loss after one step: {loss2:.6f}")
