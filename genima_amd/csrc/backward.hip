@@ -462,6 +462,22 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float* __restr
     out[0] = bad ? 0.0f : fminf(1.0f, max_norm / (norm + 1e-6f));
   }
 }
+// latents = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scaling_factor  -- DiagonalGaussianDistribution.sample()
+// (diffusion/train_controlnet_genima.py:1329-1332); moments [p, 2*C] = (mean | logvar), out [p, ld] zero-padded
+__global__ void latent_sample_kernel(const f16* __restrict__ mom, const f16* __restrict__ eps, f16* __restrict__ out, long pixels, int C, int ld_mom,
+                                     int ld_eps, int ld_out, float scale) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pixels * ld_out) return;
+  const long p = idx / ld_out;
+  const int c = (int)(idx - p * ld_out);
+  float v = 0.f;
+  if (c < C) {
+    const float mean = (float)mom[p * ld_mom + c];
+    const float logvar = fminf(fmaxf((float)mom[p * ld_mom + C + c], -30.0f), 20.0f);
+    v = (mean + __expf(0.5f * logvar) * (float)eps[p * ld_eps + c]) * scale;
+  }
+  out[idx] = (f16)v;
+}
 __global__ void cast_f32_f16_kernel(const float* __restrict__ x, f16* __restrict__ out, long n) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = (f16)x[i];
@@ -656,6 +672,14 @@ int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, fl
   return GN_OK;
 }
 
+int32_t gn_latent_sample(gn_ctx* ctx, const void* moments, const void* eps, void* out, int64_t pixels, int32_t C, int32_t ld_moments, int32_t ld_eps,
+                         int32_t ld_out, float scale) {
+  GN_REQUIRE(ctx && moments && eps && out && pixels > 0 && C > 0 && ld_moments >= 2 * C && ld_eps >= C && ld_out >= C, "gn_latent_sample: bad arguments");
+  hipLaunchKernelGGL(latent_sample_kernel, dim3(nblk(pixels * ld_out)), dim3(256), 0, ctx->stream, (const f16*)moments, (const f16*)eps, (f16*)out,
+                     (long)pixels, C, ld_moments, ld_eps, ld_out, scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
 int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n) {
   GN_REQUIRE(ctx && x && out && n > 0, "gn_cast_f32_f16: bad arguments");
   hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, x, (f16*)out, (long)n);

@@ -202,6 +202,15 @@ def adamw(E: Engine, param, grad, m, v, lr, beta1, beta2, eps, wd, step: int, cl
     check(E.lib.gn_adamw_flat(E._ctx, _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps, wd, step, _ptr(clip), grad_scale), "gn_adamw_flat")
 
 
+def latent_sample(E: Engine, moments: torch.Tensor, eps: torch.Tensor, C_lat: int, scale: float, ld_out: int = 8) -> torch.Tensor:
+    """moments [..., >= 2*C_lat] (mean | logvar), eps [..., >= C_lat] -> f16 [..., ld_out] scaled posterior sample, zero padded."""
+    out = torch.empty(tuple(moments.shape[:-1]) + (ld_out,), dtype=F16, device=E.device)
+    pixels = moments.numel() // moments.shape[-1]
+    check(E.lib.gn_latent_sample(E._ctx, _ptr(moments), _ptr(eps), _ptr(out), pixels, C_lat, moments.shape[-1], eps.shape[-1], ld_out, float(scale)),
+          "gn_latent_sample")
+    return out
+
+
 def cast_f32_f16(E: Engine, x: torch.Tensor, out: torch.Tensor):
     check(E.lib.gn_cast_f32_f16(E._ctx, _ptr(x), _ptr(out), x.numel()), "gn_cast_f32_f16")
     return out

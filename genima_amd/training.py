@@ -285,7 +285,8 @@ class Graph:
         Nkr, ldk = k.t.shape[1], k.t.shape[2]
         Cc = v.t.shape[-1]
         D = Cc // heads
-        assert Nkr % 8 == 0 and N % 8 == 0 and v.t.shape[1] == Nkr
+        assert Nkr % 8 == 0 and N % 8 == 0 and v.t.shape[1] == Nkr, \
+            f"attention backward needs token counts in multiples of 8 (queries {N}, key rows {Nkr}); SD latents >= 32x32 satisfy this"
         vt = T.transpose2d(E, v.t, Nkr, Cc, batch=B, in_bs=Nkr * Cc, pad_to=64).view(B, Cc, -1)
         o = E.attention(q.t[:, :, q_off:q_off + Cc], k.t[:, :, k_off:k_off + Cc], vt, heads, Nk=nk_valid)
         out = Var(o, q.needs or k.needs or v.needs)
@@ -562,3 +563,35 @@ class ControlNetTrainer:
         self.optimizer_step()
         self.update_scale()
         return loss
+
+    # ---- the whole step body from a collated batch (VAE encode + text encode + noise sampling in front of step())
+    def attach_frozen(self, vae_cfg, vae_W, text_cfg, text_W, noise_scheduler, seed: int = 0):
+        """Frozen fp16 VAE / CLIP text tower (packed weights) and the DDPMScheduler (diffusion/train_controlnet_genima.py:1038-1060)."""
+        self.vae_cfg, self.vae_W, self.text_cfg, self.text_W, self.noise_scheduler = vae_cfg, vae_W, text_cfg, text_W, noise_scheduler
+        self._gen_dev = torch.Generator(device=self.E.device).manual_seed(seed)
+        self._gen_cpu = torch.Generator().manual_seed(seed)
+
+    def _nhwc8(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() == 4 and x.shape[-1] == 8 and x.dtype == F16:
+            return x.to(self.E.device)
+        from .host import nchw_to_nhwc
+        return nchw_to_nhwc(x.to(self.E.device, F16), 8)
+
+    def train_step(self, batch) -> torch.Tensor:
+        """batch: ``pixel_values`` (NCHW in [-1, 1], or NHWC f16 8-channel), ``conditioning_pixel_values`` (same, in [0, 1]),
+        ``input_ids`` [b, 77] -- the collate_fn output of diffusion/train_controlnet_genima.py:934-964.  Returns the device loss."""
+        E, dev = self.E, self.E.device
+        x8 = self._nhwc8(batch["pixel_values"])
+        cond8 = self._nhwc8(batch["conditioning_pixel_values"])
+        ids = batch["input_ids"].to(dev, torch.int32).contiguous()
+        B = x8.shape[0]
+        Cl = self.vae_cfg["latent_channels"]
+        mom = graphs.emit_vae_encode_moments(E, self.vae_W, self.vae_cfg, x8)
+        shape = tuple(mom.shape[:-1]) + (Cl,)
+        lat8 = T.latent_sample(E, mom, torch.randn(shape, generator=self._gen_dev, device=dev, dtype=F32).to(F16), Cl,
+                               self.vae_cfg.get("scaling_factor", 0.18215))
+        noise8 = E.scale_pad(torch.randn(shape, generator=self._gen_dev, device=dev, dtype=F32).to(F16), 1.0, 8)
+        t = torch.randint(0, int(self.noise_scheduler.config.num_train_timesteps), (B,), generator=self._gen_cpu)
+        sa, s1 = self.noise_scheduler.add_noise_coeffs(t)
+        ctx = graphs.emit_clip_text(E, self.text_W, self.text_cfg, ids)
+        return self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8)

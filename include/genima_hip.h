@@ -209,6 +209,10 @@ int32_t gn_sumsq_f32(gn_ctx* ctx, const float* x, int64_t n, float* out, void* w
 int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm, float inv_scale);
 int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int32_t step, const float* clip_dev, float grad_scale);
+/* VAE posterior sample of the train step (diffusion/train_controlnet_genima.py:1329-1332): moments [p, ld_moments] = (mean | logvar),
+ * out[p, 0:C] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale, out[p, C:ld_out] = 0 */
+int32_t gn_latent_sample(gn_ctx* ctx, const void* moments, const void* eps, void* out, int64_t pixels, int32_t C,
+                         int32_t ld_moments, int32_t ld_eps, int32_t ld_out, float scale);
 int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n);
 int32_t gn_fill_f32(gn_ctx* ctx, float* x, int64_t n, float v);
 

@@ -26,10 +26,10 @@ def _setup(B=2, seed=0):
     usd = weights.round_to(weights.synth_state_dict(schema.unet_schema(ucfg), 1), torch.float16)
     csd = weights.round_to(weights.synth_state_dict(schema.controlnet_schema(ccfg), 2), torch.float16)
     g = torch.Generator().manual_seed(seed)
-    lat = q16(torch.randn(B, 4, 16, 16, generator=g))
-    noise = q16(torch.randn(B, 4, 16, 16, generator=g))
+    lat = q16(torch.randn(B, 4, 32, 32, generator=g))  # 32x32 latents: the mid block then has 16 tokens (attention needs N % 8 == 0)
+    noise = q16(torch.randn(B, 4, 32, 32, generator=g))
     ctx = q16(torch.randn(B, 77, 128, generator=g))
-    cond = q16(torch.rand(B, 3, 128, 128, generator=g))
+    cond = q16(torch.rand(B, 3, 256, 256, generator=g))
     t = torch.tensor([801, 399][:B])
     sa, s1 = DDPMScheduler().add_noise_coeffs(t)
     return ucfg, ccfg, usd, csd, lat, noise, ctx, cond, t, sa, s1
@@ -88,12 +88,13 @@ def test_controlnet_train_step_tiny():
     gflat = (tr.cn.grad.clone() / S).cpu()
     tr.optimizer_step()
     assert tr.update_scale()
-    w = torch.nn.Parameter(m0.clone())
-    w.grad = gflat.clone()
-    norm = float(torch.nn.utils.clip_grad_norm_([w], 1.0))
+    # (torch's f32 CPU vector_norm is off by 1e-3 on a 7.5 M element buffer, so the reference step is done in f64)
+    w = torch.nn.Parameter(m0.double())
+    norm = float(gflat.double().norm())
+    w.grad = gflat.double() * min(1.0, 1.0 / (norm + 1e-6))
     torch.optim.AdamW([w], lr=1e-4, betas=(0.9, 0.999), weight_decay=1e-2, eps=1e-8).step()
-    assert abs(tr.last["grad_norm"] - norm) <= 1e-4 * norm
-    assert float((tr.cn.master.cpu() - w.detach()).abs().max()) <= 1e-7 + 1e-3 * 1e-4
+    assert abs(tr.last["grad_norm"] - norm) <= 1e-5 * norm
+    assert float((tr.cn.master.cpu().double() - w.detach()).abs().max()) <= 1e-7 + 1e-3 * 1e-4
     assert float(tr.cn.grad.abs().max()) == 0.0
     assert torch.equal(tr.cn.half.cpu(), tr.cn.master.cpu().half())
     # a second step runs from the refreshed f16 weights and changes the loss
