@@ -32,59 +32,123 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const f16* __restrict_
   }
 }
 
+// 16-byte variant (cols, ld_in, ld_out, batch strides multiples of 8; 16-byte aligned bases; ld_out >= rup(rows, 8)): a 64x64 tile is
+// read as 8-element row chunks, parked in LDS with a 33-word row pitch (conflict-free column reads: lanes differ by 8 rows = 264
+// words = 8 banks), and written back as 8-element chunks of the transposed rows.  Rows >= `rows` inside the last 8-row granule
+// come out as zeros (the GEMM-operand padding).
+__device__ __forceinline__ void tile_store_chunk(uint32_t (*tile)[33], int r, int chunk, uint4 v) {
+  uint32_t* d = &tile[r][chunk * 4];
+  d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+}
+__device__ __forceinline__ uint4 tile_load_column_chunk(uint32_t (*tile)[33], int r8, int col) {
+  // elements tile[r8 .. r8+7][col] packed as 8 f16
+  uint32_t h[8];
+  const int w = col >> 1, sh = (col & 1) * 16;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (tile[r8 + i][w] >> sh) & 0xffffu;
+  return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+}
+__global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restrict__ in, f16* __restrict__ out, int rows, int cols, long ld_in,
+                                                              long ld_out, long in_bs, long out_bs) {
+  __shared__ uint32_t tile[64][33];
+  const int b = blockIdx.z;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int t = threadIdx.x, lo = t & 7, hi = t >> 3;
+  in += (long)b * in_bs;
+  out += (long)b * out_bs;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int r = r0 + hi + 32 * it, c = c0 + lo * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows && c < cols) v = *reinterpret_cast<const uint4*>(in + (long)r * ld_in + c);
+    tile_store_chunk(tile, hi + 32 * it, lo, v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int oc = hi + 32 * it, c = c0 + oc, r = r0 + lo * 8;
+    if (c < cols && r < rows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = tile_load_column_chunk(tile, lo * 8, oc);
+  }
+}
+
 // ---- im2col^T: out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c]  (0 in the padding) ---------------------
+// Same 64x64 tile / 16-byte scheme as transpose2d_vec_kernel, with the row (pixel) address computed per tap.  C % 8 == 0, M % 8 == 0.
 struct Im2colP { const f16* x; f16* out; int B, H, W, C, KH, KW, stride, pad, Ho, Wo; long M; };
 __global__ __launch_bounds__(256) void im2col_t_kernel(const Im2colP p) {
-  __shared__ f16 tile[64][66];
+  __shared__ uint32_t tile[64][33];
   const int tap = blockIdx.z, dy = tap / p.KW, dx = tap - dy * p.KW;
   const long m0 = (long)blockIdx.y * 64;
   const int c0 = blockIdx.x * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int t = threadIdx.x, lo = t & 7, hi = t >> 3;
   const int hw = p.Ho * p.Wo;
-  for (int i = ty; i < 64; i += 4) {
-    const long m = m0 + i;
-    f16 v = (f16)0.0f;
-    const int c = c0 + tx;
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const long m = m0 + hi + 32 * it;
+    const int c = c0 + lo * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
     if (m < p.M && c < p.C) {
       const int b = (int)(m / hw), rem = (int)(m - (long)b * hw);
       const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
       const int iy = oy * p.stride - p.pad + dy, ix = ox * p.stride - p.pad + dx;
-      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = p.x[(((long)b * p.H + iy) * p.W + ix) * p.C + c];
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const uint4*>(p.x + (((long)b * p.H + iy) * p.W + ix) * p.C + c);
     }
-    tile[i][tx] = v;
+    tile_store_chunk(tile, hi + 32 * it, lo, v);
   }
   __syncthreads();
-  for (int i = ty; i < 64; i += 4) {
-    const int c = c0 + i;
-    const long m = m0 + tx;
-    if (c < p.C && m < p.M) p.out[((long)tap * p.C + c) * p.M + m] = tile[tx][i];
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const int oc = hi + 32 * it, c = c0 + oc;
+    const long m = m0 + lo * 8;
+    if (c < p.C && m < p.M) *reinterpret_cast<uint4*>(p.out + ((long)tap * p.C + c) * p.M + m) = tile_load_column_chunk(tile, lo * 8, oc);
   }
 }
 
 // ---- column sums: out[nb][cols] (+)= sum over each batch's rows; two deterministic stages ----------------------------------------
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const f16* __restrict__ x, float* __restrict__ part, int rpb, int cols,
                                                              long ld, int chunks) {
-  // grid: (ceil(cols/64), chunks, nb); 4 waves walk 4 rows at a time, lanes own columns
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+  // grid: (ceil(cols/128), chunks, nb); a thread owns 8 consecutive columns (one 16-byte load per row), 16 row lanes per block
+  __shared__ float red[16][129];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 128 + tx * 8;
   const int chunk = blockIdx.y, b = blockIdx.z;
   const int rows_per = (rpb + chunks - 1) / chunks;
   const int r0 = chunk * rows_per, r1 = min(rpb, r0 + rows_per);
-  float s = 0.f;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (c < cols)
-    for (int r = r0 + w; r < r1; r += 4) s += (float)x[((long)b * rpb + r) * ld + c];
-  red[w][threadIdx.x & 63] = s;
+    for (int r = r0 + ty; r < r1; r += 16) {
+      const uint4 raw = *reinterpret_cast<const uint4*>(x + ((long)b * rpb + r) * ld + c);
+      const f16x8 h = *reinterpret_cast<const f16x8*>(&raw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] += (float)h[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ty][tx * 8 + e] = s[e];
   __syncthreads();
-  if (w == 0 && c < cols)
-    part[((long)b * chunks + chunk) * cols + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  const int t = threadIdx.x;
+  if (t < 128 && blockIdx.x * 128 + t < cols) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a += red[i][t];
+    part[((long)b * chunks + chunk) * cols + blockIdx.x * 128 + t] = a;
+  }
 }
 __global__ void reduce_rows_f32_kernel(const float* __restrict__ part, float* __restrict__ out, int groups, int R, int cols, int accumulate) {
-  // out[g][c] (+)= sum_{r < R} part[(g*R + r)][c]
+  // out[g][c] (+)= sum_{r < R} part[(g*R + r)][c]   (fixed order; 4 independent accumulators keep the loads in flight)
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)groups * cols) return;
   const int g = (int)(idx / cols), c = (int)(idx - (long)g * cols);
-  float s = 0.f;
-  for (int r = 0; r < R; ++r) s += part[((long)g * R + r) * cols + c];
+  const float* src = part + (long)g * R * cols + c;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int r = 0;
+  for (; r + 4 <= R; r += 4) {
+    s0 += src[(long)r * cols];
+    s1 += src[(long)(r + 1) * cols];
+    s2 += src[(long)(r + 2) * cols];
+    s3 += src[(long)(r + 3) * cols];
+  }
+  for (; r < R; ++r) s0 += src[(long)r * cols];
+  const float s = (s0 + s1) + (s2 + s3);
   out[idx] = accumulate ? out[idx] + s : s;
 }
 
@@ -272,24 +336,58 @@ __device__ __forceinline__ float gnb_dyh(float dy, float x, float a, float s, in
   return act == GN_ACT_SILU ? dy * act_grad(x * a + s, GN_ACT_SILU) : dy;
 }
 __global__ __launch_bounds__(256) void gnb_partial_kernel(const GNBParams p, const float* __restrict__ scsh) {
-  // thread owns one channel (fixed) and walks the slab's rows: sums of dyh and dyh*x per channel
+  // per-channel sums of dyh and dyh*x over the slab's rows.  A thread owns one 8-channel group (16-byte loads of x and dy) and one
+  // of TY row lanes; the row lanes are folded through LDS in a fixed order.
+  __shared__ float red[256][17];
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int r0 = chunk * p.rows, r1 = min(p.HW, r0 + p.rows);
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    const f16* src; int cs, co;
-    if (c < p.C1) { src = p.x; cs = p.C1; co = c; } else { src = p.x2; cs = p.C2; co = c - p.C1; }
-    const float a = scsh[((long)b * p.C + c) * 2], s = scsh[((long)b * p.C + c) * 2 + 1];
-    float s1 = 0.f, s2 = 0.f;
-    for (int r = r0; r < r1; ++r) {
-      const long pix = (long)b * p.HW + r;
-      const float xv = (float)src[pix * cs + co];
-      const float d = gnb_dyh((float)p.dy[pix * p.C + c], xv, a, s, p.act);
-      s1 += d;
-      s2 += d * xv;
+  const int CC = p.C >> 3;
+  const int TX = CC < 256 ? CC : 256, TY = 256 / TX;
+  const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+  float* o = p.part + (((long)b * p.chunks + chunk) * 2) * p.C;
+  for (int cb = 0; cb < CC; cb += TX) {
+    const int cc = cb + tx, c8 = cc * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    if (ty < TY && cc < CC) {
+      const f16* src; int cs, co;
+      if (c8 < p.C1) { src = p.x; cs = p.C1; co = c8; } else { src = p.x2; cs = p.C2; co = c8 - p.C1; }
+      float a[8], s[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        a[e] = scsh[((long)b * p.C + c8 + e) * 2];
+        s[e] = scsh[((long)b * p.C + c8 + e) * 2 + 1];
+      }
+      for (int r = r0 + ty; r < r1; r += TY) {
+        const long pix = (long)b * p.HW + r;
+        const uint4 xr = *reinterpret_cast<const uint4*>(src + pix * cs + co);
+        const uint4 dr = *reinterpret_cast<const uint4*>(p.dy + pix * p.C + c8);
+        const f16x8 xh = *reinterpret_cast<const f16x8*>(&xr), dh = *reinterpret_cast<const f16x8*>(&dr);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xv = (float)xh[e];
+          const float d = gnb_dyh((float)dh[e], xv, a[e], s[e], p.act);
+          s1[e] += d;
+          s2[e] += d * xv;
+        }
+      }
     }
-    float* o = p.part + (((long)b * p.chunks + chunk) * 2) * p.C;
-    o[c] = s1;
-    o[p.C + c] = s2;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[threadIdx.x][e] = s1[e];
+      red[threadIdx.x][8 + e] = s2[e];
+    }
+    __syncthreads();
+    if (ty == 0 && cc < CC) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        float acc = 0.f;
+        for (int j = 0; j < TY; ++j) acc += red[j * TX + tx][e];
+        o[(e < 8 ? 0 : p.C - 8) + c8 + e] = acc;
+      }
+    }
+    __syncthreads();
   }
 }
 __global__ __launch_bounds__(256) void gnb_finalize_kernel(const GNBParams p, const float* __restrict__ stats) {
@@ -494,8 +592,15 @@ extern "C" {
 int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
                        int64_t in_bs, int64_t out_bs) {
   GN_REQUIRE(ctx && in && out && rows > 0 && cols > 0 && batch > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d: bad arguments");
-  hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out,
-                     rows, cols, (long)ld_in, (long)ld_out, (long)in_bs, (long)out_bs);
+  const dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
+  const bool vec = cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && in_bs % 8 == 0 && out_bs % 8 == 0 && ld_out >= (rows + 7) / 8 * 8 &&
+                   ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
+  if (vec)
+    hipLaunchKernelGGL(transpose2d_vec_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
+                       (long)in_bs, (long)out_bs);
+  else
+    hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
+                       (long)in_bs, (long)out_bs);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
@@ -503,24 +608,34 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
 int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize, int32_t stride,
                     int32_t pad) {
   GN_REQUIRE(ctx && x && out && B > 0 && H > 0 && W > 0 && C > 0 && ksize > 0 && stride > 0, "gn_im2col_t: bad arguments");
+  GN_REQUIRE(C % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 15) == 0, "gn_im2col_t: C (%d) must be a multiple of 8, buffers 16-byte aligned", C);
   Im2colP p;
   p.x = (const f16*)x; p.out = (f16*)out; p.B = B; p.H = H; p.W = W; p.C = C; p.KH = ksize; p.KW = ksize; p.stride = stride; p.pad = pad;
   p.Ho = (H + 2 * pad - ksize) / stride + 1; p.Wo = (W + 2 * pad - ksize) / stride + 1;
   p.M = (long)B * p.Ho * p.Wo;
+  GN_REQUIRE(p.M % 8 == 0, "gn_im2col_t: B*Ho*Wo (%ld) must be a multiple of 8", p.M);
   hipLaunchKernelGGL(im2col_t_kernel, dim3((C + 63) / 64, (unsigned)((p.M + 63) / 64), ksize * ksize), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
 
+static inline int colsum_chunks(int nb, int rows_per_batch) {
+  // enough row chunks to fill the chip (~1024 blocks) without shrinking a chunk below 64 rows
+  int chunks = rows_per_batch / 64; if (chunks < 1) chunks = 1;
+  const int want = (1024 + nb - 1) / nb;
+  if (chunks > want) chunks = want;
+  if (chunks > 128) chunks = 128;
+  return chunks;
+}
 int64_t gn_colsum_workspace_bytes(int32_t nb, int32_t rows_per_batch, int32_t cols) {
-  int chunks = rows_per_batch / 256; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  return (int64_t)nb * chunks * cols * 4;
+  return (int64_t)nb * colsum_chunks(nb, rows_per_batch) * cols * 4;
 }
 int32_t gn_colsum_f32(gn_ctx* ctx, const void* x, float* out, int32_t nb, int32_t rows_per_batch, int32_t cols, int64_t ld, void* workspace,
                       int32_t accumulate) {
   GN_REQUIRE(ctx && x && out && workspace && nb > 0 && rows_per_batch > 0 && cols > 0 && ld >= cols, "gn_colsum_f32: bad arguments");
-  int chunks = rows_per_batch / 256; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, chunks, nb), dim3(256), 0, ctx->stream, (const f16*)x, (float*)workspace,
+  GN_REQUIRE(cols % 8 == 0 && ld % 8 == 0 && ((uintptr_t)x & 15) == 0, "gn_colsum_f32: cols (%d) / ld must be multiples of 8, x 16-byte aligned", cols);
+  const int chunks = colsum_chunks(nb, rows_per_batch);
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 127) / 128, chunks, nb), dim3(256), 0, ctx->stream, (const f16*)x, (float*)workspace,
                      rows_per_batch, cols, (long)ld, chunks);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)nb * cols)), dim3(256), 0, ctx->stream, (const float*)workspace, out, nb, chunks, cols, accumulate);
@@ -596,7 +711,7 @@ int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy
   p.x = (const f16*)d->x; p.x2 = (const f16*)d->x2; p.dy = (const f16*)dy; p.gamma = (const f16*)d->gamma; p.beta = (const f16*)d->beta;
   p.dx = (f16*)dx; p.dx2 = (f16*)dx2; p.dgamma = dgamma; p.dbeta = dbeta;
   p.B = d->B; p.HW = d->HW; p.C1 = d->C1; p.C2 = d->C2; p.C = d->C1 + d->C2; p.G = d->groups; p.cpg = p.C / p.G; p.act = d->act; p.eps = d->eps;
-  GN_REQUIRE(p.C <= 4096, "gn_groupnorm_bwd: C <= 4096");
+  GN_REQUIRE(p.C <= 4096 && p.C % 8 == 0 && p.C1 % 8 == 0, "gn_groupnorm_bwd: C <= 4096, C and C1 multiples of 8");
   int chunks = p.HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
   p.rows = (p.HW + chunks - 1) / chunks;
   p.chunks = (p.HW + p.rows - 1) / p.rows;

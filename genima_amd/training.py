@@ -136,6 +136,7 @@ class Graph:
     def __init__(self, E: Engine):
         self.E = E
         self.tape: List = []
+        self._xt = (None, None)  # one-entry cache: (activation, its transpose) shared by consecutive weight-gradient GEMMs
 
     # ---- gradient plumbing
     def acc(self, v: Optional[Var], g: torch.Tensor):
@@ -148,6 +149,7 @@ class Graph:
         for fn in reversed(self.tape):
             fn()
         self.tape.clear()
+        self._xt = (None, None)
 
     def _push(self, out: Var, fn):
         def run():
@@ -190,7 +192,11 @@ class Graph:
             self.acc(residual, dy)
             if net.G is not None:
                 dyt = T.transpose2d(E, dy2, M, N)
-                xt = T.transpose2d(E, x.t.view(M, K), M, K)
+                if self._xt[0] is x.t:  # the previous backward op consumed the same input (q|k and v projections of one LayerNorm)
+                    xt = self._xt[1]
+                else:
+                    xt = T.transpose2d(E, x.t.view(M, K), M, K)
+                    self._xt = (x.t, xt)
                 Mp = dyt.shape[1]
                 T.gemm(E, dyt, xt, net.G[wn], N, K, Mp, Mp, Mp, K, f32_out=True, accumulate=True)
                 if bn:
