@@ -174,11 +174,16 @@ class Engine:
 
     @staticmethod
     def _tune_key(d: GemmDesc) -> str:
-        return "|".join(str(int(v)) for v in (d.conv, d.M, d.N, d.K, d.C1, d.C2, d.KH, d.stride, d.upsample2x, d.act,
-                                              d.out_mode, 1 if d.residual else 0))
+        key = "|".join(str(int(v)) for v in (d.conv, d.M, d.N, d.K, d.C1, d.C2, d.KH, d.stride, d.upsample2x, d.act,
+                                             d.out_mode, 1 if d.residual else 0))
+        if d.batch > 1:  # batched (attention backward) and accumulating (weight gradient) problems: suffixes keep older keys valid
+            key += f"|b{int(d.batch)}"
+        if d.accumulate:
+            key += "|acc"
+        return key
 
-    def _autotune(self, d: GemmDesc):
-        key = self._tune_key(d)
+    def _autotune(self, d: GemmDesc, key: Optional[str] = None):
+        key = key or self._tune_key(d)
         table = _tune_table()
         if key in table:
             return table[key]

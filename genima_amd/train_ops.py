@@ -35,11 +35,31 @@ def gemm(E: Engine, a, w, out, M: int, N: int, K: int, lda: int, ldw: int, ldo: 
         d.a_bs, d.a_bs2 = a_bs
         d.w_bs, d.w_bs2 = w_bs
         d.out_bs, d.out_bs2 = out_bs
+    if E.autotune:
+        d.tile = _tuned_tile(E, d, out)
     nb = int(E.lib.gn_gemm_workspace_bytes(C.byref(d)))
     if nb > 0:
         d.workspace = E._workspace(nb).data_ptr()
     check(E.lib.gn_gemm(E._ctx, C.byref(d)), "gn_gemm")
     return out
+
+
+def _tuned_tile(E: Engine, d: GemmDesc, out: torch.Tensor) -> int:
+    """Per-shape tile choice (Engine._autotune).  The timing launches write to a scratch copy of the output region, never to the real
+    (possibly accumulating) destination."""
+    from .engine import _tune_table
+    key = E._tune_key(d)
+    hit = _tune_table().get(key)
+    if hit is not None:
+        return hit
+    scratch = torch.empty_like(out)
+    real_out, real_acc = d.out, d.accumulate
+    d.out = scratch.data_ptr() + (real_out - out.data_ptr())
+    d.accumulate = 0
+    try:
+        return E._autotune(d, key)
+    finally:
+        d.out, d.accumulate = real_out, real_acc
 
 
 def transpose2d(E: Engine, x: torch.Tensor, rows: int, cols: int, *, ld_in: Optional[int] = None, batch: int = 1, in_bs: int = 0,
