@@ -48,6 +48,48 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor, dtype=torch.float16) -> Tuple[t
     return wp.to(dtype).contiguous(), bp.to(dtype).contiguous()
 
 
+def _unpack_geglu(t: torch.Tensor) -> torch.Tensor:
+    n2 = t.shape[0]
+    blocks = t.reshape(n2 // 64, 2, 32, *t.shape[1:])
+    return torch.cat([blocks[:, 0].reshape(n2 // 2, *t.shape[1:]), blocks[:, 1].reshape(n2 // 2, *t.shape[1:])], dim=0)
+
+
+def unpack_state_dict(packed: Dict[str, torch.Tensor], schema: Dict[str, tuple], temb_slices=None) -> "OrderedDict[str, torch.Tensor]":
+    """Inverse of ``pack_state_dict`` for the names of ``schema`` (diffusers layout, fp32): what ``save_pretrained`` of a network
+    trained in the packed layout writes (diffusion/train_controlnet_genima.py:1486).  ``temb_slices``: the packer's
+    ``__meta__['temb_slices']`` (needed when the per-ResNet ``time_emb_proj`` entries were dropped in favour of the fused one)."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for name, shape in schema.items():
+        shape = tuple(shape)
+        if name not in packed:
+            for q_or_k, fused, half in ((".attn1.to_q.weight", ".attn1.to_qk.weight", 0), (".attn1.to_k.weight", ".attn1.to_qk.weight", 1)):
+                if name.endswith(q_or_k):
+                    f = packed[name[: -len(q_or_k)] + fused]
+                    n = f.shape[0] // 2
+                    out[name] = f[half * n:(half + 1) * n].float().clone()
+            if name.endswith(".time_emb_proj.weight") or name.endswith(".time_emb_proj.bias"):
+                kind = name.rsplit(".", 1)[1]
+                o, n = temb_slices[name[: -len(".time_emb_proj." + kind)]]
+                out[name] = packed["time_emb_proj_all." + kind][o:o + n].float().clone()
+            assert name in out, f"cannot reconstruct {name} from the packed tensors"
+            continue
+        t = packed[name].float()
+        if len(shape) == 4:
+            O, I, KH, KW = shape
+            t = t.reshape(t.shape[0], KH, KW, -1)[:O, :, :, :I].permute(0, 3, 1, 2)
+        elif len(shape) == 2:
+            if name.endswith("ff.net.0.proj.weight"):
+                t = _unpack_geglu(t)
+            t = t[:, : shape[1]]
+        elif len(shape) == 1:
+            if name.endswith("ff.net.0.proj.bias"):
+                t = _unpack_geglu(t)
+            t = t[: shape[0]]
+        out[name] = t.contiguous().clone()
+        assert tuple(out[name].shape) == shape, (name, tuple(out[name].shape), shape)
+    return out
+
+
 def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
     """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries).
     ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams)."""

@@ -570,6 +570,47 @@ class ControlNetTrainer:
         self.update_scale()
         return loss
 
+    # ---- checkpoints: diffusers ControlNet directory + optimizer state (diffusion/train_controlnet_genima.py:1077-1105, 1416-1457, 1486)
+    def controlnet_state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """fp32 diffusers-named ControlNet weights (the master copy un-packed)."""
+        from . import schema
+        from .packing import unpack_state_dict
+        return unpack_state_dict(self.cn.packed_master(), schema.controlnet_schema(self.cn_cfg), self.cn.temb_slices)
+
+    def save_pretrained(self, path: str):
+        from . import weights
+        weights.save_diffusers_dir(path, dict(self.cn_cfg), self.controlnet_state_dict(), torch.float32)
+
+    def save_state(self, output_dir: str, global_step: int) -> str:
+        """accelerator.save_state layout: ``checkpoint-<step>/controlnet`` (diffusers dir) + flat optimizer tensors beside it."""
+        import os
+        from safetensors.torch import save_file
+        d = os.path.join(output_dir, f"checkpoint-{global_step}")
+        self.save_pretrained(os.path.join(d, "controlnet"))
+        save_file({"exp_avg": self.cn.exp_avg.cpu(), "exp_avg_sq": self.cn.exp_avg_sq.cpu(),
+                   "scalars": torch.tensor([self.opt_step, self.loss_scale, self._clean, global_step], dtype=torch.float64)},
+                  os.path.join(d, "optimizer_flat.safetensors"))
+        return d
+
+    def load_state(self, checkpoint_dir: str) -> int:
+        """Resume from ``save_state``'s directory.  Returns the global step it was written at."""
+        import os
+        from safetensors.torch import load_file
+        from . import schema, weights
+        _, sd = weights.load_diffusers_dir(os.path.join(checkpoint_dir, "controlnet"))
+        sd = OrderedDict((k, sd[k]) for k in schema.controlnet_schema(self.cn_cfg))  # safetensors files are key-sorted
+        fresh = TrainParams(self.E, sd)
+        assert fresh.layout == self.cn.layout, "checkpoint does not match this ControlNet configuration"
+        self.cn.master.copy_(fresh.master)
+        st = load_file(os.path.join(checkpoint_dir, "optimizer_flat.safetensors"))
+        self.cn.exp_avg.copy_(st["exp_avg"])
+        self.cn.exp_avg_sq.copy_(st["exp_avg_sq"])
+        self.opt_step, self.loss_scale, self._clean, gstep = (float(v) for v in st["scalars"])
+        self.opt_step, self._clean = int(self.opt_step), int(self._clean)
+        self.cn.sync_half()
+        self.cn.zero_grad()
+        return int(gstep)
+
     # ---- the whole step body from a collated batch (VAE encode + text encode + noise sampling in front of step())
     def attach_frozen(self, vae_cfg, vae_W, text_cfg, text_W, noise_scheduler, seed: int = 0):
         """Frozen fp16 VAE / CLIP text tower (packed weights) and the DDPMScheduler (diffusion/train_controlnet_genima.py:1038-1060)."""
