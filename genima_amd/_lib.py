@@ -44,8 +44,15 @@ class AttnDesc(C.Structure):
         ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("vt_bs", C.c_int64), ("o_bs", C.c_int64),
         ("q_rs", C.c_int32), ("k_rs", C.c_int32), ("vt_rs", C.c_int32), ("o_rs", C.c_int32),
         ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
-        ("causal", C.c_int32), ("scale", C.c_float),
+        ("causal", C.c_int32), ("scale", C.c_float), ("lse", C.c_void_p),
     ]
+
+
+class AttnBwdDesc(C.Structure):
+    _fields_ = ([(n, C.c_void_p) for n in ("q", "k", "v", "o", "d_o", "qt", "kt", "dot", "lse", "delta", "dq", "dk", "dv")]
+                + [(n + "_bs", C.c_int64) for n in ("q", "k", "v", "o", "do", "qt", "kt", "dot", "dq", "dk", "dv")]
+                + [(n + "_rs", C.c_int32) for n in ("q", "k", "v", "o", "do", "qt", "kt", "dot", "dq", "dk", "dv")]
+                + [(n, C.c_int32) for n in ("B", "heads", "Nq", "Nk", "Nk_rows", "D")] + [("scale", C.c_float)])
 
 
 class GroupNormDesc(C.Structure):
@@ -71,6 +78,7 @@ SIGNATURES = {
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
     "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
+    "gn_attention_bwd": (_I32, [_P, C.POINTER(AttnBwdDesc)]),
     "gn_groupnorm_workspace_bytes": (_I64, [C.POINTER(GroupNormDesc)]),
     "gn_groupnorm_fwd": (_I32, [_P, C.POINTER(GroupNormDesc)]),
     "gn_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F]),

@@ -37,6 +37,7 @@ struct AttnParams {
   int q_rs, k_rs, vt_rs, o_rs;
   int heads, Nq, Nk, causal;
   float scale_log2;  // scale * log2(e)
+  float* lse;        // optional [B][heads][Nq]: m + log2(l), so that P = exp2(s * scale_log2 - lse) (training)
 };
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
@@ -244,6 +245,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const float l_tot = l_run[tq] + __shfl_xor(l_run[tq], 32, 64);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     const int qrow = qw + 32 * tq;
+    if (p.lse && hi == 0 && qrow < p.Nq)
+      p.lse[((long)b * p.heads + h) * p.Nq + qrow] = l_tot > 0.0f ? m_run[tq] + __builtin_amdgcn_logf(l_tot) : INFINITY;
     if (qrow < p.Nq) {
       f16* op = p.o + (long)b * p.o_bs + (long)qrow * p.o_rs + (long)h * D;
 #pragma unroll
@@ -292,6 +295,7 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   p.q_rs = d->q_rs; p.k_rs = d->k_rs; p.vt_rs = d->vt_rs; p.o_rs = d->o_rs;
   p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.causal = d->causal;
   p.scale_log2 = d->scale * 1.4426950408889634f;
+  p.lse = d->lse;
   if (d->D == 32) {
     launch_attn<32, 4, 1>(p, d->B, ctx->stream);
   } else {

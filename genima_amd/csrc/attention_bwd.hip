@@ -1,0 +1,364 @@
+// Flash-attention backward on MFMA for gfx950 (D = 64 heads of the SD-Turbo UNet / ControlNet; SURVEY.md section 8 row a12,
+// xformers' memory-efficient attention backward in the reference's step, diffusion/train_controlnet_genima.py:1125-1126, :1402).
+//
+// P is never materialised in HBM: it is recomputed per tile from q, k and the forward's log-sum-exp (gn_attn_desc.lse),
+//     P = exp2(s*c - lse2),   dS = scale * P * (dP - delta),   delta[q] = sum_d dO[q, d] * O[q, d],
+// in two deterministic kernels (no atomics):
+//   * attn_bwd_dq_kernel   -- a block owns 128 queries (registers) and streams 64-key tiles:  dQ^T += K^T . dS^T
+//   * attn_bwd_dkv_kernel  -- a block owns 128 keys (registers) and streams 64-query tiles:   dV^T += dO^T . P,  dK^T += Q^T . dS
+// Both follow the forward kernel's transposed formulation (attention.hip): the owner side sits in the MFMA B operand / the lane
+// (= accumulator column), the streamed side is the A operand read from XOR-swizzled LDS tiles whose rows are stored with index bits
+// 2 and 3 swapped, so the 8 accumulators a lane holds per 16-row step are 8 consecutive streamed rows and convert straight into the
+// next MFMA's B operand.  The second product of each kernel needs the streamed operand transposed ([d][row]); those copies
+// (Q^T, K^T, dO^T) are made by gn_transpose2d beforehand (3 x 2 bytes per element, against >= 7 matrix products per score).
+#include "common.h"
+
+namespace {
+
+constexpr int D = 64;          // head dim
+constexpr int TS = 64;         // streamed rows per tile
+constexpr int TILE = 64 * 128; // bytes of one [64][64] f16 tile
+
+struct AttnBwdParams {
+  const f16 *q, *k, *v, *o, *d_o, *qt, *kt, *dot;
+  const float* lse;
+  float* delta;
+  f16 *dq, *dk, *dv;
+  long q_bs, k_bs, v_bs, o_bs, do_bs, qt_bs, kt_bs, dot_bs, dq_bs, dk_bs, dv_bs;
+  int q_rs, k_rs, v_rs, o_rs, do_rs, qt_rs, kt_rs, dot_rs, dq_rs, dk_rs, dv_rs;
+  int heads, Nq, Nk, Nk_rows;
+  float scale, scale_log2;
+};
+
+__device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+__device__ __forceinline__ int perm_row(int r) { return (r & 32) | swap23(r & 31); }
+
+// delta[b][h][q] = sum_d dO * O
+__global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdParams p, int B) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * p.Nq * p.heads) return;
+  const int h = (int)(idx % p.heads);
+  const long bq = idx / p.heads;
+  const int q = (int)(bq % p.Nq), b = (int)(bq / p.Nq);
+  const f16* o = p.o + (long)b * p.o_bs + (long)q * p.o_rs + h * D;
+  const f16* g = p.d_o + (long)b * p.do_bs + (long)q * p.do_rs + h * D;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < D / 8; ++c) {
+    const uint4 a = *reinterpret_cast<const uint4*>(o + c * 8), d = *reinterpret_cast<const uint4*>(g + c * 8);
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(&a), dh = *reinterpret_cast<const f16x8*>(&d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += (float)ah[e] * (float)dh[e];
+  }
+  p.delta[((long)b * p.heads + h) * p.Nq + q] = s;
+}
+
+// ---- dQ --------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * TILE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+  const bool qlive = qrow < p.Nq;
+
+  const f16* kp = p.k + (long)b * p.k_bs + h * D;
+  const f16* vp = p.v + (long)b * p.v_bs + h * D;
+  const f16* ktp = p.kt + (long)b * p.kt_bs + (long)h * D * p.kt_rs;
+
+  f16x8 qf[4], gf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+    if (qlive) {
+      a = *reinterpret_cast<const uint4*>(p.q + (long)b * p.q_bs + (long)qrow * p.q_rs + h * D + ks * 16 + hi * 8);
+      g = *reinterpret_cast<const uint4*>(p.d_o + (long)b * p.do_bs + (long)qrow * p.do_rs + h * D + ks * 16 + hi * 8);
+    }
+    qf[ks] = *reinterpret_cast<f16x8*>(&a);
+    gf[ks] = *reinterpret_cast<f16x8*>(&g);
+  }
+  const long sidx = ((long)b * p.heads + h) * p.Nq + qrow;
+  const float L = qlive ? p.lse[sidx] : 0.0f;
+  const float dl = qlive ? p.delta[sidx] : 0.0f;
+  const float c = p.scale_log2, sc = p.scale;
+
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 acc[2] = {zero16, zero16};
+
+  const int ntiles = (p.Nk + TS - 1) / TS;
+  uint4 rk[2], rv[2], rt[2];
+  auto load_tile = [&](int t) {
+    const int j0 = t * TS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0), x = make_uint4(0, 0, 0, 0);
+      if (j0 + row < p.Nk_rows) {
+        a = *reinterpret_cast<const uint4*>(kp + (long)(j0 + row) * p.k_rs + ch * 8);
+        g = *reinterpret_cast<const uint4*>(vp + (long)(j0 + row) * p.v_rs + ch * 8);
+      }
+      if (j0 + ch * 8 < p.Nk_rows) x = *reinterpret_cast<const uint4*>(ktp + (long)row * p.kt_rs + j0 + ch * 8);
+      rk[i] = a; rv[i] = g; rt[i] = x;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* Ks = smem + buf * 3 * TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+      *reinterpret_cast<uint4*>(Ks + lds_swz<128>(perm_row(row), ch)) = rk[i];
+      *reinterpret_cast<uint4*>(Ks + TILE + lds_swz<128>(perm_row(row), ch)) = rv[i];
+      *reinterpret_cast<uint4*>(Ks + 2 * TILE + lds_swz<128>(row, ch)) = rt[i];
+    }
+  };
+  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(t + 1);
+    const unsigned char* Ks = smem + cur * 3 * TILE;
+    const unsigned char* Vs = Ks + TILE;
+    const unsigned char* Ts = Ks + 2 * TILE;
+    const int j0 = t * TS;
+    const bool need_mask = j0 + TS > p.Nk;
+
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[u], 0, 0, 0);
+        dp[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, gf[ks], ks == 0 ? zero16 : dp[u], 0, 0, 0);
+      }
+    // accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7)
+    f16x8 dsf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pv = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, -L));
+        if (need_mask && (j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7) >= p.Nk)) pv = 0.0f;
+        dsf[u][r >> 3][r & 7] = (f16)(pv * (dp[u][r] - dl) * sc);
+      }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const f16x8 tf = *reinterpret_cast<const f16x8*>(Ts + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
+          acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, dsf[u][g], acc[dt], 0, 0, 0);
+        }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (qlive) {
+    f16* op = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (f16)acc[dt][4 * g + i];
+        *reinterpret_cast<f16x4*>(op + dt * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+// ---- dK, dV ----------------------------------------------------------------------------------------------------------------
+constexpr int KV_BUF = 4 * TILE + 2 * 64 * 4;  // Q, dO, Q^T, dO^T tiles + lse + delta of the query tile
+
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BUF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  const bool klive = key < p.Nk;
+
+  const f16* qp = p.q + (long)b * p.q_bs + h * D;
+  const f16* gp = p.d_o + (long)b * p.do_bs + h * D;
+  const f16* qtp = p.qt + (long)b * p.qt_bs + (long)h * D * p.qt_rs;
+  const f16* gtp = p.dot + (long)b * p.dot_bs + (long)h * D * p.dot_rs;
+  const float* lsep = p.lse + ((long)b * p.heads + h) * p.Nq;
+  const float* delp = p.delta + ((long)b * p.heads + h) * p.Nq;
+
+  f16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0);
+    if (klive) {
+      a = *reinterpret_cast<const uint4*>(p.k + (long)b * p.k_bs + (long)key * p.k_rs + h * D + ks * 16 + hi * 8);
+      g = *reinterpret_cast<const uint4*>(p.v + (long)b * p.v_bs + (long)key * p.v_rs + h * D + ks * 16 + hi * 8);
+    }
+    kf[ks] = *reinterpret_cast<f16x8*>(&a);
+    vf[ks] = *reinterpret_cast<f16x8*>(&g);
+  }
+  const float c = p.scale_log2, sc = p.scale;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  f32x16 accK[2] = {zero16, zero16}, accV[2] = {zero16, zero16};
+
+  const int ntiles = (p.Nq + TS - 1) / TS;
+  uint4 rq[2], rg[2], rqt[2], rgt[2];
+  float rl = 0.f, rd = 0.f;
+  auto load_tile = [&](int t) {
+    const int j0 = t * TS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0), x = make_uint4(0, 0, 0, 0), y = make_uint4(0, 0, 0, 0);
+      if (j0 + row < p.Nq) {
+        a = *reinterpret_cast<const uint4*>(qp + (long)(j0 + row) * p.q_rs + ch * 8);
+        g = *reinterpret_cast<const uint4*>(gp + (long)(j0 + row) * p.do_rs + ch * 8);
+      }
+      if (j0 + ch * 8 < p.Nq) {  // Nq % 8 == 0: a chunk never straddles the end
+        x = *reinterpret_cast<const uint4*>(qtp + (long)row * p.qt_rs + j0 + ch * 8);
+        y = *reinterpret_cast<const uint4*>(gtp + (long)row * p.dot_rs + j0 + ch * 8);
+      }
+      rq[i] = a; rg[i] = g; rqt[i] = x; rgt[i] = y;
+    }
+    if (tid < 64) {
+      const bool live = j0 + tid < p.Nq;
+      rl = live ? lsep[j0 + tid] : INFINITY;  // dead query rows: P = exp2(.. - inf) = 0
+      rd = live ? delp[j0 + tid] : 0.0f;
+    }
+  };
+  auto store_tile = [&](int buf) {
+    unsigned char* Qs = smem + buf * KV_BUF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+      *reinterpret_cast<uint4*>(Qs + lds_swz<128>(perm_row(row), ch)) = rq[i];
+      *reinterpret_cast<uint4*>(Qs + TILE + lds_swz<128>(perm_row(row), ch)) = rg[i];
+      *reinterpret_cast<uint4*>(Qs + 2 * TILE + lds_swz<128>(row, ch)) = rqt[i];
+      *reinterpret_cast<uint4*>(Qs + 3 * TILE + lds_swz<128>(row, ch)) = rgt[i];
+    }
+    if (tid < 64) {
+      reinterpret_cast<float*>(Qs + 4 * TILE)[tid] = rl;
+      reinterpret_cast<float*>(Qs + 4 * TILE + 256)[tid] = rd;
+    }
+  };
+  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) load_tile(t + 1);
+    const unsigned char* Qs = smem + cur * KV_BUF;
+    const unsigned char* Gs = Qs + TILE;
+    const unsigned char* QTs = Qs + 2 * TILE;
+    const unsigned char* GTs = Qs + 3 * TILE;
+    const float* Ls = reinterpret_cast<const float*>(Qs + 4 * TILE);
+    const float* Ds = Ls + 64;
+
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const f16x8 qfr = *reinterpret_cast<const f16x8*>(Qs + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
+        const f16x8 gfr = *reinterpret_cast<const f16x8*>(Gs + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
+        s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], ks == 0 ? zero16 : s[u], 0, 0, 0);
+        dp[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfr, vf[ks], ks == 0 ? zero16 : dp[u], 0, 0, 0);
+      }
+    // accumulator r of sub-tile u holds query j0 + 32u + 16(r>>3) + 8hi + (r&7)  (row statistics come from LDS)
+    f16x8 pf[2][2], dsf[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int base = 32 * u + 16 * g + 8 * hi;
+        const f32x4 l0 = *reinterpret_cast<const f32x4*>(Ls + base), l1 = *reinterpret_cast<const f32x4*>(Ls + base + 4);
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(Ds + base), d1 = *reinterpret_cast<const f32x4*>(Ds + base + 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float Lq = j < 4 ? l0[j & 3] : l1[j & 3];
+          const float dq_ = j < 4 ? d0[j & 3] : d1[j & 3];
+          const int r = 8 * g + j;
+          const float pv = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, -Lq));
+          pf[u][g][j] = (f16)pv;
+          dsf[u][g][j] = (f16)(pv * (dp[u][r] - dq_) * sc);
+        }
+      }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          const f16x8 gt = *reinterpret_cast<const f16x8*>(GTs + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
+          const f16x8 qt = *reinterpret_cast<const f16x8*>(QTs + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
+          accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gt, pf[u][g], accV[dt], 0, 0, 0);
+          accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qt, dsf[u][g], accK[dt], 0, 0, 0);
+        }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  if (klive) {
+    f16* okp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_rs + h * D;
+    f16* ovp = p.dv + (long)b * p.dv_bs + (long)key * p.dv_rs + h * D;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f16x4 a, v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a[i] = (f16)accK[dt][4 * g + i];
+          v[i] = (f16)accV[dt][4 * g + i];
+        }
+        *reinterpret_cast<f16x4*>(okp + dt * 32 + 8 * g + 4 * hi) = a;
+        *reinterpret_cast<f16x4*>(ovp + dt * 32 + 8 * g + 4 * hi) = v;
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int32_t gn_attention_bwd(gn_ctx* ctx, const gn_attn_bwd_desc* d) {
+  GN_REQUIRE(ctx && d, "gn_attention_bwd: null ctx/desc");
+  GN_REQUIRE(d->q && d->k && d->v && d->o && d->d_o && d->qt && d->kt && d->dot && d->lse && d->delta && d->dq && d->dk && d->dv,
+             "gn_attention_bwd: null pointer");
+  GN_REQUIRE(d->D == 64, "gn_attention_bwd: head dim %d unsupported (64)", d->D);
+  GN_REQUIRE(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0 && d->Nq % 8 == 0 && d->Nk_rows % 8 == 0 && d->Nk_rows >= d->Nk,
+             "gn_attention_bwd: Nq (%d) and Nk_rows (%d) must be multiples of 8, Nk_rows >= Nk (%d)", d->Nq, d->Nk_rows, d->Nk);
+  const int64_t bs[] = {d->q_bs, d->k_bs, d->v_bs, d->o_bs, d->do_bs, d->qt_bs, d->kt_bs, d->dot_bs};
+  const int32_t rs[] = {d->q_rs, d->k_rs, d->v_rs, d->o_rs, d->do_rs, d->qt_rs, d->kt_rs, d->dot_rs};
+  for (int i = 0; i < 8; ++i) GN_REQUIRE(bs[i] % 8 == 0 && rs[i] % 8 == 0, "gn_attention_bwd: input strides must be multiples of 8");
+  GN_REQUIRE(d->dq_rs % 4 == 0 && d->dk_rs % 4 == 0 && d->dv_rs % 4 == 0 && d->dq_bs % 4 == 0 && d->dk_bs % 4 == 0 && d->dv_bs % 4 == 0,
+             "gn_attention_bwd: output strides must be multiples of 4");
+  GN_REQUIRE(d->qt_rs >= d->Nq && d->dot_rs >= d->Nq && d->kt_rs >= d->Nk_rows, "gn_attention_bwd: transposed copies too narrow");
+  const void* in[] = {d->q, d->k, d->v, d->o, d->d_o, d->qt, d->kt, d->dot};
+  for (int i = 0; i < 8; ++i) GN_REQUIRE(((uintptr_t)in[i] & 15) == 0, "gn_attention_bwd: inputs must be 16-byte aligned");
+  GN_REQUIRE(((uintptr_t)d->dq & 7) == 0 && ((uintptr_t)d->dk & 7) == 0 && ((uintptr_t)d->dv & 7) == 0, "gn_attention_bwd: outputs must be 8-byte aligned");
+  GN_REQUIRE(d->scale > 0.0f, "gn_attention_bwd: scale must be positive");
+  AttnBwdParams p;
+  p.q = (const f16*)d->q; p.k = (const f16*)d->k; p.v = (const f16*)d->v; p.o = (const f16*)d->o; p.d_o = (const f16*)d->d_o;
+  p.qt = (const f16*)d->qt; p.kt = (const f16*)d->kt; p.dot = (const f16*)d->dot;
+  p.lse = d->lse; p.delta = d->delta;
+  p.dq = (f16*)d->dq; p.dk = (f16*)d->dk; p.dv = (f16*)d->dv;
+  p.q_bs = d->q_bs; p.k_bs = d->k_bs; p.v_bs = d->v_bs; p.o_bs = d->o_bs; p.do_bs = d->do_bs; p.qt_bs = d->qt_bs; p.kt_bs = d->kt_bs;
+  p.dot_bs = d->dot_bs; p.dq_bs = d->dq_bs; p.dk_bs = d->dk_bs; p.dv_bs = d->dv_bs;
+  p.q_rs = d->q_rs; p.k_rs = d->k_rs; p.v_rs = d->v_rs; p.o_rs = d->o_rs; p.do_rs = d->do_rs; p.qt_rs = d->qt_rs; p.kt_rs = d->kt_rs;
+  p.dot_rs = d->dot_rs; p.dq_rs = d->dq_rs; p.dk_rs = d->dk_rs; p.dv_rs = d->dv_rs;
+  p.heads = d->heads; p.Nq = d->Nq; p.Nk = d->Nk; p.Nk_rows = d->Nk_rows;
+  p.scale = d->scale; p.scale_log2 = d->scale * 1.4426950408889634f;
+  const long nd = (long)d->B * d->Nq * d->heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, ctx->stream, p, d->B);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->Nq + 127) / 128, d->heads, d->B), dim3(256), 0, ctx->stream, p);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->Nk + 127) / 128, d->heads, d->B), dim3(256), 0, ctx->stream, p);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}

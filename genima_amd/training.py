@@ -24,6 +24,7 @@ The tape below is a plain list of closures in forward order -- there is no graph
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -137,6 +138,7 @@ class Graph:
         self.E = E
         self.tape: List = []
         self._xt = (None, None)  # one-entry cache: (activation, its transpose) shared by consecutive weight-gradient GEMMs
+        self.flash_bwd = os.environ.get("GN_ATTN_BWD", "flash") != "gemm"  # "gemm": materialised batched-GEMM backward (cross-check)
 
     # ---- gradient plumbing
     def acc(self, v: Optional[Var], g: torch.Tensor):
@@ -294,8 +296,23 @@ class Graph:
         assert Nkr % 8 == 0 and N % 8 == 0 and v.t.shape[1] == Nkr, \
             f"attention backward needs token counts in multiples of 8 (queries {N}, key rows {Nkr}); SD latents >= 32x32 satisfy this"
         vt = T.transpose2d(E, v.t, Nkr, Cc, batch=B, in_bs=Nkr * Cc, pad_to=64).view(B, Cc, -1)
-        o = E.attention(q.t[:, :, q_off:q_off + Cc], k.t[:, :, k_off:k_off + Cc], vt, heads, Nk=nk_valid)
+        flash = self.flash_bwd and D == 64
+        lse = torch.empty((B, heads, N), dtype=F32, device=E.device) if flash else None
+        o = E.attention(q.t[:, :, q_off:q_off + Cc], k.t[:, :, k_off:k_off + Cc], vt, heads, Nk=nk_valid, lse=lse)
         out = Var(o, q.needs or k.needs or v.needs)
+        fused = q is k or q.cell is k.cell
+
+        def bw_flash(dO):
+            # gn_attention_bwd: P recomputed per tile from (q, k, lse); dq / dk / dv in two deterministic MFMA kernels
+            zeros = torch.zeros if Nkr != nk_valid else torch.empty  # padded key rows are not written by the kernel
+            dq = torch.empty_like(q.t)
+            dk = dq if fused else zeros(k.t.shape, dtype=F16, device=E.device)
+            dv = zeros(v.t.shape, dtype=F16, device=E.device)
+            T.attention_bwd(E, q.t, q_off, k.t, k_off, v.t, o, dO, lse, heads, nk_valid, dq, dk, dv)
+            self.acc(q, dq)
+            if not fused:
+                self.acc(k, dk)
+            self.acc(v, dv)
 
         def bw(dO):
             BH, scale = B * heads, float(D) ** -0.5
@@ -316,7 +333,6 @@ class Graph:
                 self.acc(v, dV)
                 del PT, dOT
             del P
-            fused = q is k or q.cell is k.cell
             dq = torch.empty_like(q.t) if q.needs else None
             dk = dq if fused else (torch.empty_like(k.t) if k.needs else None)
             if dq is not None:
@@ -332,7 +348,7 @@ class Graph:
                 self.acc(q, dq)
             if dk is not None and not fused:
                 self.acc(k, dk)
-        return self._push(out, bw)
+        return self._push(out, bw_flash if flash else bw)
 
 
 # =============================================================================================================== network blocks

@@ -101,8 +101,28 @@ typedef struct gn_attn_desc {
   int32_t B, heads, Nq, Nk, D;
   int32_t causal;
   float scale;
+  float* lse;                        /* optional f32 [B][heads][Nq]: log2-domain log-sum-exp of the scaled scores, kept for
+                                        gn_attention_bwd (training); NULL in inference */
 } gn_attn_desc;
 int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d);
+
+/* Flash-attention backward (D = 64; xformers memory-efficient attention backward under accelerator.backward,
+ * diffusion/train_controlnet_genima.py:1125-1126, :1402).  P is recomputed per tile from q, k and the forward's lse; two
+ * deterministic kernels (dQ over key tiles; dK, dV over query tiles), no atomics.  q / k / v / o / d_o and the gradients are
+ * row-major [B][rows][ld] with head h at column h*D of the given base pointer; qt / kt / dot are gn_transpose2d copies
+ * [B][heads*D][rows_pad] of Q, K and dO.  Rows Nk .. Nk_rows-1 of k / v must be zero padding (their dk / dv rows are left
+ * untouched); Nq and Nk_rows are multiples of 8.  delta: f32 [B][heads][Nq] scratch (sum_d dO*O, written here). */
+typedef struct gn_attn_bwd_desc {
+  const void* q; const void* k; const void* v; const void* o; const void* d_o;
+  const void* qt; const void* kt; const void* dot;
+  const float* lse; float* delta;
+  void* dq; void* dk; void* dv;
+  int64_t q_bs, k_bs, v_bs, o_bs, do_bs, qt_bs, kt_bs, dot_bs, dq_bs, dk_bs, dv_bs;   /* batch strides (elements) */
+  int32_t q_rs, k_rs, v_rs, o_rs, do_rs, qt_rs, kt_rs, dot_rs, dq_rs, dk_rs, dv_rs;   /* row strides (elements) */
+  int32_t B, heads, Nq, Nk, Nk_rows, D;
+  float scale;
+} gn_attn_bwd_desc;
+int32_t gn_attention_bwd(gn_ctx* ctx, const gn_attn_bwd_desc* d);
 
 /* ---- K2: GroupNorm(+SiLU), NHWC --------------------------------------------------------------------------------
  * y = act(GroupNorm_G(cat(x, x2)) * gamma + beta).  Three launches: coalesced partial statistics over pixel slabs, a finalize

@@ -158,6 +158,45 @@ def test_geglu_block_layout_masked_softmax_weight_rotation(engine):
     assert xt.shape == (40, 8) and torch.equal(xt[:, :3].cpu(), x.t().half()) and float(xt[:, 3:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("N,Nk,fused", [(256, 256, True), (200, 77, False), (1024, 1024, True), (64, 77, False)])
+def test_flash_attention_backward(engine, N, Nk, fused):
+    """gn_attention_bwd (flash, P recomputed from lse) vs torch autograd of softmax attention; fused = q|k share one buffer."""
+    B, heads, D = 2, 3, 64
+    Cc = heads * D
+    Nkr = (Nk + 7) // 8 * 8
+    q = q16(torch.randn(B, N, Cc, generator=g(1)))
+    k = torch.zeros(B, Nkr, Cc)
+    v = torch.zeros(B, Nkr, Cc)
+    k[:, :Nk] = q16(torch.randn(B, Nk, Cc, generator=g(2)))
+    v[:, :Nk] = q16(torch.randn(B, Nk, Cc, generator=g(3)))
+    dO = q16(torch.randn(B, N, Cc, generator=g(4)))
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k[:, :Nk], v[:, :Nk]))
+    sp = lambda t, n: t.view(B, n, heads, D).transpose(1, 2)  # noqa: E731
+    o_ref = F.scaled_dot_product_attention(sp(qr, N), sp(kr, Nk), sp(vr, Nk)).transpose(1, 2).reshape(B, N, Cc)
+    o_ref.backward(dO)
+    if fused:
+        qk = h(torch.cat([q, k], -1))
+        qd, kd, q_off, k_off = qk, qk, 0, Cc
+    else:
+        qd, kd, q_off, k_off = h(q), h(k), 0, 0
+    vd = h(v)
+    vt = T.transpose2d(engine, vd, Nkr, Cc, batch=B, in_bs=Nkr * Cc, pad_to=64).view(B, Cc, -1)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
+    o = engine.attention(qd[:, :, q_off:q_off + Cc], kd[:, :, k_off:k_off + Cc], vt, heads, Nk=Nk, lse=lse)
+    assert_close(o, o_ref.detach(), what="attention fwd (lse variant)")
+    s = torch.einsum("bnhd,bmhd->bhnm", q.view(B, N, heads, D), k[:, :Nk].view(B, Nk, heads, D)) * D ** -0.5
+    assert_close(lse, torch.logsumexp(s, -1) * 1.4426950408889634, what="lse (log2 units)")
+    dq = torch.empty_like(qd)
+    dk = dq if fused else torch.zeros_like(kd)
+    dv = torch.zeros_like(vd)
+    T.attention_bwd(engine, qd, q_off, kd, k_off, vd, o, h(dO), lse, heads, Nk, dq, dk, dv)
+    assert_close(dq[:, :, q_off:q_off + Cc], qr.grad, rel=2e-3, what="dQ")
+    assert_close(dk[:, :Nk, k_off:k_off + Cc], kr.grad, rel=2e-3, what="dK")
+    assert_close(dv[:, :Nk], vr.grad, rel=2e-3, what="dV")
+    if Nkr != Nk:
+        assert float(dv[:, Nk:].abs().max()) == 0.0 and float(dk[:, Nk:].abs().max()) == 0.0
+
+
 def test_layernorm_backward(engine):
     M, C = 300, 320
     x = q16(torch.randn(M, C, generator=g(1)) * 2 + 0.5).requires_grad_(True)
