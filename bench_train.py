@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--family", default="sd-turbo")
     ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
     args = ap.parse_args()
 
     from genima_amd import configs, dist, schema, weights
@@ -89,6 +90,16 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     dt = dist.max_over_ranks(time.perf_counter() - t0, device=dev)
+    if args.gemm_table and rank == 0:  # one extra, untimed step with every GEMM launch bracketed by HIP events
+        E.gemm_log = []
+        tr.train_step(batch)
+        rows = sorted(E.gemm_log_report().items(), key=lambda kv: -kv[1][1])
+        E.gemm_log = None
+        os.makedirs(os.path.dirname(os.path.abspath(args.gemm_table)), exist_ok=True)
+        with open(args.gemm_table, "w") as f:
+            f.write("conv|M|N|K|C1|C2|KH|stride|up2x|act|out_mode|residual[|b<batch>][|acc]|t<tile>,calls,total_ms,tflops\n")
+            for k, (calls, ms, tf) in rows:
+                f.write(f"{k},{calls},{ms:.4f},{tf:.1f}\n")
     if rank == 0:
         save_tune_table()
         ms = dt / args.steps * 1e3

@@ -134,22 +134,32 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const f16* __restri
   }
 }
 __global__ void reduce_rows_f32_kernel(const float* __restrict__ part, float* __restrict__ out, int groups, int R, int cols, int accumulate) {
-  // out[g][c] (+)= sum_{r < R} part[(g*R + r)][c]   (fixed order; 4 independent accumulators keep the loads in flight)
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)groups * cols) return;
-  const int g = (int)(idx / cols), c = (int)(idx - (long)g * cols);
-  const float* src = part + (long)g * R * cols + c;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int r = 0;
-  for (; r + 4 <= R; r += 4) {
-    s0 += src[(long)r * cols];
-    s1 += src[(long)(r + 1) * cols];
-    s2 += src[(long)(r + 2) * cols];
-    s3 += src[(long)(r + 3) * cols];
+  // out[g][c] (+)= sum_{r < R} part[(g*R + r)][c].  A block of 4 waves owns 64 consecutive (g, c) outputs; wave w sums rows
+  // w, w+4, ... with 4 independent accumulators (16 loads in flight per output), then the waves combine in a fixed order.
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const long idx = (long)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (idx < (long)groups * cols) {
+    const int g = (int)(idx / cols), c = (int)(idx - (long)g * cols);
+    const float* src = part + (long)g * R * cols + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = w;
+    for (; r + 12 < R; r += 16) {
+      s0 += src[(long)r * cols];
+      s1 += src[(long)(r + 4) * cols];
+      s2 += src[(long)(r + 8) * cols];
+      s3 += src[(long)(r + 12) * cols];
+    }
+    for (; r < R; r += 4) s0 += src[(long)r * cols];
+    s = (s0 + s1) + (s2 + s3);
   }
-  for (; r < R; ++r) s0 += src[(long)r * cols];
-  const float s = (s0 + s1) + (s2 + s3);
-  out[idx] = accumulate ? out[idx] + s : s;
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && idx < (long)groups * cols) {
+    const float t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    out[idx] = accumulate ? out[idx] + t : t;
+  }
 }
 
 // ---- activation backward: dz = dy * act'(z) ---------------------------------------------------------------------------------
@@ -184,24 +194,38 @@ __device__ __forceinline__ long geglu_hidden_col(int j, int Hd, int blk, int* ga
   *gate_off = Hd;
   return j;
 }
+// a thread handles 8 consecutive outputs (Hd and blk multiples of 8: the 8 hidden / gate inputs are one 16-byte chunk each)
 __global__ void geglu_fwd_kernel(const f16* __restrict__ hg, f16* __restrict__ out, long M, int Hd, int blk) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (idx >= M * Hd) return;
   const long m = idx / Hd;
   int go;
   const long hc = m * 2 * Hd + geglu_hidden_col((int)(idx - m * Hd), Hd, blk, &go);
-  const float h = (float)hg[hc], g = (float)hg[hc + go];
-  out[idx] = (f16)(h * act_gelu(g));
+  const uint4 hr = *reinterpret_cast<const uint4*>(hg + hc), gr = *reinterpret_cast<const uint4*>(hg + hc + go);
+  const f16x8 hh = *reinterpret_cast<const f16x8*>(&hr), gh = *reinterpret_cast<const f16x8*>(&gr);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)((float)hh[e] * act_gelu((float)gh[e]));
+  *reinterpret_cast<uint4*>(out + idx) = *reinterpret_cast<uint4*>(&o);
 }
 __global__ void geglu_bwd_kernel(const f16* __restrict__ dy, const f16* __restrict__ hg, f16* __restrict__ dhg, long M, int Hd, int blk) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (idx >= M * Hd) return;
   const long m = idx / Hd;
   int go;
   const long hc = m * 2 * Hd + geglu_hidden_col((int)(idx - m * Hd), Hd, blk, &go);
-  const float h = (float)hg[hc], g = (float)hg[hc + go], d = (float)dy[idx];
-  dhg[hc] = (f16)(d * act_gelu(g));
-  dhg[hc + go] = (f16)(d * h * act_grad(g, GN_ACT_GELU));
+  const uint4 hr = *reinterpret_cast<const uint4*>(hg + hc), gr = *reinterpret_cast<const uint4*>(hg + hc + go);
+  const uint4 dr = *reinterpret_cast<const uint4*>(dy + idx);
+  const f16x8 hh = *reinterpret_cast<const f16x8*>(&hr), gh = *reinterpret_cast<const f16x8*>(&gr), dh = *reinterpret_cast<const f16x8*>(&dr);
+  f16x8 oh, og;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float g = (float)gh[e], d = (float)dh[e];
+    oh[e] = (f16)(d * act_gelu(g));
+    og[e] = (f16)(d * (float)hh[e] * act_grad(g, GN_ACT_GELU));
+  }
+  *reinterpret_cast<uint4*>(dhg + hc) = *reinterpret_cast<uint4*>(&oh);
+  *reinterpret_cast<uint4*>(dhg + hc + go) = *reinterpret_cast<uint4*>(&og);
 }
 
 // ---- softmax backward (attention): ds = scale * p * (dp - sum_j p*dp), in place over dp ----------------------------------------
@@ -327,6 +351,7 @@ struct GNBParams {
   f16* dx; f16* dx2;
   float* part;    // [B][chunks][2][C] per-channel partial sums of dyh and dyh*x
   float* coef;    // [B][C][3]: dx = a1*dyh + a2*x + a3
+  float* sums;    // [B][2][C]: per-channel totals over the whole slab (S1 | S2)
   float* dgamma; float* dbeta;  // f32 [C] accumulated (nullable)
   int B, HW, C1, C2, C, G, cpg, chunks, rows, act;
   float eps;
@@ -394,30 +419,47 @@ __global__ __launch_bounds__(256) void gnb_finalize_kernel(const GNBParams p, co
   // stats[b][g] = (mean, rstd) from the forward.  Per channel: S1 = sum dyh, S2 = sum dyh*x.
   // per group: c2 = mean(dyh*gamma), c1 = mean(dyh*gamma*xhat);  dx = r*gamma*dyh - r*c2 - r*xhat*c1
   //          = (r*gamma) dyh + (-r^2 c1) x + (r^2 c1 mu - r c2)
-  __shared__ float S1[4096], S2[4096];
+  __shared__ float S1[4096], S2[4096], T1[256], T2[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int c = tid; c < p.C; c += 256) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int ch = 0; ch < p.chunks; ++ch) {
-      const float* o = p.part + (((long)b * p.chunks + ch) * 2) * p.C;
-      s1 += o[c];
-      s2 += o[p.C + c];
+    // fixed-order sum over the row chunks, two interleaved accumulators per quantity to keep the loads in flight
+    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+    const float* o = p.part + ((long)b * p.chunks * 2) * p.C + c;
+    int ch = 0;
+    for (; ch + 2 <= p.chunks; ch += 2) {
+      a1 += o[(long)(2 * ch) * p.C];
+      a2 += o[(long)(2 * ch + 1) * p.C];
+      b1 += o[(long)(2 * ch + 2) * p.C];
+      b2 += o[(long)(2 * ch + 3) * p.C];
     }
+    if (ch < p.chunks) {
+      a1 += o[(long)(2 * ch) * p.C];
+      a2 += o[(long)(2 * ch + 1) * p.C];
+    }
+    const float s1 = a1 + b1, s2 = a2 + b2;
     S1[c] = s1;
     S2[c] = s2;
+    p.sums[((long)b * 2) * p.C + c] = s1;       // kept for gnb_param_kernel
+    p.sums[((long)b * 2 + 1) * p.C + c] = s2;
   }
   __syncthreads();
-  for (int c = tid; c < p.C; c += 256) {
-    const int g = c / p.cpg;
+  for (int g = tid; g < p.G; g += 256) {
     const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
-    float t1 = 0.f, t2 = 0.f;  // sum over the group's channels of gamma*S1 and gamma*(S2 - mu*S1)*r
+    float t1 = 0.f, t2 = 0.f;  // sum over the group's channels of gamma*(S2 - mu*S1)*r and gamma*S1
     for (int cc = g * p.cpg; cc < (g + 1) * p.cpg; ++cc) {
       const float gm = (float)p.gamma[cc];
       t2 += gm * S1[cc];
       t1 += gm * (S2[cc] - mu * S1[cc]) * r;
     }
+    T1[g] = t1;
+    T2[g] = t2;
+  }
+  __syncthreads();
+  for (int c = tid; c < p.C; c += 256) {
+    const int g = c / p.cpg;
+    const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
     const float n = (float)p.HW * (float)p.cpg;
-    const float c1 = t1 / n, c2 = t2 / n;
+    const float c1 = T1[g] / n, c2 = T2[g] / n;
     float* o = p.coef + ((long)b * p.C + c) * 3;
     o[0] = r * (float)p.gamma[c];
     o[1] = -r * r * c1;
@@ -431,12 +473,7 @@ __global__ void gnb_param_kernel(const GNBParams p, const float* __restrict__ st
   const int g = c / p.cpg;
   float dg = 0.f, db = 0.f;
   for (int b = 0; b < p.B; ++b) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int ch = 0; ch < p.chunks; ++ch) {
-      const float* o = p.part + (((long)b * p.chunks + ch) * 2) * p.C;
-      s1 += o[c];
-      s2 += o[p.C + c];
-    }
+    const float s1 = p.sums[((long)b * 2) * p.C + c], s2 = p.sums[((long)b * 2 + 1) * p.C + c];  // from gnb_finalize_kernel
     const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
     dg += (s2 - mu * s1) * r;
     db += s1;
@@ -445,18 +482,29 @@ __global__ void gnb_param_kernel(const GNBParams p, const float* __restrict__ st
   p.dbeta[c] += db;
 }
 __global__ __launch_bounds__(256) void gnb_apply_kernel(const GNBParams p, const float* __restrict__ scsh) {
+  // one 8-channel group (16 bytes of x, dy, dx) per thread
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   const int b = blockIdx.y;
-  if (idx >= (long)p.HW * p.C) return;
-  const int r = (int)(idx / p.C), c = (int)(idx - (long)r * p.C);
+  const int CC = p.C >> 3;
+  if (idx >= (long)p.HW * CC) return;
+  const int r = (int)(idx / CC), c = (int)(idx - (long)r * CC) * 8;
   const long pix = (long)b * p.HW + r;
   const f16* src; f16* dst; int cs, co;
   if (c < p.C1) { src = p.x; dst = p.dx; cs = p.C1; co = c; } else { src = p.x2; dst = p.dx2; cs = p.C2; co = c - p.C1; }
-  const float xv = (float)src[pix * cs + co];
-  const float a = scsh[((long)b * p.C + c) * 2], s = scsh[((long)b * p.C + c) * 2 + 1];
-  const float d = gnb_dyh((float)p.dy[pix * p.C + c], xv, a, s, p.act);
+  if (!dst) return;
+  const uint4 xr = *reinterpret_cast<const uint4*>(src + pix * cs + co);
+  const uint4 dr = *reinterpret_cast<const uint4*>(p.dy + pix * p.C + c);
+  const f16x8 xh = *reinterpret_cast<const f16x8*>(&xr), dh = *reinterpret_cast<const f16x8*>(&dr);
+  const float* ss = scsh + ((long)b * p.C + c) * 2;
   const float* k = p.coef + ((long)b * p.C + c) * 3;
-  if (dst) dst[pix * cs + co] = (f16)(k[0] * d + k[1] * xv + k[2]);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float xv = (float)xh[e];
+    const float d = gnb_dyh((float)dh[e], xv, ss[2 * e], ss[2 * e + 1], p.act);
+    o[e] = (f16)(k[3 * e] * d + k[3 * e + 1] * xv + k[3 * e + 2]);
+  }
+  *reinterpret_cast<uint4*>(dst + pix * cs + co) = *reinterpret_cast<uint4*>(&o);
 }
 
 // ---- strided / upsampled conv dgrad helpers ------------------------------------------------------------------------------
@@ -638,14 +686,14 @@ int32_t gn_colsum_f32(gn_ctx* ctx, const void* x, float* out, int32_t nb, int32_
   hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 127) / 128, chunks, nb), dim3(256), 0, ctx->stream, (const f16*)x, (float*)workspace,
                      rows_per_batch, cols, (long)ld, chunks);
   GN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)nb * cols)), dim3(256), 0, ctx->stream, (const float*)workspace, out, nb, chunks, cols, accumulate);
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)nb * cols, 64)), dim3(256), 0, ctx->stream, (const float*)workspace, out, nb, chunks, cols, accumulate);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
 
 int32_t gn_reduce_rows_f32(gn_ctx* ctx, const float* part, float* out, int32_t groups, int32_t R, int32_t cols, int32_t accumulate) {
   GN_REQUIRE(ctx && part && out && groups > 0 && R > 0 && cols > 0, "gn_reduce_rows_f32: bad arguments");
-  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups * cols)), dim3(256), 0, ctx->stream, part, out, groups, R, cols, accumulate);
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups * cols, 64)), dim3(256), 0, ctx->stream, part, out, groups, R, cols, accumulate);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
@@ -658,14 +706,16 @@ int32_t gn_act_bwd(gn_ctx* ctx, const void* dy, const void* z, void* dz, int64_t
 }
 
 int32_t gn_geglu_fwd(gn_ctx* ctx, const void* hg, void* out, int64_t M, int32_t Hd, int32_t block) {
-  GN_REQUIRE(ctx && hg && out && M > 0 && Hd > 0 && block >= 0 && (block == 0 || Hd % block == 0), "gn_geglu_fwd: bad arguments");
-  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)hg, (f16*)out, (long)M, Hd, block);
+  GN_REQUIRE(ctx && hg && out && M > 0 && Hd > 0 && Hd % 8 == 0 && block >= 0 && block % 8 == 0 && (block == 0 || Hd % block == 0),
+             "gn_geglu_fwd: Hd and block must be multiples of 8, block | Hd");
+  hipLaunchKernelGGL(geglu_fwd_kernel, dim3(nblk(M * Hd / 8)), dim3(256), 0, ctx->stream, (const f16*)hg, (f16*)out, (long)M, Hd, block);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
 int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int64_t M, int32_t Hd, int32_t block) {
-  GN_REQUIRE(ctx && dy && hg && dhg && M > 0 && Hd > 0 && block >= 0 && (block == 0 || Hd % block == 0), "gn_geglu_bwd: bad arguments");
-  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblk(M * Hd)), dim3(256), 0, ctx->stream, (const f16*)dy, (const f16*)hg, (f16*)dhg, (long)M, Hd, block);
+  GN_REQUIRE(ctx && dy && hg && dhg && M > 0 && Hd > 0 && Hd % 8 == 0 && block >= 0 && block % 8 == 0 && (block == 0 || Hd % block == 0),
+             "gn_geglu_bwd: Hd and block must be multiples of 8, block | Hd");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(nblk(M * Hd / 8)), dim3(256), 0, ctx->stream, (const f16*)dy, (const f16*)hg, (f16*)dhg, (long)M, Hd, block);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
@@ -693,7 +743,7 @@ int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const vo
   if (dgamma) {
     // partial rows are [blocks*4][2][C]: view as R = blocks*4 rows of 2C columns -> [2C] sums
     GN_REQUIRE(dbeta == dgamma + C, "gn_layernorm_bwd: dbeta must follow dgamma contiguously (flat gradient buffer layout)");
-    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk(2L * C)), dim3(256), 0, ctx->stream, (const float*)workspace, dgamma, 1, (int)(blocks * 4), 2 * C, 1);
+    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk(2L * C, 64)), dim3(256), 0, ctx->stream, (const float*)workspace, dgamma, 1, (int)(blocks * 4), 2 * C, 1);
     GN_LAUNCH_CHECK();
   }
   return GN_OK;
@@ -701,7 +751,7 @@ int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const vo
 
 int64_t gn_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
   int chunks = HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
-  return ((int64_t)B * chunks * 2 * C + (int64_t)B * C * 3) * 4;
+  return ((int64_t)B * chunks * 2 * C + (int64_t)B * C * 3 + (int64_t)B * C * 2) * 4;
 }
 /* fwd_ws: the forward's workspace (gn_groupnorm_workspace_bytes) still holding scsh[B][C][2]; stats: [B][G][2] (mean, rstd) */
 int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy, void* dx, void* dx2, const float* scsh, const float* stats,
@@ -717,6 +767,7 @@ int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy
   p.chunks = (p.HW + p.rows - 1) / p.rows;
   p.part = (float*)workspace;
   p.coef = p.part + (long)p.B * chunks * 2 * p.C;
+  p.sums = p.coef + (long)p.B * p.C * 3;
   hipLaunchKernelGGL(gnb_partial_kernel, dim3(p.chunks, p.B), dim3(256), 0, ctx->stream, p, scsh);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gnb_finalize_kernel, dim3(p.B), dim3(256), 0, ctx->stream, p, stats);
@@ -725,7 +776,7 @@ int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy
     hipLaunchKernelGGL(gnb_param_kernel, dim3(nblk(p.C)), dim3(256), 0, ctx->stream, p, stats);
     GN_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(gnb_apply_kernel, dim3(nblk((long)p.HW * p.C), p.B), dim3(256), 0, ctx->stream, p, scsh);
+  hipLaunchKernelGGL(gnb_apply_kernel, dim3(nblk((long)p.HW * (p.C / 8)), p.B), dim3(256), 0, ctx->stream, p, scsh);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -690,11 +690,16 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   int sk = d->splitk;
   if (sk <= 0) {
     sk = 1;
-    if (d->act != GN_ACT_GEGLU && d->out_mode != GN_OUT_BATCH_TRANSPOSED && d->batch <= 1 && blocks < 192 && K >= 1024) {
-      sk = (int)cdiv64(384, blocks);
+    if (d->act != GN_ACT_GEGLU && d->out_mode != GN_OUT_BATCH_TRANSPOSED && d->batch <= 1 &&
+        blocks < (d->out_mode == GN_OUT_F32 ? 512 : 192) && K >= 1024) {
+      // f32 output = weight gradients: a handful of output tiles under a reduction over every pixel of the batch (K up to 2^21), so
+      // the K split has to supply the parallelism; f16 outputs keep the inference limits (their summation order is part of the
+      // recorded results)
+      const bool wgrad = d->out_mode == GN_OUT_F32;
+      sk = (int)cdiv64(wgrad ? 1024 : 384, blocks);
       const int maxsk = (int)(K / 512);
       if (sk > maxsk) sk = maxsk;
-      if (sk > 16) sk = 16;
+      if (sk > (wgrad ? 256 : 16)) sk = wgrad ? 256 : 16;
       if (sk < 1) sk = 1;
     }
   }

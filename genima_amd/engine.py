@@ -226,7 +226,34 @@ class Engine:
             self.meta.append(dict(kind=kind, flops=2.0 * d.M * d.N * d.K, bytes=2.0 * (d.M * d.K / max(1, d.KH * d.KW if d.conv else 1) + d.N * d.K + d.M * n_out),
                                   shape=(int(d.M), int(d.N), int(d.K))))
         else:
+            self.run_gemm(d)
+
+    def run_gemm(self, d: GemmDesc):
+        """Eager launch; with ``self.gemm_log`` set (a list) each launch is bracketed by HIP events for the per-shape tables."""
+        log = getattr(self, "gemm_log", None)
+        if log is None:
             check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm")
+            return
+        e0, e1 = self.event(), self.event()
+        self.event_record(e0)
+        check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm")
+        self.event_record(e1)
+        log.append((self._tune_key(d) + f"|t{int(d.tile)}", 2.0 * d.M * d.N * d.K * max(1, d.batch), e0, e1))
+
+    def gemm_log_report(self):
+        """-> {key: (calls, total ms, TFLOP/s)} from the events collected in ``self.gemm_log`` (synchronises)."""
+        self.synchronize()
+        agg = {}
+        for key, fl, e0, e1 in self.gemm_log:
+            ms = self.event_elapsed_ms(e0, e1)
+            c = agg.setdefault(key, [0, 0.0, 0.0])
+            c[0] += 1
+            c[1] += ms
+            c[2] += fl
+            self.lib.gn_event_destroy(e0)
+            self.lib.gn_event_destroy(e1)
+        self.gemm_log = []
+        return {k: (c[0], c[1], c[2] / (c[1] * 1e9) if c[1] > 0 else 0.0) for k, c in agg.items()}
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
         """f32 split-K / GroupNorm scratch: one shared grow-only buffer (ops on one stream run in order)."""

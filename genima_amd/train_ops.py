@@ -40,7 +40,7 @@ def gemm(E: Engine, a, w, out, M: int, N: int, K: int, lda: int, ldw: int, ldo: 
     nb = int(E.lib.gn_gemm_workspace_bytes(C.byref(d)))
     if nb > 0:
         d.workspace = E._workspace(nb).data_ptr()
-    check(E.lib.gn_gemm(E._ctx, C.byref(d)), "gn_gemm")
+    E.run_gemm(d)
     return out
 
 
