@@ -58,6 +58,45 @@ TINY_CONTROLNET = dict(
     global_pool_conditions=False,
 )
 
+# ----------------------------------------------------------------------------- SDXL-Turbo family (BASELINE.json configs[4]; SURVEY Appendix A.5;
+# diffusion/train_controlnet_sdxl_genima.py:107, controller/agent/sdxl_controlnet_agent.py:36-42)
+SDXL_TURBO_UNET = dict(
+    SD_TURBO_UNET,
+    sample_size=64,  # 512x512 tiled observations -> 64x64 latents
+    block_out_channels=[320, 640, 1280],
+    down_block_types=["DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"],
+    up_block_types=["CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"],
+    attention_head_dim=[5, 10, 20],
+    transformer_layers_per_block=[1, 2, 10],
+    cross_attention_dim=2048,
+    addition_embed_type="text_time",
+    addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=2816,  # 6 time ids x 256 + pooled text 1280
+)
+SDXL_TURBO_CONTROLNET = dict(
+    {k: v for k, v in SDXL_TURBO_UNET.items() if k not in ("out_channels", "up_block_types")},
+    _class_name="ControlNetModel",
+    conditioning_channels=3,
+    conditioning_embedding_out_channels=[16, 32, 96, 256],
+    global_pool_conditions=False,
+)
+TINY_XL_UNET = dict(
+    SDXL_TURBO_UNET,
+    block_out_channels=[64, 128, 256],
+    attention_head_dim=[1, 2, 4],
+    transformer_layers_per_block=[1, 2, 3],
+    cross_attention_dim=192,
+    addition_time_embed_dim=32,
+    projection_class_embeddings_input_dim=6 * 32 + 128,
+    sample_size=32,
+)
+TINY_XL_CONTROLNET = dict(
+    {k: v for k, v in TINY_XL_UNET.items() if k not in ("out_channels", "up_block_types")},
+    _class_name="ControlNetModel",
+    conditioning_channels=3,
+    conditioning_embedding_out_channels=[16, 32, 96, 256],
+    global_pool_conditions=False,
+)
 # ----------------------------------------------------------------------------- AutoencoderKL
 SD_TURBO_VAE = {
     "_class_name": "AutoencoderKL",
@@ -72,6 +111,7 @@ SD_TURBO_VAE = {
     "sample_size": 768,
 }
 TINY_VAE = dict(SD_TURBO_VAE, block_out_channels=[32, 64, 64, 64], sample_size=128)
+SDXL_VAE = dict(SD_TURBO_VAE, scaling_factor=0.13025, sample_size=1024)  # madebyollin/sdxl-vae-fp16-fix: same architecture
 
 # ----------------------------------------------------------------------------- CLIP text towers
 SD_TURBO_TEXT = {  # OpenCLIP ViT-H/14 text tower truncated to 23 layers
@@ -88,6 +128,16 @@ SD_TURBO_TEXT = {  # OpenCLIP ViT-H/14 text tower truncated to 23 layers
 }
 TINY_TEXT = dict(SD_TURBO_TEXT, vocab_size=1024, hidden_size=128, intermediate_size=512,
                  num_hidden_layers=2, num_attention_heads=2)
+
+# SDXL's two towers (diffusion/train_controlnet_sdxl_genima.py:1027-1071): the penultimate hidden state of each is concatenated to
+# the 2048-wide cross-attention context, the pooled + projected bigG output is the `text_embeds` added condition (:879-893)
+SDXL_TEXT_L = dict(SD_TURBO_TEXT, hidden_size=768, intermediate_size=3072, num_hidden_layers=12, num_attention_heads=12,
+                   hidden_act="quick_gelu", projection_dim=0)
+SDXL_TEXT_G = dict(SD_TURBO_TEXT, _class_name="CLIPTextModelWithProjection", hidden_size=1280, intermediate_size=5120,
+                   num_hidden_layers=32, num_attention_heads=20, hidden_act="gelu", projection_dim=1280)
+TINY_XL_TEXT_L = dict(SDXL_TEXT_L, vocab_size=1024, hidden_size=64, intermediate_size=256, num_hidden_layers=2, num_attention_heads=1)
+TINY_XL_TEXT_G = dict(SDXL_TEXT_G, vocab_size=1024, hidden_size=128, intermediate_size=512, num_hidden_layers=3, num_attention_heads=2,
+                      projection_dim=128)
 
 ACT_CLIP_TEXT = {  # openai CLIP ViT-B/32 text tower (controller/method/genima_act.py:314-346)
     "_class_name": "CLIPTextModel",
@@ -148,6 +198,12 @@ def family(name: str) -> dict:
                    scheduler=SD_TURBO_SCHEDULER, act=ACT_POLICY, act_text=ACT_CLIP_TEXT)
     elif name == "tiny":
         fam = dict(unet=TINY_UNET, controlnet=TINY_CONTROLNET, vae=TINY_VAE, text=TINY_TEXT,
+                   scheduler=SD_TURBO_SCHEDULER, act=TINY_ACT_POLICY, act_text=TINY_ACT_CLIP_TEXT)
+    elif name == "sdxl-turbo":  # two text towers: text = CLIP-L, text_2 = OpenCLIP bigG with projection
+        fam = dict(unet=SDXL_TURBO_UNET, controlnet=SDXL_TURBO_CONTROLNET, vae=SDXL_VAE, text=SDXL_TEXT_L, text_2=SDXL_TEXT_G,
+                   scheduler=SD_TURBO_SCHEDULER, act=ACT_POLICY, act_text=ACT_CLIP_TEXT)
+    elif name == "tiny-xl":
+        fam = dict(unet=TINY_XL_UNET, controlnet=TINY_XL_CONTROLNET, vae=TINY_VAE, text=TINY_XL_TEXT_L, text_2=TINY_XL_TEXT_G,
                    scheduler=SD_TURBO_SCHEDULER, act=TINY_ACT_POLICY, act_text=TINY_ACT_CLIP_TEXT)
     else:
         raise KeyError(f"unknown model family {name!r}")

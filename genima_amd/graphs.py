@@ -30,13 +30,34 @@ def _heads(cfg, i):
 
 
 # ------------------------------------------------------------------------------------------------ time embedding
-def emit_time_shifts(E: Engine, W, cfg, t_dev: torch.Tensor) -> torch.Tensor:
-    """t_dev f32 [B] -> all ResNet time shifts [B, temb_total] (one GEMM for every ``time_emb_proj``)."""
+def emit_added_cond(E: Engine, cfg, added) -> torch.Tensor:
+    """SDXL ``text_time`` input of ``add_embedding``: cat(text_embeds [B, P] f16, sinusoid(time_ids [B, 6] f32)) -> [B, P + 6*dim]
+    (diffusion/train_controlnet_sdxl_genima.py:1236-1262).  Recordable: the concat is two strided device copies."""
+    text_embeds, time_ids = added
+    B, P = text_embeds.shape
+    dim = cfg["addition_time_embed_dim"]
+    te = E.timestep_embedding(time_ids.reshape(-1), dim, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0), name="a_sin")
+    n = P + 6 * dim
+    a = E.buf("a_cat", (B, n))
+    E.copy4d(text_embeds, a, (1, 1, 1, B), (0, 0, 0, text_embeds.stride(0)), (0, 0, 0, n), P)
+    E.copy4d(te, a[:, P:], (1, 1, 1, B), (0, 0, 0, 6 * dim), (0, 0, 0, n), 6 * dim)
+    return a
+
+
+def emit_time_shifts(E: Engine, W, cfg, t_dev: torch.Tensor, added=None) -> torch.Tensor:
+    """t_dev f32 [B] -> all ResNet time shifts [B, temb_total] (one GEMM for every ``time_emb_proj``).
+    ``added`` = (text_embeds, time_ids) for SDXL's ``addition_embed_type="text_time"``."""
     c0 = cfg["block_out_channels"][0]
     e = E.timestep_embedding(t_dev, c0, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0), name="t_sin")
     e = E.linear(e, W["time_embedding.linear_1.weight"], W["time_embedding.linear_1.bias"], act=ACT_SILU, name="t_l1")
-    # linear_2, then the SiLU every ResnetBlock2D applies to temb before its time_emb_proj
-    e = E.linear(e, W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"], act=ACT_SILU, name="t_l2")
+    if cfg.get("addition_embed_type") == "text_time":
+        emb = E.linear(e, W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"], name="t_l2")
+        a = E.linear(emit_added_cond(E, cfg, added), W["add_embedding.linear_1.weight"], W["add_embedding.linear_1.bias"], act=ACT_SILU, name="a_l1")
+        emb = E.linear(a, W["add_embedding.linear_2.weight"], W["add_embedding.linear_2.bias"], residual=emb, name="a_l2")
+        e = E.act(emb, ACT_SILU, name="t_act")
+    else:
+        # linear_2, then the SiLU every ResnetBlock2D applies to temb before its time_emb_proj
+        e = E.linear(e, W["time_embedding.linear_2.weight"], W["time_embedding.linear_2.bias"], act=ACT_SILU, name="t_l2")
     return E.linear(e, W["time_emb_proj_all.weight"], W["time_emb_proj_all.bias"], name="t_shifts")
 
 
@@ -129,11 +150,12 @@ def _emit_mid(E: Engine, W, cfg, h, shifts, kv):
 
 
 def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down_res: Optional[Sequence[torch.Tensor]] = None,
-              mid_res: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x8: scaled latents [B, H, W, 8] (channels >= in_channels zero).  Returns eps [B, H, W, 8] (first out_channels valid)."""
+              mid_res: Optional[torch.Tensor] = None, added=None) -> torch.Tensor:
+    """x8: scaled latents [B, H, W, 8] (channels >= in_channels zero).  Returns eps [B, H, W, 8] (first out_channels valid).
+    ``added`` = (text_embeds, time_ids): SDXL added conditions."""
     G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     with E.scope("unet"):
-        shifts = emit_time_shifts(E, W, cfg, t_dev)
+        shifts = emit_time_shifts(E, W, cfg, t_dev, added)
         h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         if down_res is not None:
@@ -166,10 +188,10 @@ def emit_controlnet_cond(E: Engine, W, cfg, cond8: torch.Tensor) -> torch.Tensor
         return E.conv2d(h, W[p + ".conv_out.weight"], W[p + ".conv_out.bias"], name="out")
 
 
-def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, conditioning_scale: float = 1.0):
-    """-> (list of 12 down residuals, mid residual), NHWC."""
+def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, conditioning_scale: float = 1.0, added=None):
+    """-> (list of down residuals (12 for SD-2.x, 9 for SDXL), mid residual), NHWC."""
     with E.scope("cn"):
-        shifts = emit_time_shifts(E, W, cfg, t_dev)
+        shifts = emit_time_shifts(E, W, cfg, t_dev, added)
         h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], residual=cond_emb, name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         h = _emit_mid(E, W, cfg, h, shifts, kv)
@@ -247,7 +269,7 @@ def emit_vae_encode_moments(E: Engine, W, cfg, x8: torch.Tensor) -> torch.Tensor
 
 
 # ------------------------------------------------------------------------------------------------ CLIP text tower
-def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor) -> torch.Tensor:
+def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor, hidden: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
     """ids int32 [B, L] -> last_hidden_state f16 [B, L, D] (after final_layer_norm)."""
     B, L = ids.shape
     heads = cfg["num_attention_heads"]
@@ -269,4 +291,19 @@ def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor) -> torch.Tensor:
                 n = E.layernorm(x, W[p + ".layer_norm2.weight"], W[p + ".layer_norm2.bias"], eps, name="ln2")
                 h = E.linear(n, W[p + ".mlp.fc1.weight"], W[p + ".mlp.fc1.bias"], act=act, name="fc1")
                 x = E.linear(h, W[p + ".mlp.fc2.weight"], W[p + ".mlp.fc2.bias"], residual=x, name="fc2")
+                if hidden is not None:
+                    hidden.append(x)
         return E.layernorm(x, W["text_model.final_layer_norm.weight"], W["text_model.final_layer_norm.bias"], eps, name="ln_f")
+
+
+def emit_clip_text_sdxl(E: Engine, W, cfg, ids: torch.Tensor):
+    """SDXL ``encode_prompt`` per tower (diffusion/train_controlnet_sdxl_genima.py:854-893): -> (hidden_states[-2] [B, L, D],
+    ``text_embeds`` [B, projection_dim] = text_projection(final_layer_norm(last)[eot]) for the projection tower, else None)."""
+    hidden: List[torch.Tensor] = []
+    last = emit_clip_text(E, W, cfg, ids, hidden)
+    pooled = None
+    if "text_projection.weight" in W:
+        with E.scope("clip_pool"):
+            eot = E.argmax_rows(ids, name="eot")
+            pooled = E.linear(E.gather_rows(last, eot, name="pooled"), W["text_projection.weight"], name="proj")
+    return hidden[-2], pooled

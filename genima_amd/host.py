@@ -167,12 +167,21 @@ def _t_dev(timestep, B, device) -> torch.Tensor:
     return t.to(device).contiguous()
 
 
+def _added(added_cond_kwargs, device):
+    """SDXL ``added_cond_kwargs={"text_embeds": [B, 1280], "time_ids": [B, 6]}`` (diffusion/train_controlnet_sdxl_genima.py:1448-1471)
+    -> the (text_embeds f16, time_ids f32) device pair the lowering takes."""
+    if not added_cond_kwargs:
+        return None
+    return (added_cond_kwargs["text_embeds"].to(device, torch.float16).contiguous(),
+            added_cond_kwargs["time_ids"].to(device, torch.float32).contiguous())
+
+
 class UNet2DConditionModel(HipModule):
     schema_fn = staticmethod(schema.unet_schema)
 
     def __call__(self, sample, timestep, encoder_hidden_states, down_block_additional_residuals=None,
-                 mid_block_additional_residual=None, return_dict=True, **kw):
-        """Call surface of diffusion/train_controlnet_genima.py:1377-1388 (NCHW tensors)."""
+                 mid_block_additional_residual=None, return_dict=True, added_cond_kwargs=None, **kw):
+        """Call surface of diffusion/train_controlnet_genima.py:1377-1388 (NCHW tensors); ``added_cond_kwargs`` for SDXL."""
         E = self.engine()
         B = sample.shape[0]
         x8 = nchw_to_nhwc(sample.to(self.device, torch.float16), 8)
@@ -182,7 +191,8 @@ class UNet2DConditionModel(HipModule):
         if down_block_additional_residuals is not None:
             down = [nchw_to_nhwc(r.to(self.device, torch.float16)) for r in down_block_additional_residuals]
         mid = None if mid_block_additional_residual is None else nchw_to_nhwc(mid_block_additional_residual.to(self.device, torch.float16))
-        eps = graphs.emit_unet(E, self.W, self.config, x8, _t_dev(timestep, B, self.device), kv, down, mid)
+        eps = graphs.emit_unet(E, self.W, self.config, x8, _t_dev(timestep, B, self.device), kv, down, mid,
+                               added=_added(added_cond_kwargs, self.device))
         out = nhwc_to_nchw(eps, self.config["out_channels"])
         return SimpleNamespace(sample=out) if return_dict else (out,)
 
@@ -210,8 +220,8 @@ class ControlNetModel(HipModule):
         return cls(cfg, sd)
 
     def __call__(self, sample, timestep, encoder_hidden_states, controlnet_cond, conditioning_scale=1.0, guess_mode=False,
-                 return_dict=True, **kw):
-        """Call surface of diffusion/train_controlnet_genima.py:1368-1374: -> (list of 12 down residuals, mid residual), NCHW."""
+                 return_dict=True, added_cond_kwargs=None, **kw):
+        """Call surface of diffusion/train_controlnet_genima.py:1368-1374: -> (list of 12 (SDXL: 9) down residuals, mid residual), NCHW."""
         E = self.engine()
         B = sample.shape[0]
         x8 = nchw_to_nhwc(sample.to(self.device, torch.float16), 8)
@@ -219,7 +229,8 @@ class ControlNetModel(HipModule):
         ctx = encoder_hidden_states.to(self.device, torch.float16).contiguous()
         kv = graphs.emit_cross_kv(E, self.W, ctx, "cn")
         cemb = graphs.emit_controlnet_cond(E, self.W, self.config, cond8)
-        outs, mid = graphs.emit_controlnet(E, self.W, self.config, x8, _t_dev(timestep, B, self.device), kv, cemb, conditioning_scale)
+        outs, mid = graphs.emit_controlnet(E, self.W, self.config, x8, _t_dev(timestep, B, self.device), kv, cemb, conditioning_scale,
+                                           added=_added(added_cond_kwargs, self.device))
         outs = [nhwc_to_nchw(o) for o in outs]
         mid = nhwc_to_nchw(mid)
         if return_dict:
@@ -263,7 +274,21 @@ class CLIPTextModel(HipModule):
     schema_fn = staticmethod(schema.clip_text_schema)
     weight_name = "model.safetensors"
 
-    def __call__(self, input_ids, attention_mask=None, **kw):
+    def __call__(self, input_ids, attention_mask=None, output_hidden_states=False, **kw):
+        """``text_encoder(ids)[0]`` (train_controlnet_genima.py:1362); with ``output_hidden_states=True`` the SDXL call of
+        train_controlnet_sdxl_genima.py:879-893: ``out[0]`` = last hidden state (or ``text_embeds`` for the projection tower),
+        ``out[-1][-2]`` = penultimate hidden state (only the last two entries of the hidden-state list are materialised)."""
         E = self.engine()
         ids = input_ids.to(self.device, torch.int32).contiguous()
-        return (graphs.emit_clip_text(E, self.W, self.config, ids),)
+        if not output_hidden_states:
+            return (graphs.emit_clip_text(E, self.W, self.config, ids),)
+        hidden = []
+        last = graphs.emit_clip_text(E, self.W, self.config, ids, hidden)
+        first = last
+        if "text_projection.weight" in self.W:
+            first = E.linear(E.gather_rows(last, E.argmax_rows(ids)), self.W["text_projection.weight"])
+        return (first, [None] * (len(hidden) - 1) + hidden[-2:])
+
+
+class CLIPTextModelWithProjection(CLIPTextModel):
+    """SDXL's second tower (OpenCLIP bigG): same encoder + ``text_projection`` on the EOT row."""

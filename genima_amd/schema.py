@@ -64,26 +64,35 @@ def _transformer2d(s, p, c, ctx_dim, n_layers=1):
     _linear(s, p + ".proj_out", c, c)
 
 
+def transformer_layers(cfg, level: int) -> int:
+    """``transformer_layers_per_block``: an int (SD-2.x: 1) or one entry per resolution level (SDXL: 1, 2, 10)."""
+    t = cfg.get("transformer_layers_per_block", 1)
+    return t[level] if isinstance(t, (list, tuple)) else t
+
+
 def _unet_encoder(s, cfg):
-    """conv_in + time embedding + down blocks + mid block (shared by UNet and ControlNet)."""
+    """conv_in + time (+ SDXL added-condition) embedding + down blocks + mid block (shared by UNet and ControlNet)."""
     boc = cfg["block_out_channels"]
     temb = boc[0] * 4
     ctx = cfg["cross_attention_dim"]
     _conv(s, "conv_in", cfg["in_channels"], boc[0], 3)
     _linear(s, "time_embedding.linear_1", boc[0], temb)
     _linear(s, "time_embedding.linear_2", temb, temb)
+    if cfg.get("addition_embed_type") == "text_time":  # SDXL micro-conditioning (SURVEY Appendix A.5)
+        _linear(s, "add_embedding.linear_1", cfg["projection_class_embeddings_input_dim"], temb)
+        _linear(s, "add_embedding.linear_2", temb, temb)
     cout = boc[0]
     for i, btype in enumerate(cfg["down_block_types"]):
         cin, cout = cout, boc[i]
         for j in range(cfg["layers_per_block"]):
             _resnet(s, f"down_blocks.{i}.resnets.{j}", cin if j == 0 else cout, cout, temb)
             if btype == "CrossAttnDownBlock2D":
-                _transformer2d(s, f"down_blocks.{i}.attentions.{j}", cout, ctx)
+                _transformer2d(s, f"down_blocks.{i}.attentions.{j}", cout, ctx, transformer_layers(cfg, i))
         if i != len(boc) - 1:
             _conv(s, f"down_blocks.{i}.downsamplers.0.conv", cout, cout, 3)
     c = boc[-1]
     _resnet(s, "mid_block.resnets.0", c, c, temb)
-    _transformer2d(s, "mid_block.attentions.0", c, ctx)
+    _transformer2d(s, "mid_block.attentions.0", c, ctx, transformer_layers(cfg, len(boc) - 1))
     _resnet(s, "mid_block.resnets.1", c, c, temb)
 
 
@@ -104,7 +113,7 @@ def unet_schema(cfg) -> "OrderedDict[str, Shape]":
             rin = prev if j == 0 else cout
             _resnet(s, f"up_blocks.{i}.resnets.{j}", rin + skip, cout, temb)
             if btype == "CrossAttnUpBlock2D":
-                _transformer2d(s, f"up_blocks.{i}.attentions.{j}", cout, ctx)
+                _transformer2d(s, f"up_blocks.{i}.attentions.{j}", cout, ctx, transformer_layers(cfg, len(boc) - 1 - i))
         if i != len(boc) - 1:
             _conv(s, f"up_blocks.{i}.upsamplers.0.conv", cout, cout, 3)
     _norm(s, "conv_norm_out", boc[0])

@@ -411,13 +411,19 @@ def t_transformer(g: Graph, net, p: str, x: Var, kv, heads: int, groups: int, nk
     return out.view(B, H, Wd, Cc)
 
 
-def t_time_shifts(g: Graph, net: TrainParams, cfg, t_dev: torch.Tensor, B: int) -> Var:
-    """Timestep MLP + every ResNet's time_emb_proj as one GEMM, with saved pre-activations (graphs.emit_time_shifts)."""
+def t_time_shifts(g: Graph, net: TrainParams, cfg, t_dev: torch.Tensor, B: int, added=None) -> Var:
+    """Timestep MLP (+ SDXL added-condition MLP) + every ResNet's time_emb_proj as one GEMM, with saved pre-activations
+    (graphs.emit_time_shifts)."""
     E = g.E
     c0 = cfg["block_out_channels"][0]
     e = Var(E.timestep_embedding(t_dev, c0, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0)), needs=False)
     z = g.act(g.linear(net, e, "time_embedding.linear_1.weight", "time_embedding.linear_1.bias"), ACT_SILU)
-    z = g.act(g.linear(net, z, "time_embedding.linear_2.weight", "time_embedding.linear_2.bias"), ACT_SILU)
+    emb = g.linear(net, z, "time_embedding.linear_2.weight", "time_embedding.linear_2.bias")
+    if cfg.get("addition_embed_type") == "text_time":
+        a = Var(graphs.emit_added_cond(E, cfg, added), needs=False)
+        a = g.act(g.linear(net, a, "add_embedding.linear_1.weight", "add_embedding.linear_1.bias"), ACT_SILU)
+        emb = g.linear(net, a, "add_embedding.linear_2.weight", "add_embedding.linear_2.bias", residual=emb)
+    z = g.act(emb, ACT_SILU)
     shifts = g.linear(net, z, "time_emb_proj_all.weight", "time_emb_proj_all.bias")
     # per-ResNet f32 accumulators of d(shift) = per-batch column sums of the conv1 output gradients, gathered once every ResNet ran
     net.dshift = {p: torch.zeros((B, n), dtype=F32, device=E.device) for p, (o, n) in net.temb_slices.items()}
@@ -453,11 +459,12 @@ def t_mid(g: Graph, net, cfg, h: Var, shifts, kv, nk_valid: int) -> Var:
 
 
 def t_controlnet(g: Graph, net: TrainParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx_pad: torch.Tensor, nk_valid: int,
-                 cond8: torch.Tensor):
-    """Trainable ControlNet forward (graphs.emit_controlnet_cond + emit_controlnet with every activation kept)."""
+                 cond8: torch.Tensor, added=None):
+    """Trainable ControlNet forward (graphs.emit_controlnet_cond + emit_controlnet with every activation kept).
+    ``added`` = (text_embeds, time_ids) for the SDXL family."""
     W = net.W
     B = x8.shape[0]
-    shifts = t_time_shifts(g, net, cfg, t_dev, B)
+    shifts = t_time_shifts(g, net, cfg, t_dev, B, added)
     kv = t_cross_kv(g, net, Var(ctx_pad, needs=False), _attn2_prefixes(W, ("down_blocks.", "mid_block.")))
     p = "controlnet_cond_embedding"
     h = g.act(g.conv(net, Var(cond8, needs=False), p + ".conv_in.weight", p + ".conv_in.bias"), ACT_SILU)
@@ -474,12 +481,12 @@ def t_controlnet(g: Graph, net: TrainParams, cfg, x8: torch.Tensor, t_dev: torch
 
 
 def t_unet(g: Graph, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx: torch.Tensor, ctx_pad: torch.Tensor,
-           nk_valid: int, down_res: Sequence[Var], mid_res: Var) -> Var:
+           nk_valid: int, down_res: Sequence[Var], mid_res: Var, added=None) -> Var:
     """Frozen UNet: encoder + mid through the fused inference lowering (no gradient flows there), decoder with activations kept
     so that d(loss)/d(residuals) reaches the ControlNet (diffusion/train_controlnet_genima.py:1377-1388)."""
     E, W = g.E, net.W
     G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
-    shifts = graphs.emit_time_shifts(E, W, cfg, t_dev)
+    shifts = graphs.emit_time_shifts(E, W, cfg, t_dev, added)
     kv_inf = graphs.emit_cross_kv(E, W, ctx, "unet_train")
     h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"])
     h, skips = graphs._emit_encoder(E, W, cfg, h, shifts, kv_inf)
@@ -536,15 +543,16 @@ class ControlNetTrainer:
         self.last = {}
 
     # ---- forward + backward: fills self.cn.grad (loss-scaled) and returns the device loss scalar
-    def forward_backward(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, c_valid: int = 4):
+    def forward_backward(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, c_valid: int = 4, added=None):
         """latents8 / noise8: f16 [B, h, w, 8] (channels >= c_valid zero); t_dev f32 [B] timesteps; sqrt_ac / sqrt_1mac f32 [B]
-        (DDPMScheduler.add_noise coefficients); ctx f16 [B, L, D] prompt states; cond8 f16 [B, H, W, 8] conditioning image in [0, 1]."""
+        (DDPMScheduler.add_noise coefficients); ctx f16 [B, L, D] prompt states; cond8 f16 [B, H, W, 8] conditioning image in [0, 1];
+        added = (text_embeds f16 [B, P], time_ids f32 [B, 6]) for the SDXL family (train_controlnet_sdxl_genima.py:1448-1471)."""
         E = self.E
         g = Graph(E)
         noisy = E.add_noise(latents8, noise8, sqrt_ac, sqrt_1mac)
         ctx_pad, L = pad_context(ctx), ctx.shape[1]
-        down, mid = t_controlnet(g, self.cn, self.cn_cfg, noisy, t_dev, ctx_pad, L, cond8)
-        pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid)
+        down, mid = t_controlnet(g, self.cn, self.cn_cfg, noisy, t_dev, ctx_pad, L, cond8, added)
+        pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid, added)
         loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale)
         pred.cell[0] = dpred
         g.backward()
@@ -580,8 +588,8 @@ class ControlNetTrainer:
             self._clean = 0
         return True
 
-    def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8) -> torch.Tensor:
-        loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8)
+    def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=None) -> torch.Tensor:
+        loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
         self.optimizer_step()
         self.update_scale()
         return loss

@@ -69,11 +69,22 @@ def timestep_embedding(t: Tensor, dim: int, flip_sin_to_cos=True, freq_shift=0.0
     return emb
 
 
-def time_embed(sd, cfg, t: Tensor, q=_id) -> Tensor:
+def time_embed(sd, cfg, t: Tensor, q=_id, added=None) -> Tensor:
+    """``added`` = (text_embeds [B, P], time_ids [B, 6]) for SDXL's ``addition_embed_type="text_time"`` (SURVEY Appendix A.5;
+    diffusion/train_controlnet_sdxl_genima.py:1236-1262): aug = add_embedding(cat(text_embeds, sinusoid(time_ids))), emb += aug."""
     c0 = cfg["block_out_channels"][0]
-    e = q(timestep_embedding(t, c0, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0)))
+    flip, shift = cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0)
+    e = q(timestep_embedding(t, c0, flip, shift))
     e = q(F.silu(linear(sd, "time_embedding.linear_1", e)))
-    return q(linear(sd, "time_embedding.linear_2", e))
+    emb = q(linear(sd, "time_embedding.linear_2", e))
+    if cfg.get("addition_embed_type") == "text_time":
+        text_embeds, time_ids = added
+        B = text_embeds.shape[0]
+        te = q(timestep_embedding(time_ids.reshape(-1), cfg["addition_time_embed_dim"], flip, shift)).reshape(B, -1)
+        a = q(torch.cat([text_embeds, te], dim=-1))
+        a = q(F.silu(linear(sd, "add_embedding.linear_1", a)))
+        emb = q(emb + linear(sd, "add_embedding.linear_2", a))
+    return emb
 
 
 # ----------------------------------------------------------------------------- blocks
@@ -170,12 +181,12 @@ def _mid(sd, cfg, h, emb, ctx, q=_id):
 
 def unet_forward(sd, cfg, sample: Tensor, t: Tensor, ctx: Tensor,
                  down_residuals: Optional[Sequence[Tensor]] = None, mid_residual: Optional[Tensor] = None,
-                 q=_id) -> Tensor:
+                 q=_id, added=None) -> Tensor:
     """``UNet2DConditionModel.forward(...).sample`` (call site diffusion/train_controlnet_genima.py:1377-1388)."""
     G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     if t.dim() == 0:
         t = t[None].expand(sample.shape[0])
-    emb = time_embed(sd, cfg, t, q)
+    emb = time_embed(sd, cfg, t, q, added)
     h = q(conv(sd, "conv_in", sample))
     h, skips = _encoder(sd, cfg, h, emb, ctx, q)
     if down_residuals is not None:
@@ -209,12 +220,12 @@ def controlnet_cond_embedding(sd, cfg, cond: Tensor, q=_id) -> Tensor:
 
 
 def controlnet_forward(sd, cfg, sample: Tensor, t: Tensor, ctx: Tensor, cond: Tensor,
-                       conditioning_scale: float = 1.0, q=_id) -> Tuple[List[Tensor], Tensor]:
+                       conditioning_scale: float = 1.0, q=_id, added=None) -> Tuple[List[Tensor], Tensor]:
     """``ControlNetModel.forward(..., return_dict=False)`` -> (12 down residuals, mid residual)
     (call site diffusion/train_controlnet_genima.py:1368-1374)."""
     if t.dim() == 0:
         t = t[None].expand(sample.shape[0])
-    emb = time_embed(sd, cfg, t, q)
+    emb = time_embed(sd, cfg, t, q, added)
     h = q(conv(sd, "conv_in", sample) + controlnet_cond_embedding(sd, cfg, cond, q))
     h, skips = _encoder(sd, cfg, h, emb, ctx, q)
     h = _mid(sd, cfg, h, emb, ctx, q)
@@ -285,7 +296,7 @@ def vae_postprocess_u8(img: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- CLIP text tower
-def clip_text_forward(sd, cfg, ids: Tensor, q=_id) -> Tensor:
+def clip_text_forward(sd, cfg, ids: Tensor, q=_id, hidden=None) -> Tensor:
     """transformers ``CLIPTextModel(ids)[0]`` = last_hidden_state after final_layer_norm
     (call site diffusion/train_controlnet_genima.py:1362)."""
     B, L = ids.shape
@@ -307,7 +318,22 @@ def clip_text_forward(sd, cfg, ids: Tensor, q=_id) -> Tensor:
         else:
             h = F.gelu(h)
         x = q(x + linear(sd, p + ".mlp.fc2", q(h)))
+        if hidden is not None:
+            hidden.append(x)
     return q(layer_norm(sd, "text_model.final_layer_norm", x, eps))
+
+
+def clip_text_penultimate_and_pooled(sd, cfg, ids: Tensor, q=_id):
+    """SDXL ``encode_prompt`` (diffusion/train_controlnet_sdxl_genima.py:854-893): ``text_encoder(ids, output_hidden_states=True)``
+    -> (hidden_states[-2] = the input of the last encoder layer, no final LayerNorm;  for CLIPTextModelWithProjection also
+    ``text_embeds`` = text_projection(final_layer_norm(last)[eot]), else None)."""
+    hidden = []
+    last = clip_text_forward(sd, cfg, ids, q, hidden)
+    pooled = None
+    if "text_projection.weight" in sd:
+        eot = ids.argmax(dim=-1)
+        pooled = q(last[torch.arange(last.shape[0]), eot] @ sd["text_projection.weight"].t())
+    return hidden[-2], pooled
 
 
 def clip_text_pooled_projection(sd, cfg, ids: Tensor, q=_id) -> Tensor:

@@ -1,0 +1,116 @@
+"""-m gpu: the SDXL-Turbo family deltas (diffusion/train_controlnet_sdxl_genima.py) on the tiny-xl configs
+(same topology: 3 levels, no attention at level 0, 1/2/3 transformer layers per block (1/2/10 at full size), text_time added conditions,
+two CLIP towers with penultimate-hidden-state context and pooled projection) against the CPU oracle: forward of both towers / ControlNet /
+UNet through the host classes, then the fine-tune step's loss and gradients.  Bars as in test_models_gpu.py / test_training_gpu.py."""
+import pytest
+import torch
+
+from genima_amd import configs, schema, weights
+from genima_amd.engine import Engine
+from genima_amd.host import CLIPTextModel, CLIPTextModelWithProjection, ControlNetModel, UNet2DConditionModel, nchw_to_nhwc
+from genima_amd.packing import pack_state_dict
+from genima_amd.scheduler import DDPMScheduler
+from genima_amd.training import ControlNetTrainer
+from oracle import sd_torch as O
+from oracle import train_torch as OT
+from util import q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FAM = configs.family("tiny-xl")
+
+
+def _r16(sd):
+    return weights.round_to(sd, torch.float16)
+
+
+def _ids(V, B=2):
+    ids = torch.zeros(B, 77, dtype=torch.int64)
+    ids[0, :14] = torch.tensor([V - 2] + [320 + i for i in range(12)] + [V - 1])
+    ids[1, :5] = torch.tensor([V - 2, 7, 8, 9, V - 1])
+    return ids[:B]
+
+
+def _close(name, y, ref16, ref32, tol16=3e-3, tol32=1e-2):
+    e16, e32, eref = rel_l2(y, ref16), rel_l2(y, ref32), rel_l2(ref16, ref32)
+    print(f"{name}: rel-L2 vs f16-storage oracle {e16:.2e}, vs fp32 oracle {e32:.2e} (f16-storage oracle vs fp32: {eref:.2e})")
+    assert torch.isfinite(y.float()).all()
+    assert e16 <= tol16 and e32 <= min(tol32, 1.5 * eref + 5e-4), name
+
+
+def test_sdxl_text_towers():
+    for key, cls, seed in (("text", CLIPTextModel, 5), ("text_2", CLIPTextModelWithProjection, 6)):
+        cfg = FAM[key]
+        sd = _r16(weights.synth_state_dict(schema.clip_text_schema(cfg), seed))
+        ids = _ids(cfg["vocab_size"])
+        out = cls(cfg, sd).to("cuda")(ids, output_hidden_states=True)
+        with torch.no_grad():
+            p16, e16 = O.clip_text_penultimate_and_pooled(sd, cfg, ids, q16)
+            p32, e32 = O.clip_text_penultimate_and_pooled(sd, cfg, ids)
+        _close(f"{key} hidden_states[-2]", out[-1][-2].float().cpu(), p16, p32, 1e-3, 3e-3)
+        if e32 is not None:
+            _close(f"{key} text_embeds", out[0].float().cpu(), e16, e32, 2e-3, 5e-3)
+
+
+def _inputs(B=2, seed=0):
+    ucfg = FAM["unet"]
+    g = torch.Generator().manual_seed(seed)
+    lat = q16(torch.randn(B, 4, 32, 32, generator=g))
+    noise = q16(torch.randn(B, 4, 32, 32, generator=g))
+    ctx = q16(torch.randn(B, 77, ucfg["cross_attention_dim"], generator=g))
+    cond = q16(torch.rand(B, 3, 256, 256, generator=g))
+    text_embeds = q16(torch.randn(B, ucfg["projection_class_embeddings_input_dim"] - 6 * ucfg["addition_time_embed_dim"], generator=g))
+    time_ids = torch.tensor([[256.0, 256.0, 0.0, 0.0, 256.0, 256.0]] * B)  # compute_embeddings: original size, crop, target size
+    t = torch.tensor([801, 399][:B])
+    return lat, noise, ctx, cond, (text_embeds, time_ids), t
+
+
+def test_sdxl_unet_and_controlnet_forward():
+    ucfg, ccfg = FAM["unet"], FAM["controlnet"]
+    usd = _r16(weights.synth_state_dict(schema.unet_schema(ucfg), 1))
+    csd = _r16(weights.synth_state_dict(schema.controlnet_schema(ccfg), 2))
+    unet, cn = UNet2DConditionModel(ucfg, usd).to("cuda"), ControlNetModel(ccfg, csd).to("cuda")
+    x, _, ctx, cond, added, t = _inputs()
+    tf = t.float()
+    kw = dict(added_cond_kwargs={"text_embeds": added[0], "time_ids": added[1]})
+    down, mid = cn(x.half(), tf, ctx.half(), cond.half(), return_dict=False, **kw)
+    assert len(down) == 9  # SDXL: 3 levels -> 9 skips
+    with torch.no_grad():
+        d16, m16 = O.controlnet_forward(csd, ccfg, x, tf, ctx, cond, q=q16, added=added)
+        d32, m32 = O.controlnet_forward(csd, ccfg, x, tf, ctx, cond, added=added)
+    for i, (a, b, c) in enumerate(zip(down, d16, d32)):
+        _close(f"xl controlnet down[{i}]", a.float().cpu(), b, c)
+    _close("xl controlnet mid", mid.float().cpu(), m16, m32)
+    eps = unet(x.half(), tf, ctx.half(), [d.half() for d in d16], m16.half(), **kw).sample
+    with torch.no_grad():
+        e16 = O.unet_forward(usd, ucfg, x, tf, ctx, [q16(d) for d in d16], q16(m16), q=q16, added=added)
+        e32 = O.unet_forward(usd, ucfg, x, tf, ctx, [q16(d) for d in d16], q16(m16), added=added)
+    _close("xl unet eps", eps.float().cpu(), e16, e32)
+
+
+def test_sdxl_controlnet_train_step():
+    ucfg, ccfg = FAM["unet"], FAM["controlnet"]
+    usd = _r16(weights.synth_state_dict(schema.unet_schema(ucfg), 1))
+    csd = _r16(weights.synth_state_dict(schema.controlnet_schema(ccfg), 2))
+    lat, noise, ctx, cond, added, t = _inputs()
+    sa, s1 = DDPMScheduler().add_noise_coeffs(t)
+    S = 4096.0
+    tr = ControlNetTrainer(Engine("cuda:0"), ucfg, ccfg, pack_state_dict(usd, "cuda"), csd, lr=1e-4, loss_scale=S)
+    dev = lambda x: x.cuda()  # noqa: E731
+    loss = float(tr.forward_backward(dev(nchw_to_nhwc(lat, 8).half()), dev(nchw_to_nhwc(noise, 8).half()), dev(t.float()), dev(sa), dev(s1),
+                                     dev(ctx.half()), dev(nchw_to_nhwc(cond, 8).half()), added=(dev(added[0].half()), dev(added[1]))).cpu())
+    layout = list(tr.cn.layout)
+    assert any(n.startswith("add_embedding.") for n in layout)
+    g_hip = torch.cat([(tr.cn.G[n].float() / S).reshape(-1).cpu() for n in layout])
+    l32, g32, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond, added=added)
+    l16, g16, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond, q=q16, added=added)
+    P32, P16 = pack_state_dict(g32, "cpu", dtype=torch.float32), pack_state_dict(g16, "cpu", dtype=torch.float32)
+    f32_, f16_ = (torch.cat([P[n].reshape(-1).float() for n in layout]) for P in (P32, P16))
+    e, eref = rel_l2(g_hip, f32_), rel_l2(f16_, f32_)
+    print(f"xl loss hip {loss:.6f} oracle {float(l32):.6f}; flat gradient rel-L2 vs fp32 oracle {e:.2e} (f16-storage oracle: {eref:.2e})")
+    assert abs(loss - float(l32)) <= 2e-3 * float(l32)
+    assert e <= min(1e-2, 1.5 * eref + 2e-3)
+    gn = float(f32_.double().norm())
+    for n in layout:
+        if n.startswith("add_embedding."):
+            assert float((tr.cn.G[n].float().cpu() / S - P32[n]).double().norm()) <= 2e-2 * float(P32[n].double().norm()) + 1e-4 * gn, n
