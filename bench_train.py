@@ -28,7 +28,9 @@ import torch  # noqa: E402
 
 MFMA_PEAK_TF = 2500.0
 # algorithmic TFLOP per sample: forward 2.25 (VAE-enc 1.13, CN 0.33, UNet 0.80 at 64x64 latents) + backward 1.37
-TFLOP_PER_SAMPLE = {512: 2.25 + 1.37}
+TFLOP_PER_SAMPLE = {("sd-turbo", 512): 2.25 + 1.37,
+                    # SDXL ControlNet fine-tune at 512x512: forward 3.42 + backward 3.01 TFLOP per sample
+                    ("sdxl-turbo", 512): 3.42 + 3.01}
 
 
 def main():
@@ -66,7 +68,9 @@ def main():
     tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet_W, cn_sd, lr=args.lr,
                            allreduce=dist.allreduce_mean_flat if world > 1 else None)
     del cn_sd
-    tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank)
+    text2_W = pack_state_dict(synth(schema.clip_text_schema(fam["text_2"]), 5), dev) if "text_2" in fam else None
+    tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank,
+                     text2_cfg=fam.get("text_2"), text2_W=text2_W)
 
     B, R = args.batch, args.resolution
     g = torch.Generator(device=dev).manual_seed(77 + rank)
@@ -103,20 +107,23 @@ def main():
     if rank == 0:
         save_tune_table()
         ms = dt / args.steps * 1e3
-        tf = TFLOP_PER_SAMPLE.get(R)
+        tf = TFLOP_PER_SAMPLE.get((args.family, R))
         achieved = tf * B * args.steps / dt if tf else None
         line = {
             "metric": "ControlNet train steps/sec", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic (seeded random-init SD-Turbo weights, uniform random images, fixed 14-token prompt)",
+            "data": f"synthetic (seeded random-init {args.family} weights, uniform random images, fixed 14-token prompt)",
             "samples_per_sec": B * world * args.steps / dt,
-            "config": {"workload": "BASELINE.json configs[3]: SD-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views)",
+            "config": {"workload": ("BASELINE.json configs[4]: SDXL-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views), f16 (fp8 MFMA not built yet)"
+                                    if args.family == "sdxl-turbo" else
+                                    "BASELINE.json configs[3]: SD-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views)"),
+                       "family": args.family,
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master, f16 compute, loss scale",
                        "trainable_params_padded": int(tr.cn.numel)},
             "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "grad_norm_last": tr.last.get("grad_norm"),
             "loss_scale": tr.loss_scale, "applied_steps": tr.opt_step,
             "roofline": ({"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TF,
-                          "traffic": None, "note": "whole step, algorithmic FLOPs of SURVEY.md row a12 (3.62 TFLOP per sample)"}
+                          "traffic": None, "note": f"whole step, algorithmic FLOPs of SURVEY.md section 8 ({tf} TFLOP per sample)"}
                          if achieved else None),
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         }

@@ -636,9 +636,11 @@ class ControlNetTrainer:
         return int(gstep)
 
     # ---- the whole step body from a collated batch (VAE encode + text encode + noise sampling in front of step())
-    def attach_frozen(self, vae_cfg, vae_W, text_cfg, text_W, noise_scheduler, seed: int = 0):
-        """Frozen fp16 VAE / CLIP text tower (packed weights) and the DDPMScheduler (diffusion/train_controlnet_genima.py:1038-1060)."""
+    def attach_frozen(self, vae_cfg, vae_W, text_cfg, text_W, noise_scheduler, seed: int = 0, text2_cfg=None, text2_W=None):
+        """Frozen fp16 VAE / CLIP text tower(s) (packed weights) and the DDPMScheduler (diffusion/train_controlnet_genima.py:1038-1060;
+        SDXL: the second, projection tower of train_controlnet_sdxl_genima.py:1027-1071 as ``text2_*``)."""
         self.vae_cfg, self.vae_W, self.text_cfg, self.text_W, self.noise_scheduler = vae_cfg, vae_W, text_cfg, text_W, noise_scheduler
+        self.text2_cfg, self.text2_W = text2_cfg, text2_W
         self._gen_dev = torch.Generator(device=self.E.device).manual_seed(seed)
         self._gen_cpu = torch.Generator().manual_seed(seed)
 
@@ -664,5 +666,19 @@ class ControlNetTrainer:
         noise8 = E.scale_pad(torch.randn(shape, generator=self._gen_dev, device=dev, dtype=F32).to(F16), 1.0, 8)
         t = torch.randint(0, int(self.noise_scheduler.config.num_train_timesteps), (B,), generator=self._gen_cpu)
         sa, s1 = self.noise_scheduler.add_noise_coeffs(t)
-        ctx = graphs.emit_clip_text(E, self.text_W, self.text_cfg, ids)
-        return self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8)
+        added = None
+        if getattr(self, "text2_W", None) is None:
+            ctx = graphs.emit_clip_text(E, self.text_W, self.text_cfg, ids)
+        else:
+            # SDXL encode_prompt + compute_embeddings (train_controlnet_sdxl_genima.py:854-893, 1232-1262): context = the two towers'
+            # penultimate states side by side, added conditions = pooled projection + (original size, crop, target size)
+            ids2 = batch.get("input_ids_2", batch["input_ids"]).to(dev, torch.int32).contiguous()
+            pen_l, _ = graphs.emit_clip_text_sdxl(E, self.text_W, self.text_cfg, ids)
+            pen_g, pooled = graphs.emit_clip_text_sdxl(E, self.text2_W, self.text2_cfg, ids2)
+            L, dl, dg = pen_l.shape[1], pen_l.shape[2], pen_g.shape[2]
+            ctx = torch.empty((B, L, dl + dg), dtype=F16, device=dev)
+            E.copy4d(pen_l, ctx, (1, 1, B, L), (0, 0, L * dl, dl), (0, 0, L * (dl + dg), dl + dg), dl)
+            E.copy4d(pen_g, ctx[:, :, dl:], (1, 1, B, L), (0, 0, L * dg, dg), (0, 0, L * (dl + dg), dl + dg), dg)
+            R = float(x8.shape[1])
+            added = (pooled, torch.tensor([[R, R, 0.0, 0.0, R, R]] * B, dtype=F32, device=dev))
+        return self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8, added)
