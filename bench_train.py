@@ -7,7 +7,8 @@
 Workload = BASELINE.json configs[3]: train_controlnet_genima.py SD-Turbo fine-tune at 512x512 (4 tiled 256x256 views), per-GPU
 batch 8 (global batch 64 on 8 GPUs), data parallel with one RCCL all-reduce of the flat 1.46 GB fp32 gradient buffer per step.
 A "step" is the whole step body of diffusion/train_controlnet_genima.py:1317-1408 on one synthetic batch already resident in HBM:
-VAE encode + posterior sample, noise / timestep sampling, CLIP text encode, ControlNet forward, frozen UNet forward, MSE, backward
+device-side augmentation (colour jitter + shared reflect-pad crop, README recipe), VAE encode + posterior sample, noise / timestep
+sampling, CLIP text encode, ControlNet forward, frozen UNet forward, MSE, backward
 (ControlNet dX + dW, UNet decoder dX), gradient all-reduce, unscale + global-norm clip, AdamW, f16 weight refresh, zero_grad.
 Weights are seeded random-init tensors of the full SD-Turbo architecture (no checkpoints offline); the ControlNet uses random
 (non-zero) output convs so that every gradient path carries real work.  Same JSON-line contract as bench.py (rank 0 prints it).
@@ -42,6 +43,7 @@ def main():
     ap.add_argument("--resolution", type=int, default=512)
     ap.add_argument("--family", default="sd-turbo")
     ap.add_argument("--lr", type=float, default=1e-5)
+    ap.add_argument("--augmentations", default="crop,colorjitter", help="the reference's --augmentations list (README.md:204); '' disables")
     ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
     args = ap.parse_args()
 
@@ -70,7 +72,7 @@ def main():
     del cn_sd
     text2_W = pack_state_dict(synth(schema.clip_text_schema(fam["text_2"]), 5), dev) if "text_2" in fam else None
     tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank,
-                     text2_cfg=fam.get("text_2"), text2_W=text2_W)
+                     text2_cfg=fam.get("text_2"), text2_W=text2_W, augmentations=args.augmentations or None)
 
     B, R = args.batch, args.resolution
     g = torch.Generator(device=dev).manual_seed(77 + rank)

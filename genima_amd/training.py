@@ -636,11 +636,13 @@ class ControlNetTrainer:
         return int(gstep)
 
     # ---- the whole step body from a collated batch (VAE encode + text encode + noise sampling in front of step())
-    def attach_frozen(self, vae_cfg, vae_W, text_cfg, text_W, noise_scheduler, seed: int = 0, text2_cfg=None, text2_W=None):
+    def attach_frozen(self, vae_cfg, vae_W, text_cfg, text_W, noise_scheduler, seed: int = 0, text2_cfg=None, text2_W=None,
+                      augmentations: Optional[str] = None):
         """Frozen fp16 VAE / CLIP text tower(s) (packed weights) and the DDPMScheduler (diffusion/train_controlnet_genima.py:1038-1060;
         SDXL: the second, projection tower of train_controlnet_sdxl_genima.py:1027-1071 as ``text2_*``)."""
         self.vae_cfg, self.vae_W, self.text_cfg, self.text_W, self.noise_scheduler = vae_cfg, vae_W, text_cfg, text_W, noise_scheduler
         self.text2_cfg, self.text2_W = text2_cfg, text2_W
+        self.augmentations = augmentations  # the reference's --augmentations comma list ("crop,colorjitter" in the README recipe)
         self._gen_dev = torch.Generator(device=self.E.device).manual_seed(seed)
         self._gen_cpu = torch.Generator().manual_seed(seed)
 
@@ -656,6 +658,10 @@ class ControlNetTrainer:
         E, dev = self.E, self.E.device
         x8 = self._nhwc8(batch["pixel_values"])
         cond8 = self._nhwc8(batch["conditioning_pixel_values"])
+        if self.augmentations:  # augment_data(args, batch) (:1321): colour jitter on the conditioning image, shared reflect-pad crop
+            from .augment import augment_data
+            aug = augment_data(E, self.augmentations, dict(pixel_values=x8, conditioning_pixel_values=cond8), self._gen_cpu)
+            x8, cond8 = aug["pixel_values"], aug["conditioning_pixel_values"]
         ids = batch["input_ids"].to(dev, torch.int32).contiguous()
         B = x8.shape[0]
         Cl = self.vae_cfg["latent_channels"]

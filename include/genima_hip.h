@@ -236,6 +236,17 @@ int32_t gn_latent_sample(gn_ctx* ctx, const void* moments, const void* eps, void
 int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n);
 int32_t gn_fill_f32(gn_ctx* ctx, float* x, int64_t n, float v);
 
+/* ---- train-time augmentation on the device (diffusion/train_controlnet_genima.py:775-830, README `--augmentations=crop,colorjitter`) --
+ * gn_color_jitter: torchvision ColorJitter's four adjust_* ops on [B, HW, ld] f16 RGB pixels in [0, 1], applied in `order`
+ * (op ids 0 brightness, 1 contrast, 2 saturation, 3 hue = ColorJitter.get_params' fn_idx) with `factors[id]`; f32 colour math,
+ * adjust_contrast's per-image grey mean by a deterministic two-stage sum.  out may alias x.
+ * gn_reflect_pad_crop: F.pad(mode="reflect", pad on all sides) + crop of the original H x W at (crop_i, crop_j). */
+int64_t gn_color_jitter_workspace_bytes(int32_t B);
+int32_t gn_color_jitter(gn_ctx* ctx, const void* x, void* out, int32_t B, int64_t HW, int32_t ld, const int32_t* order,
+                        const float* factors, void* workspace);
+int32_t gn_reflect_pad_crop(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad,
+                            int32_t crop_i, int32_t crop_j);
+
 /* ---- op programs: record once, replay on the stream (eagerly or as a captured hipGraph) ---------------------------
  * The host classes (UNet2DConditionModel / ControlNetModel / AutoencoderKL / pipeline) lower a forward pass to a flat list of
  * the ops above with all buffers pre-allocated, so the 5-step denoise loop runs without returning to Python. */
