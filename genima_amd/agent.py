@@ -101,3 +101,31 @@ class SDControlNetAgent(DiffusionAgent):
         return self.pipe(prompt=kwargs["prompts"], image=kwargs["images"], negative_prompt=kwargs.get("negative_prompts"),
                          num_inference_steps=kwargs["num_inference_steps"], guidance_scale=kwargs["guidance_scale"],
                          generator=kwargs.get("generator"))
+
+
+class SDXLControlNetAgent(SDControlNetAgent):
+    """SDXL-Turbo + ControlNet agent (controller/agent/sdxl_controlnet_agent.py:11-76): same checkpoint resolution and ``infer``
+    contract; the pipeline class carries the SDXL deltas.  ``autoencoder: taesdxl`` (AutoencoderTiny) is not built."""
+
+    def load_checkpoint(self):
+        from .pipeline import StableDiffusionXLControlNetPipeline
+
+        cfg = self.eval_cfg
+        if "taesdxl" in str(getattr(cfg, "autoencoder", "")):
+            raise NotImplementedError("AutoencoderTiny (taesdxl) is not built on the HIP path; use the SDXL AutoencoderKL")
+        ckpt = cfg.diffusion_ckpt
+        controlnet = None
+        if ckpt and os.path.isdir(ckpt):
+            dirs = sorted([d for d in os.listdir(ckpt) if "checkpoint" in d], key=_natural_key)
+            cn_dir = os.path.join(ckpt, dirs[-1], "controlnet") if dirs else ckpt
+            if os.path.exists(os.path.join(cn_dir, "config.json")):
+                controlnet = ControlNetModel.from_pretrained(cn_dir)
+        if cfg.sd_ckpt and os.path.isdir(str(cfg.sd_ckpt)):
+            self.pipe = StableDiffusionXLControlNetPipeline.from_pretrained(cfg.sd_ckpt, controlnet=controlnet)
+        elif str(cfg.sd_ckpt).startswith("synthetic:"):
+            self.pipe = StableDiffusionXLControlNetPipeline.from_synthetic(configs.family(str(cfg.sd_ckpt).split(":", 1)[1]))
+            if controlnet is not None:
+                self.pipe.controlnet = controlnet
+        else:
+            raise FileNotFoundError(f"sd_ckpt {cfg.sd_ckpt!r} is not a local diffusers directory (no network access); "
+                                    "use a local path or 'synthetic:<family>'")

@@ -19,7 +19,7 @@ namespace {
 
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
-  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX
+  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE
 };
 
 struct GenericArgs {  // argument block of the small ops
@@ -71,6 +71,7 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_GATHER_ROWS: return gn_gather_rows(ctx, g.p0, (const int32_t*)g.p1, g.p3, g.i0, g.i1, g.i2);
     case OP_COPY4D: return gn_copy4d(ctx, g.p0, g.p3, g.m, g.m + 4, g.m + 8, g.i0);
     case OP_ARGMAX: return gn_argmax_rows_i32(ctx, (const int32_t*)g.p0, (int32_t*)g.p3, g.i0, g.i1);
+    case OP_ADD_NOISE: return gn_add_noise(ctx, g.p0, g.p1, (const float*)g.p2, (const float*)(uintptr_t)g.m[0], g.p3, g.i0, g.n0);
     default: gn_set_error("gn_program: unknown op type %d", op.type); return GN_ERR_INVALID;
   }
 }
@@ -229,6 +230,12 @@ int32_t gn_program_add_copy4d(gn_program* p, const void* in, void* out, const in
 }
 int32_t gn_program_add_argmax_rows_i32(gn_program* p, const int32_t* x, int32_t* out, int32_t rows, int32_t cols) {
   return push_generic(p, OP_ARGMAX, x, nullptr, nullptr, out, 0, 0, rows, cols, 0, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_add_noise(gn_program* p, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac, void* out, int32_t B,
+                                 int64_t per_sample) {
+  const int32_t rc = push_generic(p, OP_ADD_NOISE, x0, noise, sqrt_ac, out, per_sample, 0, B, 0, 0, 0, 0.f, 0.f);
+  if (rc == GN_OK) p->ops.back().g.m[0] = (int64_t)(uintptr_t)sqrt_1mac;
+  return rc;
 }
 int64_t gn_program_num_ops(const gn_program* p) { return p ? (int64_t)p->ops.size() : 0; }
 

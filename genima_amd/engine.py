@@ -422,10 +422,13 @@ class Engine:
         self._small("euler_step", (x, eps), _ptr(x), _ptr(eps), x.numel() // Cc, Cc, eps.stride(-2), float(sigma), float(sigma_next))
         return x
 
-    def add_noise(self, x0, noise, sqrt_ac, sqrt_1mac, *, name=None):
-        out = self.buf(name, x0.shape)
+    def add_noise(self, x0, noise, sqrt_ac, sqrt_1mac, *, out=None, name=None):
+        """out[b] = sqrt_ac[b] * x0[b] + sqrt_1mac[b] * noise[b] (DDPM add_noise; also the ancestral sampler's x + sigma_up * noise);
+        out may alias x0."""
+        if out is None:
+            out = self.buf(name, x0.shape)
         B = x0.shape[0]
-        check(self.lib.gn_add_noise(self._ctx, _ptr(x0), _ptr(noise), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), B, x0.numel() // B), "gn_add_noise")
+        self._small("add_noise", (x0, noise, sqrt_ac, sqrt_1mac, out), _ptr(x0), _ptr(noise), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), B, x0.numel() // B)
         return out
 
     def image_u8_to_f16(self, img: torch.Tensor, cpad: int = 8, mul: float = 1.0, add: float = 0.0, *, out=None, name=None):

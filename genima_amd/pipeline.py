@@ -149,6 +149,13 @@ class StableDiffusionControlNetPipeline:
         self._progs.clear()
 
     # ---- program construction -----------------------------------------------------------------------------------------------
+    def _emit_prompt(self, E: Engine, io, B: int, L: int, H: int, W: int):
+        """-> (cross-attention context [B, L, D], added conditions or None).  SD-2.x: the single tower's last hidden state."""
+        return graphs.emit_clip_text(E, self.text_encoder.W, self.text_encoder.config, io.ids), None
+
+    def _fill_prompt_inputs(self, io, kw):
+        """Per-call inputs beyond ids / image / noise (SDXL: the second tower's ids)."""
+
     def _build(self, B: int, H: int, W: int, steps: int):
         dev = self.device
         E = Engine(dev, record=True)
@@ -166,20 +173,33 @@ class StableDiffusionControlNetPipeline:
         io.timesteps = [int(t) for t in sch.timesteps.tolist()]
         E.scale_pad(io.noise, sch.init_noise_sigma, Cl, out=io.latents)  # latents = randn * init_noise_sigma
 
-        ctx = graphs.emit_clip_text(E, self.text_encoder.W, self.text_encoder.config, io.ids)
+        ctx, added = self._emit_prompt(E, io, B, L, H, W)
         kv_cn = graphs.emit_cross_kv(E, self.controlnet.W, ctx, "cn")
         kv_un = graphs.emit_cross_kv(E, self.unet.W, ctx, "unet")
         cond8 = E.image_u8_to_f16(io.image_u8, 8, 1.0, 0.0, name="cond8")  # VaeImageProcessor(do_normalize=False)
         cemb = graphs.emit_controlnet_cond(E, self.controlnet.W, self.controlnet.config, cond8)
+        ancestral = getattr(sch, "ancestral", False)
+        if ancestral:  # EulerAncestral: fresh unit noise per step, scaled by sigma_up on the device
+            io.step_noise = E.buf("in_step_noise", (steps, B, h, w, Cl), zero=True)
+            ones = torch.ones(B, dtype=torch.float32, device=dev)
+            E._keepalive(ones)
         io.first_step_op = E.num_ops
         for i in range(steps):
             sigma, sigma_next = float(sch.sigmas[i]), float(sch.sigmas[i + 1])
             t_dev = torch.full((B,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
             E._keepalive(t_dev)
             x8 = E.scale_pad(io.latents, sch.input_scale(i), 8, name="x8")
-            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0)
-            eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid)
-            E.euler_step(io.latents, eps, sigma, sigma_next)
+            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0, added=added)
+            eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid, added=added)
+            if ancestral:
+                sigma_down, sigma_up = sch.ancestral_sigmas(i)
+                E.euler_step(io.latents, eps, sigma, sigma_down)
+                if sigma_up > 0.0:
+                    up = torch.full((B,), sigma_up, dtype=torch.float32, device=dev)
+                    E._keepalive(up)
+                    E.add_noise(io.latents, io.step_noise[i], ones, up, out=io.latents)
+            else:
+                E.euler_step(io.latents, eps, sigma, sigma_next)
             if i == 0:
                 io.ops_per_step = E.num_ops - io.first_step_op
         io.first_vae_op = E.num_ops
@@ -249,11 +269,16 @@ class StableDiffusionControlNetPipeline:
             latents = randn_latents((B, C, H // s, W // s), generator, self.device)
         else:
             latents = latents.to(self.device, torch.float16)  # unit-variance, scaled by init_noise_sigma on the device
-        if sch.draws_step_noise and generator is not None:
+        step_noise = getattr(io, "step_noise", None)
+        if step_noise is not None:  # ancestral sampler: the per-step draws are used (same order as diffusers: latents, then one per step)
+            for i in range(num_inference_steps):
+                step_noise[i].copy_(randn_latents((B, C, H // s, W // s), generator, self.device).permute(0, 2, 3, 1))
+        elif sch.draws_step_noise and generator is not None:
             for _ in range(num_inference_steps):  # mirror diffusers 0.29.0's per-step (unused) randn draw
                 randn_latents((B, C, H // s, W // s), generator, self.device)
         stream = getattr(io, "stream", None)
         cur = torch.cuda.current_stream(self.device)
+        self._fill_prompt_inputs(io, kw)
         io.ids.copy_(prompt_ids.to(torch.int32), non_blocking=False)
         io.image_u8.copy_(img_u8)
         io.noise.copy_(latents.permute(0, 2, 3, 1))
@@ -278,3 +303,83 @@ class StableDiffusionControlNetPipeline:
 
                 images = [Image.fromarray(a) for a in arr]
         return PipelineOutput(images) if return_dict else (images, None)
+
+
+class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
+    """SDXL(-Turbo) + ControlNet (controller/agent/sdxl_controlnet_agent.py:36-42, 67-76): two CLIP towers whose penultimate hidden
+    states form the 2048-wide context, ``text_embeds`` + ``time_ids`` added conditions on both networks, EulerAncestral sampling.
+    Same recorded-program execution as the SD-2.x pipeline; call surface ``pipe(prompt=, image=, negative_prompt=,
+    num_inference_steps=, guidance_scale=, generator=)`` plus ``prompt_2`` / ``prompt_ids_2``."""
+
+    def __init__(self, vae, text_encoder, text_encoder_2, tokenizer, tokenizer_2, unet, controlnet, scheduler, **kw):
+        super().__init__(vae, text_encoder, tokenizer, unet, controlnet, scheduler, **kw)
+        self.text_encoder_2 = text_encoder_2
+        self.tokenizer_2 = tokenizer_2 or HashTokenizer(text_encoder_2.config["vocab_size"])
+
+    @classmethod
+    def from_pretrained(cls, path, controlnet=None, safety_checker=None, torch_dtype=None, variant=None, **kw):
+        """diffusers SDXL pipeline directory: ``unet/ vae/ text_encoder/ text_encoder_2/ scheduler/``."""
+        import json
+        import os
+
+        from .host import CLIPTextModelWithProjection
+        from .scheduler import EulerAncestralDiscreteScheduler
+
+        unet = UNet2DConditionModel.from_pretrained(path, "unet")
+        vae = AutoencoderKL.from_pretrained(path, "vae")
+        text = CLIPTextModel.from_pretrained(path, "text_encoder")
+        text2 = CLIPTextModelWithProjection.from_pretrained(path, "text_encoder_2")
+        with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
+            cfg = json.load(f)
+        sched_cls = EulerAncestralDiscreteScheduler if "Ancestral" in cfg.get("_class_name", "EulerAncestral") else EulerDiscreteScheduler
+        if controlnet is None:
+            controlnet = ControlNetModel.from_unet(unet)
+        return cls(vae, text, text2, None, None, unet, controlnet, sched_cls.from_config(cfg))
+
+    @classmethod
+    def from_synthetic(cls, family: dict, seed: int = 0, gen_device="cpu"):
+        from .host import CLIPTextModelWithProjection
+        from .scheduler import EulerAncestralDiscreteScheduler
+
+        unet = UNet2DConditionModel.from_config(family["unet"], seed + 1, gen_device)
+        cn = ControlNetModel.from_config(family["controlnet"], seed + 2, gen_device)
+        vae = AutoencoderKL.from_config(family["vae"], seed + 3, gen_device)
+        text = CLIPTextModel.from_config(family["text"], seed + 4, gen_device)
+        text2 = CLIPTextModelWithProjection.from_config(family["text_2"], seed + 5, gen_device)
+        return cls(vae, text, text2, None, None, unet, cn, EulerAncestralDiscreteScheduler.from_config(family["scheduler"]))
+
+    def to(self, device=None, *a, **k):
+        if device is not None and not isinstance(device, torch.dtype):
+            self.text_encoder_2.to(device)
+        return super().to(device, *a, **k)
+
+    def _emit_prompt(self, E: Engine, io, B: int, L: int, H: int, W: int):
+        io.ids2 = E.buf("in_ids2", (B, L), dtype=torch.int32, zero=True)
+        with E.scope("te1"):
+            pen_l, _ = graphs.emit_clip_text_sdxl(E, self.text_encoder.W, self.text_encoder.config, io.ids)
+        with E.scope("te2"):
+            pen_g, pooled = graphs.emit_clip_text_sdxl(E, self.text_encoder_2.W, self.text_encoder_2.config, io.ids2)
+        dl, dg = pen_l.shape[2], pen_g.shape[2]
+        ctx = E.buf("ctx_cat", (B, L, dl + dg))
+        E.copy4d(pen_l, ctx, (1, 1, B, L), (0, 0, L * dl, dl), (0, 0, L * (dl + dg), dl + dg), dl)
+        E.copy4d(pen_g, ctx[:, :, dl:], (1, 1, B, L), (0, 0, L * dg, dg), (0, 0, L * (dl + dg), dl + dg), dg)
+        # _get_add_time_ids(original_size=(H, W), crops_coords_top_left=(0, 0), target_size=(H, W))
+        time_ids = torch.tensor([[float(H), float(W), 0.0, 0.0, float(H), float(W)]] * B, dtype=torch.float32, device=self.device)
+        E._keepalive(time_ids)
+        return ctx, (pooled, time_ids)
+
+    def _fill_prompt_inputs(self, io, kw):
+        ids2 = kw.get("prompt_ids_2")
+        if ids2 is None:
+            p2 = kw.get("prompt_2")
+            ids2 = self._ids_1 if p2 is None else self.tokenizer_2(p2, padding="max_length", max_length=77, truncation=True,
+                                                                   return_tensors="pt").input_ids
+        io.ids2.copy_(ids2.to(torch.int32))
+
+    def __call__(self, prompt=None, image=None, prompt_ids=None, **kw):
+        if prompt_ids is None:
+            prompt_ids = self.encode_ids(prompt)
+        self._ids_1 = prompt_ids  # the reference passes one prompt: both tokenizers see the same text
+        if kw.get("prompt_ids_2") is None and kw.get("prompt_2") is None and prompt is not None:
+            kw["prompt_2"] = prompt
+        return super().__call__(prompt=prompt, image=image, prompt_ids=prompt_ids, **kw)

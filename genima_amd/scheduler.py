@@ -89,6 +89,27 @@ class EulerDiscreteScheduler:
         return float(1.0 / (s * s + 1.0) ** 0.5)
 
 
+class EulerAncestralDiscreteScheduler(EulerDiscreteScheduler):
+    """sdxl-turbo's default sampler: same sigma table / trailing timesteps / input scaling as
+    EulerDiscrete, but every step lands on sigma_down and re-injects fresh unit noise scaled by sigma_up:
+        sigma_up   = sqrt(sigma_to^2 * (sigma_from^2 - sigma_to^2) / sigma_from^2),   sigma_down = sqrt(sigma_to^2 - sigma_up^2)
+        x <- x + eps * (sigma_down - sigma_from) + noise * sigma_up            (diffusers EulerAncestralDiscreteScheduler.step)."""
+    ancestral = True
+
+    @property
+    def init_noise_sigma(self) -> float:
+        smax = float(self.sigmas.max()) if self.sigmas is not None else float(self._train_sigmas.max())
+        if self.config.timestep_spacing in ("linspace", "trailing"):
+            return smax
+        return float((smax ** 2 + 1) ** 0.5)
+
+    def ancestral_sigmas(self, i: int):
+        s_from, s_to = float(self.sigmas[i]), float(self.sigmas[i + 1])
+        up = (s_to ** 2 * (s_from ** 2 - s_to ** 2) / s_from ** 2) ** 0.5
+        down = (s_to ** 2 - up ** 2) ** 0.5
+        return float(down), float(up)
+
+
 class DDPMScheduler:
     """Training-side noise scheduler: ``add_noise`` coefficients + config (diffusion/train_controlnet_genima.py:1350-1399)."""
 

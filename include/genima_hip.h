@@ -267,6 +267,8 @@ int32_t gn_program_add_image_f16_to_u8(gn_program* p, const void* in, uint8_t* o
 int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad,
                                        float mul, float add);
 int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n);
+int32_t gn_program_add_add_noise(gn_program* p, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac,
+                                 void* out, int32_t B, int64_t per_sample);
 int32_t gn_program_add_act(gn_program* p, const void* x, void* out, int64_t n, int32_t act);
 int32_t gn_program_add_embedding(gn_program* p, const int32_t* ids, const void* tok, const void* pos, void* out,
                                  int32_t B, int32_t L, int32_t D);

@@ -88,6 +88,57 @@ def test_sdxl_unet_and_controlnet_forward():
     _close("xl unet eps", eps.float().cpu(), e16, e32)
 
 
+def test_sdxl_pipeline_end_to_end():
+    """StableDiffusionXLControlNetPipeline (two towers -> context + added conditions, EulerAncestral with per-step noise) against the
+    oracle restating the same chain; the per-step noise comes from the same CPU generator on both sides."""
+    import numpy as np
+
+    from genima_amd.pipeline import StableDiffusionXLControlNetPipeline
+
+    pipe = StableDiffusionXLControlNetPipeline.from_synthetic(FAM, seed=30)
+    for m in (pipe.vae, pipe.text_encoder, pipe.text_encoder_2, pipe.unet, pipe.controlnet):
+        m.load_state_dict(_r16(m.state_dict()))
+    pipe.to("cuda")
+    B, steps, R = 2, 3, 256
+    img_u8 = torch.from_numpy(weights.counter_bytes(5, "xl_ctrl", B * R * R * 3).reshape(B, R, R, 3))
+    ids = _ids(FAM["text"]["vocab_size"])
+    lat = q16(torch.randn(B, 4, R // 8, R // 8, generator=torch.Generator().manual_seed(2)))
+    out = pipe(prompt_ids=ids, prompt_ids_2=ids, image=img_u8, num_inference_steps=steps, guidance_scale=0.0, latents=lat.half(),
+               generator=torch.Generator().manual_seed(11), output_type="np")
+    assert out.images.shape == (B, R, R, 3) and out.images.dtype == np.uint8
+    lat_hip = pipe.program(B, R, R, steps).latents.permute(0, 3, 1, 2).float().cpu()
+
+    def oracle(q):
+        g = torch.Generator().manual_seed(11)
+        sch = pipe.scheduler
+        sch.set_timesteps(steps)
+        tl, tg = pipe.text_encoder.state_dict(), pipe.text_encoder_2.state_dict()
+        pl, _ = O.clip_text_penultimate_and_pooled(tl, FAM["text"], ids, q)
+        pg, pooled = O.clip_text_penultimate_and_pooled(tg, FAM["text_2"], ids, q)
+        ctx = torch.cat([pl, pg], -1)
+        added = (pooled, torch.tensor([[float(R), float(R), 0.0, 0.0, float(R), float(R)]] * B))
+        cond = img_u8.permute(0, 3, 1, 2).float() / 255.0
+        x = q(lat * sch.init_noise_sigma)
+        usd, csd = pipe.unet.state_dict(), pipe.controlnet.state_dict()
+        for i in range(steps):
+            t = torch.full((B,), float(sch.timesteps[i]))
+            xin = q(x * sch.input_scale(i))
+            down, mid = O.controlnet_forward(csd, FAM["controlnet"], xin, t, ctx, q(cond), q=q, added=added)
+            eps = O.unet_forward(usd, FAM["unet"], xin, t, ctx, down, mid, q=q, added=added)
+            s_down, s_up = sch.ancestral_sigmas(i)
+            noise = torch.randn(B, 4, R // 8, R // 8, generator=g, dtype=torch.float16).float()
+            x = q(x + eps * (s_down - float(sch.sigmas[i])))
+            if s_up > 0:
+                x = q(x + noise * s_up)
+        return x
+
+    with torch.no_grad():
+        x16, x32 = oracle(q16), oracle(lambda t: t)
+    e16, e32, eref = rel_l2(lat_hip, x16), rel_l2(lat_hip, x32), rel_l2(x16, x32)
+    print(f"xl pipeline latents: rel-L2 vs f16-storage oracle {e16:.2e}, vs fp32 oracle {e32:.2e} (f16-storage oracle vs fp32: {eref:.2e})")
+    assert e16 <= 5e-3 and e32 <= min(3e-2, 1.5 * eref + 1e-3)
+
+
 def test_sdxl_controlnet_train_step():
     ucfg, ccfg = FAM["unet"], FAM["controlnet"]
     usd = _r16(weights.synth_state_dict(schema.unet_schema(ucfg), 1))
