@@ -179,13 +179,21 @@ class StableDiffusionControlNetPipeline:
         cond8 = E.image_u8_to_f16(io.image_u8, 8, 1.0, 0.0, name="cond8")  # VaeImageProcessor(do_normalize=False)
         cemb = graphs.emit_controlnet_cond(E, self.controlnet.W, self.controlnet.config, cond8)
         ancestral = getattr(sch, "ancestral", False)
-        if ancestral:  # EulerAncestral: fresh unit noise per step, scaled by sigma_up on the device
+        linear = getattr(sch, "sampler", "euler") == "linear"  # DDPM / DDIM (log_validation's train-scheduler swap): x <- A x + B eps + C z
+        coeffs = [sch.step_coeffs(i) for i in range(steps)] if linear else None
+        if ancestral or (linear and any(c[2] > 0.0 for c in coeffs)):  # fresh unit noise per step, scaled on the device
             io.step_noise = E.buf("in_step_noise", (steps, B, h, w, Cl), zero=True)
-            ones = torch.ones(B, dtype=torch.float32, device=dev)
-            E._keepalive(ones)
+        ones = torch.ones(B, dtype=torch.float32, device=dev)
+        zeros = torch.zeros(B, dtype=torch.float32, device=dev)
+        E._keepalive(ones, zeros)
+
+        def scalar(v):
+            t = torch.full((B,), float(v), dtype=torch.float32, device=dev)
+            E._keepalive(t)
+            return t
         io.first_step_op = E.num_ops
         for i in range(steps):
-            sigma, sigma_next = float(sch.sigmas[i]), float(sch.sigmas[i + 1])
+            sigma, sigma_next = (0.0, 0.0) if linear else (float(sch.sigmas[i]), float(sch.sigmas[i + 1]))
             t_dev = torch.full((B,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
             E._keepalive(t_dev)
             x8 = E.scale_pad(io.latents, sch.input_scale(i), 8, name="x8")
@@ -195,9 +203,13 @@ class StableDiffusionControlNetPipeline:
                 sigma_down, sigma_up = sch.ancestral_sigmas(i)
                 E.euler_step(io.latents, eps, sigma, sigma_down)
                 if sigma_up > 0.0:
-                    up = torch.full((B,), sigma_up, dtype=torch.float32, device=dev)
-                    E._keepalive(up)
-                    E.add_noise(io.latents, io.step_noise[i], ones, up, out=io.latents)
+                    E.add_noise(io.latents, io.step_noise[i], ones, scalar(sigma_up), out=io.latents)
+            elif linear:
+                A, Bc, Cn = coeffs[i]
+                E.add_noise(io.latents, io.latents, scalar(A), zeros, out=io.latents)   # x <- A x
+                E.euler_step(io.latents, eps, 1.0, 1.0 + Bc)                             # x <- x + B eps
+                if Cn > 0.0:
+                    E.add_noise(io.latents, io.step_noise[i], ones, scalar(Cn), out=io.latents)
             else:
                 E.euler_step(io.latents, eps, sigma, sigma_next)
             if i == 0:

@@ -122,3 +122,78 @@ class DDPMScheduler:
     def add_noise_coeffs(self, timesteps: torch.Tensor):
         ac = self.alphas_cumprod[timesteps.to("cpu", torch.long)]
         return (ac ** 0.5).to(torch.float32), ((1 - ac) ** 0.5).to(torch.float32)
+
+    # ---- sampling side: ``log_validation`` swaps the TRAINING scheduler class into the pipeline and runs 4 steps
+    # (diffusion/train_controlnet_genima.py:545-553, 631-638).  Epsilon prediction without sample clipping, so a step is linear in
+    # (x, eps, noise): x <- A x + B eps + C z; the pipeline lowers it to the scale / euler-step / add-noise kernels.
+    sampler = "linear"
+    ancestral = False
+    draws_step_noise = True
+    init_noise_sigma = 1.0
+
+    @classmethod
+    def from_config(cls, cfg, **kw):
+        d = dict(vars(cfg)) if isinstance(cfg, SimpleNamespace) else dict(cfg)
+        d.update(kw)
+        d.pop("_class_name", None)
+        d.pop("_diffusers_version", None)
+        return cls(**d)
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        n = self.config.num_train_timesteps
+        sp = self.config.get("timestep_spacing", "leading")
+        if sp == "trailing":
+            ts = np.round(np.arange(n, 0, -n / num_inference_steps)) - 1
+        elif sp == "leading":
+            ts = (np.arange(0, num_inference_steps) * (n // num_inference_steps)).round()[::-1].copy() + self.config.get("steps_offset", 0)
+        elif sp == "linspace":
+            ts = np.linspace(0, n - 1, num_inference_steps).round()[::-1].copy()
+        else:
+            raise ValueError(sp)
+        if self.config.get("clip_sample", False) or self.config.get("thresholding", False):
+            raise NotImplementedError("clip_sample / thresholding make the DDPM / DDIM step non-linear; SD-family configs set them to false")
+        if self.config.get("prediction_type", "epsilon") != "epsilon":
+            raise NotImplementedError("only epsilon prediction is on the Genima path")
+        self.num_inference_steps = num_inference_steps
+        self.timesteps = torch.from_numpy(ts.astype(np.int64))
+        return self
+
+    def input_scale(self, i: int) -> float:
+        return 1.0
+
+    def _alphas(self, i: int):
+        t = int(self.timesteps[i])
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self._final_alpha_cumprod()
+        return t, a_t, a_prev
+
+    def _final_alpha_cumprod(self) -> float:
+        return 1.0
+
+    def step_coeffs(self, i: int):
+        """diffusers DDPMScheduler.step, variance_type "fixed_small": -> (A, B, C)."""
+        t, a_t, a_prev = self._alphas(i)
+        b_t, b_prev = 1.0 - a_t, 1.0 - a_prev
+        cur_a = a_t / a_prev
+        cur_b = 1.0 - cur_a
+        c_x0 = a_prev ** 0.5 * cur_b / b_t
+        c_xt = cur_a ** 0.5 * b_prev / b_t
+        var = max(b_prev / b_t * cur_b, 1e-20)
+        return c_x0 / a_t ** 0.5 + c_xt, -c_x0 * b_t ** 0.5 / a_t ** 0.5, (var ** 0.5 if t > 0 else 0.0)
+
+
+class DDIMScheduler(DDPMScheduler):
+    """diffusers DDIMScheduler.step with eta = 0 (deterministic): x <- sqrt(a_prev) x0 + sqrt(1 - a_prev) eps."""
+    draws_step_noise = False
+
+    def __init__(self, **cfg):
+        super().__init__(**cfg)
+        self.config._class_name = "DDIMScheduler"
+
+    def _final_alpha_cumprod(self) -> float:
+        return 1.0 if self.config.get("set_alpha_to_one", True) else float(self.alphas_cumprod[0])
+
+    def step_coeffs(self, i: int):
+        t, a_t, a_prev = self._alphas(i)
+        return (a_prev / a_t) ** 0.5, (1.0 - a_prev) ** 0.5 - (a_prev * (1.0 - a_t) / a_t) ** 0.5, 0.0

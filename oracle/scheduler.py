@@ -82,3 +82,34 @@ def ddpm_add_noise(cfg, x0: np.ndarray, noise: np.ndarray, t: np.ndarray) -> np.
     a, b = ddpm_add_noise_coeffs(cfg, t)
     shp = (-1,) + (1,) * (x0.ndim - 1)
     return a.reshape(shp) * x0 + b.reshape(shp) * noise
+
+
+# ---- samplers log_validation swaps in (diffusion/train_controlnet_genima.py:545-553): the published step() of diffusers' DDPMScheduler
+# (variance_type "fixed_small", clip_sample False) and DDIMScheduler (eta 0), written out un-folded (x0 prediction first).
+def trailing_timesteps(cfg, num_inference_steps: int) -> np.ndarray:
+    n = cfg["num_train_timesteps"]
+    return (np.round(np.arange(n, 0, -n / num_inference_steps)) - 1).astype(np.int64)
+
+
+def _prev_alphas(cfg, t: int, num_inference_steps: int, final_alpha: float):
+    ac = alphas_cumprod(cfg).astype(np.float64)
+    prev_t = t - cfg["num_train_timesteps"] // num_inference_steps
+    return float(ac[t]), float(ac[prev_t] if prev_t >= 0 else final_alpha)
+
+
+def ddpm_step(cfg, eps, t: int, x, noise, num_inference_steps: int):
+    a_t, a_prev = _prev_alphas(cfg, t, num_inference_steps, 1.0)
+    b_t, b_prev = 1 - a_t, 1 - a_prev
+    cur_a = a_t / a_prev
+    cur_b = 1 - cur_a
+    x0 = (x - b_t ** 0.5 * eps) / a_t ** 0.5
+    mean = (a_prev ** 0.5 * cur_b / b_t) * x0 + (cur_a ** 0.5 * b_prev / b_t) * x
+    var = max(b_prev / b_t * cur_b, 1e-20)
+    return mean + (var ** 0.5) * noise if t > 0 else mean
+
+
+def ddim_step(cfg, eps, t: int, x, num_inference_steps: int, set_alpha_to_one: bool = True):
+    final = 1.0 if set_alpha_to_one else float(alphas_cumprod(cfg)[0])
+    a_t, a_prev = _prev_alphas(cfg, t, num_inference_steps, final)
+    x0 = (x - (1 - a_t) ** 0.5 * eps) / a_t ** 0.5
+    return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
