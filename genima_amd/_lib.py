@@ -138,6 +138,9 @@ SIGNATURES = {
     "gn_program_add_euler_step": (_I32, [_P, _P, _P, _I64, _I32, _I32, _F, _F]),
     "gn_program_add_image_f16_to_u8": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_program_add_image_u8_to_f16": (_I32, [_P, _P, _P, _I64, _I32, _F, _F]),
+    "gn_program_add_fork": (_I32, [_P]),
+    "gn_program_add_main": (_I32, [_P]),
+    "gn_program_add_join": (_I32, [_P]),
     "gn_program_add_add": (_I32, [_P, _P, _P, _P, _I64]),
     "gn_program_add_add_noise": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I64]),
     "gn_program_add_act": (_I32, [_P, _P, _P, _I64, _I32]),

@@ -19,7 +19,8 @@ namespace {
 
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
-  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE
+  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE,
+  OP_FORK, OP_MAIN, OP_JOIN  // stream control: ops after FORK go to the program's side stream until MAIN; JOIN makes main wait for it
 };
 
 struct GenericArgs {  // argument block of the small ops
@@ -48,6 +49,8 @@ struct gn_program {
   std::vector<Op> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  hipStream_t side = nullptr;          // second stream for independent sub-graphs (ControlNet next to the UNet encoder)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static int32_t run_op(gn_ctx* ctx, const Op& op) {
@@ -142,6 +145,9 @@ int32_t gn_program_destroy(gn_program* p) {
   if (p) {
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+    if (p->ev_join) (void)hipEventDestroy(p->ev_join);
+    if (p->side) (void)hipStreamDestroy(p->side);
     delete p;
   }
   return GN_OK;
@@ -237,23 +243,66 @@ int32_t gn_program_add_add_noise(gn_program* p, const void* x0, const void* nois
   if (rc == GN_OK) p->ops.back().g.m[0] = (int64_t)(uintptr_t)sqrt_1mac;
   return rc;
 }
+int32_t gn_program_add_fork(gn_program* p) { return push_generic(p, OP_FORK, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0.f, 0.f); }
+int32_t gn_program_add_main(gn_program* p) { return push_generic(p, OP_MAIN, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0.f, 0.f); }
+int32_t gn_program_add_join(gn_program* p) { return push_generic(p, OP_JOIN, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0.f, 0.f); }
 int64_t gn_program_num_ops(const gn_program* p) { return p ? (int64_t)p->ops.size() : 0; }
+
+static int32_t ensure_side_stream(gn_program* p) {
+  if (!p->side) {
+    GN_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+    GN_HIP(hipEventCreateWithFlags(&p->ev_fork, hipEventDisableTiming));
+    GN_HIP(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming));
+  }
+  return GN_OK;
+}
 
 int32_t gn_program_run(gn_program* p, int64_t first, int64_t last) {
   GN_REQUIRE(p, "gn_program_run: null program");
   const int64_t n = (int64_t)p->ops.size();
   if (last < 0 || last > n) last = n;
   GN_REQUIRE(first >= 0 && first <= last, "gn_program_run: bad range [%ld, %ld)", (long)first, (long)last);
-  for (int64_t i = first; i < last; ++i) {
-    int32_t rc = run_op(p->ctx, p->ops[(size_t)i]);
+  // stream-control ops only act on whole-program replays; a sub-range (per-op timing) runs serially on the context's stream
+  const bool two_streams = first == 0 && last == n;
+  hipStream_t main_stream = p->ctx->stream;
+  bool forked = false;  // side stream has work the main stream has not waited for
+  int32_t rc = GN_OK;
+  for (int64_t i = first; i < last && rc == GN_OK; ++i) {
+    const Op& op = p->ops[(size_t)i];
+    if (op.type == OP_FORK || op.type == OP_MAIN || op.type == OP_JOIN) {
+      if (!two_streams) continue;
+      if (op.type == OP_FORK) {
+        rc = ensure_side_stream(p);
+        if (rc != GN_OK) break;
+        if (hipEventRecord(p->ev_fork, main_stream) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) {
+          gn_set_error("gn_program_run: fork failed"); rc = GN_ERR_HIP; break;
+        }
+        p->ctx->stream = p->side;
+        forked = true;
+      } else if (op.type == OP_MAIN) {
+        p->ctx->stream = main_stream;
+      } else if (forked) {
+        p->ctx->stream = main_stream;
+        if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(main_stream, p->ev_join, 0) != hipSuccess) {
+          gn_set_error("gn_program_run: join failed"); rc = GN_ERR_HIP; break;
+        }
+        forked = false;
+      }
+      continue;
+    }
+    rc = run_op(p->ctx, op);
     if (rc != GN_OK) {
       char tmp[900];
       snprintf(tmp, sizeof(tmp), "%s", g_err);
-      gn_set_error("op %ld (type %d): %s", (long)i, p->ops[(size_t)i].type, tmp);
-      return rc;
+      gn_set_error("op %ld (type %d): %s", (long)i, op.type, tmp);
     }
   }
-  return GN_OK;
+  p->ctx->stream = main_stream;
+  if (forked) {  // never leave the side stream dangling (also required to end a stream capture)
+    (void)hipEventRecord(p->ev_join, p->side);
+    (void)hipStreamWaitEvent(main_stream, p->ev_join, 0);
+  }
+  return rc;
 }
 
 int32_t gn_program_capture(gn_program* p) {

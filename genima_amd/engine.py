@@ -256,15 +256,37 @@ class Engine:
         return {k: (c[0], c[1], c[2] / (c[1] * 1e9) if c[1] > 0 else 0.0) for k, c in agg.items()}
 
     def _workspace(self, nbytes: int) -> torch.Tensor:
-        """f32 split-K / GroupNorm scratch: one shared grow-only buffer (ops on one stream run in order)."""
+        """f32 split-K / GroupNorm scratch: one shared grow-only buffer per stream (ops on one stream run in order)."""
         n = _round_up(nbytes, 256) // 4
-        cur = self.buffers.get("__workspace__")
+        key = "__workspace_side__" if getattr(self, "_on_side", False) else "__workspace__"
+        cur = self.buffers.get(key)
         if cur is None or cur.numel() < n:
             if self.record and cur is not None:
                 self._keep.append(cur)  # earlier recorded ops still point at the old buffer
             cur = torch.empty(max(n, 1 << 20), dtype=torch.float32, device=self.device)
-            self.buffers["__workspace__"] = cur
+            self.buffers[key] = cur
         return cur
+
+    # ---- two-stream sections of a recorded program (gn_program_add_fork / main / join); no-ops when executing eagerly
+    def fork(self):
+        """Ops recorded from here run on the program's side stream (after everything recorded so far)."""
+        if self.record:
+            check(self.lib.gn_program_add_fork(self._prog), "gn_program_add_fork")
+            self.meta.append(dict(kind="stream", flops=0.0, bytes=0.0, shape=()))  # meta stays index-aligned with the op list
+            self._on_side = True
+
+    def main(self):
+        """Back to the main stream; the side stream keeps running concurrently until join()."""
+        if self.record:
+            check(self.lib.gn_program_add_main(self._prog), "gn_program_add_main")
+            self.meta.append(dict(kind="stream", flops=0.0, bytes=0.0, shape=()))
+            self._on_side = False
+
+    def join(self):
+        if self.record:
+            check(self.lib.gn_program_add_join(self._prog), "gn_program_add_join")
+            self.meta.append(dict(kind="stream", flops=0.0, bytes=0.0, shape=()))
+            self._on_side = False
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,

@@ -150,17 +150,21 @@ def _emit_mid(E: Engine, W, cfg, h, shifts, kv):
 
 
 def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down_res: Optional[Sequence[torch.Tensor]] = None,
-              mid_res: Optional[torch.Tensor] = None, added=None) -> torch.Tensor:
+              mid_res: Optional[torch.Tensor] = None, added=None, before_residuals=None) -> torch.Tensor:
     """x8: scaled latents [B, H, W, 8] (channels >= in_channels zero).  Returns eps [B, H, W, 8] (first out_channels valid).
-    ``added`` = (text_embeds, time_ids): SDXL added conditions."""
+    ``added`` = (text_embeds, time_ids): SDXL added conditions.  ``before_residuals``: called once the encoder and mid block are
+    emitted and before the first ControlNet residual is consumed (the pipeline joins the ControlNet's stream there)."""
     G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     with E.scope("unet"):
         shifts = emit_time_shifts(E, W, cfg, t_dev, added)
         h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
+        h = _emit_mid(E, W, cfg, h, shifts, kv)
+        if before_residuals is not None:
+            before_residuals()
+        # the residual adds only feed the decoder, so they sit after the mid block (same values; lets the encoder + mid overlap the ControlNet)
         if down_res is not None:
             skips = [E.add(s, r, name=f"skip_add{i}") for i, (s, r) in enumerate(zip(skips, down_res))]
-        h = _emit_mid(E, W, cfg, h, shifts, kv)
         if mid_res is not None:
             h = E.add(h, mid_res, name="mid_add")
         nlev = len(cfg["block_out_channels"])

@@ -11,6 +11,7 @@ conditioning embedding.
 """
 from __future__ import annotations
 
+import os
 import zlib
 from types import SimpleNamespace
 from typing import List, Optional, Sequence, Union
@@ -84,6 +85,7 @@ class StableDiffusionControlNetPipeline:
         self.device = torch.device("cpu")
         self._progs = {}
         self.use_graph = False
+        self.two_streams = os.environ.get("GN_TWO_STREAMS", "1") != "0"  # ControlNet || UNet encoder inside each denoise step
         self._progress = True
 
     # ---- construction ----------------------------------------------------------------------------------------------
@@ -173,11 +175,17 @@ class StableDiffusionControlNetPipeline:
         io.timesteps = [int(t) for t in sch.timesteps.tolist()]
         E.scale_pad(io.noise, sch.init_noise_sigma, Cl, out=io.latents)  # latents = randn * init_noise_sigma
 
+        if self.two_streams:  # the conditioning-image embedding (512x512 convs) is independent of the text tower + K/V hoists
+            E.fork()
+        cond8 = E.image_u8_to_f16(io.image_u8, 8, 1.0, 0.0, name="cond8")  # VaeImageProcessor(do_normalize=False)
+        cemb = graphs.emit_controlnet_cond(E, self.controlnet.W, self.controlnet.config, cond8)
+        if self.two_streams:
+            E.main()
         ctx, added = self._emit_prompt(E, io, B, L, H, W)
         kv_cn = graphs.emit_cross_kv(E, self.controlnet.W, ctx, "cn")
         kv_un = graphs.emit_cross_kv(E, self.unet.W, ctx, "unet")
-        cond8 = E.image_u8_to_f16(io.image_u8, 8, 1.0, 0.0, name="cond8")  # VaeImageProcessor(do_normalize=False)
-        cemb = graphs.emit_controlnet_cond(E, self.controlnet.W, self.controlnet.config, cond8)
+        if self.two_streams:
+            E.join()
         ancestral = getattr(sch, "ancestral", False)
         linear = getattr(sch, "sampler", "euler") == "linear"  # DDPM / DDIM (log_validation's train-scheduler swap): x <- A x + B eps + C z
         coeffs = [sch.step_coeffs(i) for i in range(steps)] if linear else None
@@ -197,8 +205,15 @@ class StableDiffusionControlNetPipeline:
             t_dev = torch.full((B,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
             E._keepalive(t_dev)
             x8 = E.scale_pad(io.latents, sch.input_scale(i), 8, name="x8")
+            # the ControlNet and the UNet encoder + mid block both read only x8: the ControlNet runs on the program's side stream and is
+            # joined where the UNet consumes its residuals (fills the CUs the small-M deep-level kernels leave idle)
+            if self.two_streams:
+                E.fork()
             down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0, added=added)
-            eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid, added=added)
+            if self.two_streams:
+                E.main()
+            eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid, added=added,
+                                   before_residuals=E.join if self.two_streams else None)
             if ancestral:
                 sigma_down, sigma_up = sch.ancestral_sigmas(i)
                 E.euler_step(io.latents, eps, sigma, sigma_down)

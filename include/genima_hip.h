@@ -266,6 +266,14 @@ int32_t gn_program_add_euler_step(gn_program* p, void* x, const void* eps, int64
 int32_t gn_program_add_image_f16_to_u8(gn_program* p, const void* in, uint8_t* out, int64_t pixels, int32_t ld);
 int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad,
                                        float mul, float add);
+/* stream control inside a program: ops recorded after gn_program_add_fork run on the program's second HIP stream (which first
+ * waits for everything recorded before the fork) until gn_program_add_main switches back; gn_program_add_join makes the main
+ * stream wait for the side stream.  Used to run the ControlNet next to the UNet encoder inside a denoise step (both only read the
+ * scaled latents); also valid under hipGraph capture (fork / join become graph edges).  Partial replays (gn_program_run of a
+ * sub-range) ignore them and run serially. */
+int32_t gn_program_add_fork(gn_program* p);
+int32_t gn_program_add_main(gn_program* p);
+int32_t gn_program_add_join(gn_program* p);
 int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n);
 int32_t gn_program_add_add_noise(gn_program* p, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac,
                                  void* out, int32_t B, int64_t per_sample);
