@@ -45,6 +45,19 @@ WORKLOADS = {
 GFLOP_PER_CALL = {512: 8000.0, 256: 1888.0}
 
 
+def pmc_traffic_per_launch(family: str):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+    collected as MI355X_MICROARCH.md prescribes).  None when the file is missing."""
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic_tiled_b8.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        fe, wr = d["FETCH_SIZE"][family], d["WRITE_SIZE"][family]
+        return (2.0 * fe["sum_counter"] / fe["launches"] + wr["sum_counter"] / wr["launches"]) * 1024.0
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def synthetic_inputs(pipe, B, H, W, device, rank):
     from genima_amd import weights
 
@@ -252,7 +265,8 @@ def main():
         "dtype": "f16 (f32 accumulate)", "data": "synthetic (seeded random-init SD-Turbo-architecture weights, counter-PRNG images)",
         "config": {"workload": desc, "family": args.family, "per_gpu_batch": B, "global_batch": B * world,
                    "image": f"{H}x{W}", "denoise_steps": args.denoise_steps, "parallelism": f"replicas x{world} (episodes sharded, no collective)",
-                   "hip_graph": bool(args.graph), "act_controller_forward": act_agent is not None},
+                   "hip_graph": bool(args.graph), "act_controller_forward": act_agent is not None,
+                   "two_streams": bool(pipe.two_streams)},
         "images_per_sec_per_gpu": value / world,
         "act_controller_ms_per_call": act_ms,
         "value_incl_d2h_to_host": (4.0 if H == 512 else 1.0) * B / dt_host,
@@ -272,9 +286,14 @@ def main():
         g_fl = sum(agg[k]["flops"] for k in gemm_kinds)
         n_l = sum(agg[k]["launches"] for k in gemm_kinds)
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_kernel<BM,BN,2,2,CONV> (MFMA implicit-GEMM conv3x3/1x1 + Linear)",
-                           "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF, "traffic": None,
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_kernel<BM,BN,WM,WN,CONV> (MFMA implicit-GEMM conv3x3/1x1 + Linear)",
+                           "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
+                           "traffic": pmc_traffic_per_launch("gemm") if args.workload == "tiled_b8" else None,
+                           "traffic_note": "HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes of this "
+                                           "workload (profiles/r01_v3_pmc_traffic_tiled_b8.json: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; "
+                                           "the x2 is MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction); not re-collected by this run",
                            "launches_per_call": n_l, "avg_launch_ms": g_ms / max(1, n_l), "algorithmic_gflop_per_call": g_fl / 1e9,
+                           "algorithmic_bytes_per_launch": sum(agg[k]["bytes"] for k in gemm_kinds) / max(1, n_l),
                            "share_of_call_time": g_ms / sum(a["ms"] for a in agg.values())}
         extra = []
         for k in sorted(agg, key=lambda k: -agg[k]["ms"]):
