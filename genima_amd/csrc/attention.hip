@@ -24,6 +24,8 @@
 // LDS fragment reads over more MFMAs; the launcher picks the variant by problem size.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -41,6 +43,19 @@ struct AttnParams {
 };
 
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+
+// max / sum over the lane pair {l, l ^ 32} that shares a query row: gfx950's v_permlane32_swap exchanges the wave's halves in the
+// VALU (the generic __shfl_xor lowers to ds_bpermute: an LDS round trip on the critical path of every key tile)
+__device__ __forceinline__ float pair_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pair_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int D, int NW, int TQ>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
@@ -98,8 +113,49 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   if (p.causal) nk_eff = min(p.Nk, q0 + QB);
   const int ntiles = (nk_eff + KT - 1) / KT;
 
+  // ---- D = 64: K / V^T tiles go global -> LDS directly (buffer_load ... lds, 16 B per lane, as in gemm_dma_kernel): no staging
+  // registers, no ds_write, one integer add per tile and DMA instruction.  A DMA instruction fills 8 consecutive 128-byte LDS rows
+  // lane-linearly, so the row permutation of K (key bits 2 <-> 3) and the XOR chunk swizzle are applied on the SOURCE side: the
+  // lane that owns LDS (row, physical chunk) fetches key perm(row), logical chunk = chunk ^ ((row >> 1) & 7).  Keys >= Nk lie past
+  // the K descriptor's extent and read as zeros; V^T's padded key columns are finite by contract (P is exactly 0 there).
+  constexpr bool DMA = (D == 64);
+  constexpr int NG = 8 / NW > 0 ? 8 / NW : 1;  // 8-row groups per wave and tile (K and V^T each have 8)
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  static_assert(NG <= 2, "blocks have at least 4 waves");
+  unsigned koff[2], voff[2];  // (fixed extent: a template-dependent extent here makes hipcc's host pass drop the kernel stub)
+  if constexpr (DMA) {
+    static_assert(!DMA || 8 % NW == 0, "8 row groups must split evenly over the waves");
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const int row = 8 * (wv + NW * i) + (lane >> 3);
+      const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+      const int key = (row & 32) | swap23(row & 31);
+      koff[i] = (unsigned)(((long)key * p.k_rs + chunk * 8) * 2);
+      voff[i] = (unsigned)(((long)row * p.vt_rs + chunk * 8) * 2);
+    }
+  }
+  const long kbytes = ((long)(p.Nk - 1) * p.k_rs + D) * 2;
+  const long vbytes = ((long)(D - 1) * p.vt_rs + (long)((p.Nk + KT - 1) / KT) * KT) * 2;
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)kbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)vbytes, 0x00020000);
+  auto dma_tile = [&](int buf) {  // issues the NEXT tile in sequence (offsets advance by one tile per call)
+    if constexpr (DMA) {
+      unsigned char* Ks = smem + buf * (K_BYTES + V_BYTES);
+      unsigned char* Vs = Ks + K_BYTES;
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (attn_lds_ptr_t)(Ks + (wv + NW * i) * 1024), 16, koff[i], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (attn_lds_ptr_t)(Vs + (wv + NW * i) * 1024), 16, voff[i], 0, 0, 0);
+        koff[i] += (unsigned)(KT * p.k_rs * 2);
+        voff[i] += (unsigned)(KT * 2);
+      }
+    }
+  };
+
+  // ---- D = 32 (CLIP-B / ACT heads): register-staged tiles (64-byte K rows do not fit the 8-rows-per-DMA image)
   uint4 rk[KLD], rv[VLD];
   auto load_tile = [&](int t) {
+    if constexpr (DMA) { (void)t; return; }
     const int j0 = t * KT;
 #pragma unroll
     for (int i = 0; i < KLD; ++i) {
@@ -126,6 +182,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     }
   };
   auto store_tile = [&](int buf) {
+    if constexpr (DMA) { (void)buf; return; }
     unsigned char* Ks = smem + buf * (K_BYTES + V_BYTES);
     unsigned char* Vs = Ks + K_BYTES;
 #pragma unroll
@@ -144,9 +201,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   };
 
   if (ntiles > 0) {
-    load_tile(0);
-    store_tile(0);
+    if constexpr (DMA) {
+      dma_tile(0);
+    } else {
+      load_tile(0);
+      store_tile(0);
+    }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA pieces of this wave have landed (no-op for the register path)
   __syncthreads();
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -155,11 +217,31 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
-    if (more) load_tile(t + 1);
+    if (more) {
+      if constexpr (DMA) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
+      else load_tile(t + 1);
+    }
     const unsigned char* Ks = smem + cur * (K_BYTES + V_BYTES);
     const unsigned char* Vs = Ks + K_BYTES;
     const int j0 = t * KT;
     const bool need_mask = (j0 + KT > p.Nk) || (p.causal && j0 + KT - 1 > q0);  // block-uniform
+    if (DMA && j0 + KT > p.Nk) {
+      // last tile of a ragged key count (block-uniform, rare): the DMA brought V^T's pad columns in as they are, and they are not
+      // trusted (P is exactly 0 there, but 0 * NaN is NaN): clear the dead keys of the tile in LDS before anyone reads it
+      unsigned char* Vw = smem + cur * (K_BYTES + V_BYTES) + K_BYTES;
+      for (int idx = tid; idx < D * 8; idx += NT) {
+        const int row = idx >> 3, ch = idx & 7, kb = j0 + ch * 8;
+        if (kb + 8 > p.Nk) {
+          f16x8* ptr = reinterpret_cast<f16x8*>(Vw + lds_swz<128>(row, ch));
+          f16x8 e = *ptr;
+#pragma unroll
+          for (int x = 0; x < 8; ++x)
+            if (kb + x >= p.Nk) e[x] = (f16)0.0f;
+          *ptr = e;
+        }
+      }
+      __syncthreads();
+    }
 
     // ---- S^T = K . Q^T for the two 32-key sub-tiles (raw scores); each K fragment feeds TQ MFMAs ----------------------------
     f32x16 s[TQ][2];
@@ -195,7 +277,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         mx = fmaxf(fmaxf(mx, s[tq][0][r]), s[tq][0][r + 1]);
         mx = fmaxf(fmaxf(mx, s[tq][1][r]), s[tq][1][r + 1]);
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * c;  // exponent units; -inf stays -inf (c > 0)
+      mx = pair_max(mx) * c;  // exponent units; -inf stays -inf (c > 0)
       // deferred rescale: only when some row's max outgrew its reference by more than THR (wave-uniform)
       if (__any(mx > m_run[tq] + THR)) {
         const float m_new = fmaxf(m_run[tq], mx);
@@ -222,6 +304,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         }
       l_run[tq] += psum;
     }
+    // the next tile goes to the other LDS buffer here, not at the end of the iteration: its global loads (issued at the top) have
+    // had the S^T MFMAs + softmax to land, and the ds_writes then retire under the P.V MFMAs instead of right in front of the barrier
+    if (more) store_tile(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
     // ---- O^T += V^T . P^T; each V^T fragment feeds TQ MFMAs ----------------------------------------------------------------
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -234,7 +320,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
           for (int tq = 0; tq < TQ; ++tq)
             oacc[tq][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[tq][u][sstep], oacc[tq][dt], 0, 0, 0);
         }
-    if (more) store_tile(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
   }
@@ -242,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   // ---- finalize: O[q][d] = O^T[d][q] / l ----------------------------------------------------------------------------------
 #pragma unroll
   for (int tq = 0; tq < TQ; ++tq) {
-    const float l_tot = l_run[tq] + __shfl_xor(l_run[tq], 32, 64);
+    const float l_tot = pair_sum(l_run[tq]);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     const int qrow = qw + 32 * tq;
     if (p.lse && hi == 0 && qrow < p.Nq)
