@@ -33,6 +33,35 @@ struct AttnBwdParams {
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ int perm_row(int r) { return (r & 32) | swap23(r & 31); }
 
+// ---- LDS-DMA staging of the streamed [64 rows][128 B] tiles (same scheme as attention.hip / gemm_dma_kernel): a DMA instruction fills
+// 8 consecutive LDS rows lane-linearly (16 B per lane), so the lane that owns LDS (row, physical chunk) fetches source row
+// perm(row) (row-major operands) or row (transposed operands), logical chunk = chunk ^ ((row >> 1) & 7).  Anything past a
+// descriptor's extent reads as zero (rows >= the valid count of Q / dO / K / V).  4 waves: wave w issues groups w and w + 4.
+typedef __attribute__((address_space(3))) void* bwd_lds_ptr_t;
+struct TileStream {
+  unsigned off[2];  // this lane's byte offsets for its two row groups; advance by `step` bytes per tile
+  unsigned step;
+};
+__device__ __forceinline__ TileStream make_stream(int wave, int lane, long row_stride_elems, bool permute, long tile_step_bytes) {
+  TileStream s;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 8 * (wave + 4 * i) + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int src = permute ? perm_row(row) : row;
+    s.off[i] = (unsigned)(((long)src * row_stride_elems + chunk * 8) * 2);
+  }
+  s.step = (unsigned)tile_step_bytes;
+  return s;
+}
+__device__ __forceinline__ void dma_stream(TileStream& s, const __amdgpu_buffer_rsrc_t rs, unsigned char* tile, int wave) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (bwd_lds_ptr_t)(tile + (wave + 4 * i) * 1024), 16, s.off[i], 0, 0, 0);
+    s.off[i] += s.step;
+  }
+}
+
 // delta[b][h][q] = sum_d dO * O
 __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdParams p, int B) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -86,38 +115,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
   f32x16 acc[2] = {zero16, zero16};
 
   const int ntiles = (p.Nk + TS - 1) / TS;
-  uint4 rk[2], rv[2], rt[2];
-  auto load_tile = [&](int t) {
-    const int j0 = t * TS;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0), x = make_uint4(0, 0, 0, 0);
-      if (j0 + row < p.Nk_rows) {
-        a = *reinterpret_cast<const uint4*>(kp + (long)(j0 + row) * p.k_rs + ch * 8);
-        g = *reinterpret_cast<const uint4*>(vp + (long)(j0 + row) * p.v_rs + ch * 8);
-      }
-      if (j0 + ch * 8 < p.Nk_rows) x = *reinterpret_cast<const uint4*>(ktp + (long)row * p.kt_rs + j0 + ch * 8);
-      rk[i] = a; rv[i] = g; rt[i] = x;
-    }
-  };
-  auto store_tile = [&](int buf) {
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  // K / V rows past Nk_rows and the tail of the K^T slab lie beyond the descriptors and read as zeros; key columns of K^T between
+  // Nk_rows and the end of a row hold the next row's (finite) data and meet dS = 0 there
+  const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)((((long)p.Nk_rows - 1) * p.k_rs + D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)((((long)p.Nk_rows - 1) * p.v_rs + D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)ktp, 0, (int)((long)D * p.kt_rs * 2), 0x00020000);
+  TileStream sk = make_stream(wv, lane, p.k_rs, true, (long)TS * p.k_rs * 2);
+  TileStream sv = make_stream(wv, lane, p.v_rs, true, (long)TS * p.v_rs * 2);
+  TileStream st = make_stream(wv, lane, p.kt_rs, false, TS * 2);
+  auto dma_tile = [&](int buf) {  // the next tile in sequence
     unsigned char* Ks = smem + buf * 3 * TILE;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-      *reinterpret_cast<uint4*>(Ks + lds_swz<128>(perm_row(row), ch)) = rk[i];
-      *reinterpret_cast<uint4*>(Ks + TILE + lds_swz<128>(perm_row(row), ch)) = rv[i];
-      *reinterpret_cast<uint4*>(Ks + 2 * TILE + lds_swz<128>(row, ch)) = rt[i];
-    }
+    dma_stream(sk, rs_k, Ks, wv);
+    dma_stream(sv, rs_v, Ks + TILE, wv);
+    dma_stream(st, rs_t, Ks + 2 * TILE, wv);
   };
-  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  if (ntiles > 0) dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
-    if (more) load_tile(t + 1);
+    if (more) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
     const unsigned char* Ks = smem + cur * 3 * TILE;
     const unsigned char* Vs = Ks + TILE;
     const unsigned char* Ts = Ks + 2 * TILE;
@@ -153,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
           const f16x8 tf = *reinterpret_cast<const f16x8*>(Ts + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
           acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, dsf[u][g], acc[dt], 0, 0, 0);
         }
-    if (more) store_tile(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
   }
@@ -206,52 +226,50 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   f32x16 accK[2] = {zero16, zero16}, accV[2] = {zero16, zero16};
 
   const int ntiles = (p.Nq + TS - 1) / TS;
-  uint4 rq[2], rg[2], rqt[2], rgt[2];
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  // Q / dO rows past Nq and the tails of the transposed slabs read as zeros; query columns of Q^T / dO^T past Nq inside a row hold the
+  // next row's (finite) data and meet P = dS = 0 there (their lse is +inf)
+  const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (int)((((long)p.Nq - 1) * p.q_rs + D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gp, 0, (int)((((long)p.Nq - 1) * p.do_rs + D) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_qt = __builtin_amdgcn_make_buffer_rsrc((void*)qtp, 0, (int)((long)D * p.qt_rs * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gt = __builtin_amdgcn_make_buffer_rsrc((void*)gtp, 0, (int)((long)D * p.dot_rs * 2), 0x00020000);
+  TileStream sq = make_stream(wv, lane, p.q_rs, true, (long)TS * p.q_rs * 2);
+  TileStream sg = make_stream(wv, lane, p.do_rs, true, (long)TS * p.do_rs * 2);
+  TileStream sqt = make_stream(wv, lane, p.qt_rs, false, TS * 2);
+  TileStream sgt = make_stream(wv, lane, p.dot_rs, false, TS * 2);
+  int jn = 0;  // first query row of the next tile to stage
   float rl = 0.f, rd = 0.f;
-  auto load_tile = [&](int t) {
-    const int j0 = t * TS;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-      uint4 a = make_uint4(0, 0, 0, 0), g = make_uint4(0, 0, 0, 0), x = make_uint4(0, 0, 0, 0), y = make_uint4(0, 0, 0, 0);
-      if (j0 + row < p.Nq) {
-        a = *reinterpret_cast<const uint4*>(qp + (long)(j0 + row) * p.q_rs + ch * 8);
-        g = *reinterpret_cast<const uint4*>(gp + (long)(j0 + row) * p.do_rs + ch * 8);
-      }
-      if (j0 + ch * 8 < p.Nq) {  // Nq % 8 == 0: a chunk never straddles the end
-        x = *reinterpret_cast<const uint4*>(qtp + (long)row * p.qt_rs + j0 + ch * 8);
-        y = *reinterpret_cast<const uint4*>(gtp + (long)row * p.dot_rs + j0 + ch * 8);
-      }
-      rq[i] = a; rg[i] = g; rqt[i] = x; rgt[i] = y;
-    }
-    if (tid < 64) {
-      const bool live = j0 + tid < p.Nq;
-      rl = live ? lsep[j0 + tid] : INFINITY;  // dead query rows: P = exp2(.. - inf) = 0
-      rd = live ? delp[j0 + tid] : 0.0f;
-    }
-  };
-  auto store_tile = [&](int buf) {
+  auto dma_tile = [&](int buf) {  // the next tile in sequence; the 2 x 64 row statistics ride along through one register each
     unsigned char* Qs = smem + buf * KV_BUF;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-      *reinterpret_cast<uint4*>(Qs + lds_swz<128>(perm_row(row), ch)) = rq[i];
-      *reinterpret_cast<uint4*>(Qs + TILE + lds_swz<128>(perm_row(row), ch)) = rg[i];
-      *reinterpret_cast<uint4*>(Qs + 2 * TILE + lds_swz<128>(row, ch)) = rqt[i];
-      *reinterpret_cast<uint4*>(Qs + 3 * TILE + lds_swz<128>(row, ch)) = rgt[i];
-    }
+    dma_stream(sq, rs_q, Qs, wv);
+    dma_stream(sg, rs_g, Qs + TILE, wv);
+    dma_stream(sqt, rs_qt, Qs + 2 * TILE, wv);
+    dma_stream(sgt, rs_gt, Qs + 3 * TILE, wv);
     if (tid < 64) {
+      const bool live = jn + tid < p.Nq;
+      rl = live ? lsep[jn + tid] : INFINITY;  // dead query rows: P = exp2(.. - inf) = 0
+      rd = live ? delp[jn + tid] : 0.0f;
+    }
+    jn += TS;
+  };
+  auto store_stats = [&](int buf) {
+    if (tid < 64) {
+      unsigned char* Qs = smem + buf * KV_BUF;
       reinterpret_cast<float*>(Qs + 4 * TILE)[tid] = rl;
       reinterpret_cast<float*>(Qs + 4 * TILE + 256)[tid] = rd;
     }
   };
-  if (ntiles > 0) { load_tile(0); store_tile(0); }
+  if (ntiles > 0) {
+    dma_tile(0);
+    store_stats(0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int cur = 0;
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
-    if (more) load_tile(t + 1);
+    if (more) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
     const unsigned char* Qs = smem + cur * KV_BUF;
     const unsigned char* Gs = Qs + TILE;
     const unsigned char* QTs = Qs + 2 * TILE;
@@ -299,7 +317,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
           accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gt, pf[u][g], accV[dt], 0, 0, 0);
           accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qt, dsf[u][g], accK[dt], 0, 0, 0);
         }
-    if (more) store_tile(cur ^ 1);
+    if (more) store_stats(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
   }
