@@ -213,7 +213,7 @@ class Engine:
     def _gemm(self, d: GemmDesc, keep):
         if d.tile == 0 and d.splitk == 0:
             # autotuning engines measure unknown shapes; every engine uses a tile that was already measured on this architecture
-            d.tile = self._autotune(d) if self.autotune else _tune_table().get(self._tune_key(d), 0)
+            d.tile = self._autotune(d) if self.autotune else (0 if getattr(self, "no_table", False) else _tune_table().get(self._tune_key(d), 0))
         ws_bytes = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
         ws = None
         if ws_bytes > 0:

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from genima_amd.engine import Engine  # noqa: E402
 
 E = Engine("cuda:0")
+E.no_table = True  # time the configuration forced through gn_set_gemm_tile_override, not the tuned one
 CFG = ["256x128", "128x128", "128x64", "64x64", "256x64", "128x256",
        "D256x256", "D256x128", "D128x128", "D128x64", "D64x64", "D256x64", "D128x320", "D256x320"]
 ALL = tuple(int(c) for c in os.environ.get("CFGS", "0,1,2,3,4,5,6,7,8,9,10,11,12,13").split(","))
