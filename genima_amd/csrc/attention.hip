@@ -10,15 +10,18 @@
 // V arrives already transposed ([b][h*D+d][key]) from the V projection's epilogue, so both tiles use the same 16-byte-chunk
 // XOR-swizzled LDS image as the GEMM kernel (conflict-free ds_read_b128).
 //
-// At D = 64 the kernel is VALU-bound, not MFMA-bound (256 MFMA flops vs ~10 f32 VALU ops per score at a 16:1 rate ratio), so
-// the softmax is trimmed to ~5 VALU per score:
-//   * the softmax scale is folded into the exponent:  p = exp2(fma(s, c, -m)),  c = scale*log2(e); the max is taken on raw s;
-//   * masking (key >= Nk, causal) runs only in the tiles that need it (block-uniform branch);
-//   * the O^T / l rescale is deferred: it runs only when some row's max grew by more than 2^THR since its last rescale
-//     (wave-uniform branch; P stays <= 2^THR, harmless for f16's relative precision) -- on typical data once or twice per row;
+// At D = 64 the kernel is VALU-issue-bound, not MFMA-bound (PMC, MI355X: VALU issue active 59 % of the SIMD cycles with the
+// matrix pipe busy 40 % when the softmax costs ~4.5 VALU per score), so the common tile runs an "optimistic" softmax of
+// 2 VALU per score -- v_exp_f32, half a v_cvt_pk_f16_f32, half a v_dot2c_f32_f16 -- and nothing else:
+//   * the scale c = scale*log2(e) is multiplied into the Q fragments once, and the softmax reference m enters as the accumulator
+//     init of the first QK^T MFMA (16 registers holding -m), so the MFMA accumulators ARE the exponents s*c - m;
+//   * no row max is taken: m is whatever the last careful tile left.  P = exp2(s*c - m) may exceed 1; f16's relative precision
+//     is scale-free and O and l carry the same factor, so only range matters.  A lane's 32-key sum of P above 2^13 (or inf / NaN)
+//     flags the tile (wave-uniform) before anything is accumulated: the scores are recomputed and the tile takes the careful path;
+//   * the careful path (first tile, masked tiles, flagged tiles) masks, takes the row max with v_max3_f32 chains, moves the
+//     reference (rescaling O^T and l) and re-bases the exponents -- on typical data once or twice per row;
 //   * P is packed with v_cvt_pk_f16_f32 and its row sum taken with v_dot2c_f32_f16 on the packed pairs (the sum then matches
-//     the f16 P that enters the PV MFMA exactly);
-//   * v_max3_f32 chains for the row max.
+//     the f16 P that enters the PV MFMA exactly).
 // K/V tiles are double-buffered in LDS (one barrier per 64-key tile), global -> register loads of tile t+1 are in flight under
 // the MFMAs of tile t.  Block = NW waves x TQ x 32 query rows (template): more rows per block amortise the K/V staging and
 // LDS fragment reads over more MFMAs; the launcher picks the variant by problem size.
@@ -31,7 +34,7 @@
 namespace {
 
 constexpr int KT = 64;       // keys per tile
-constexpr float THR = 8.0f;  // deferred-rescale threshold in log2 units
+constexpr float PLIM = 8192.0f;  // a lane's 32-key sum of P beyond this means some P > 2^8: re-reference the row
 
 struct AttnParams {
   const f16* q; const f16* k; const f16* vt; f16* o;
@@ -92,21 +95,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
       uint4 v = make_uint4(0, 0, 0, 0);
       const int qrow = qw + 32 * tq;
       if (qrow < p.Nq) v = *reinterpret_cast<const uint4*>(qp + (long)qrow * p.q_rs + ks * 16 + hi * 8);
-      qf[tq][ks] = *reinterpret_cast<f16x8*>(&v);
+      f16x8 q8 = *reinterpret_cast<f16x8*>(&v);
+#pragma unroll
+      for (int x = 0; x < 8; ++x) q8[x] = (f16)((float)q8[x] * p.scale_log2);  // exponent units straight out of the MFMA
+      qf[tq][ks] = q8;
     }
 
-  f32x16 oacc[TQ][DT];
+  f32x16 oacc[TQ][DT], negm[TQ];
   float m_run[TQ], l_run[TQ];
 #pragma unroll
   for (int tq = 0; tq < TQ; ++tq) {
-    m_run[tq] = -1e30f;  // running max in exponent units (raw score * scale_log2), as of the last rescale
-    l_run[tq] = 0.0f;    // this lane's half of the row sum
+    m_run[tq] = 0.0f;  // softmax reference in exponent units (score * scale * log2 e); the first key tile sets it
+    l_run[tq] = 0.0f;  // this lane's half of the row sum
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[tq][r] = 0.0f;  // -m_run as an MFMA accumulator init (all 16 entries equal)
 #pragma unroll
     for (int t = 0; t < DT; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[tq][t][r] = 0.0f;
   }
-  const float c = p.scale_log2;
 
   // key range: causal rows never look past their own index
   int nk_eff = p.Nk;
@@ -211,7 +218,6 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // DMA pieces of this wave have landed (no-op for the register path)
   __syncthreads();
 
-  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const f16x2 ones = {(f16)1.0f, (f16)1.0f};
 
   int cur = 0;
@@ -243,67 +249,97 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
       __syncthreads();
     }
 
-    // ---- S^T = K . Q^T for the two 32-key sub-tiles (raw scores); each K fragment feeds TQ MFMAs ----------------------------
+    // ---- S'^T = (K . (cQ)^T) - m for the two 32-key sub-tiles: the scale c rides in the Q fragments and the running reference m
+    // enters as the accumulator init of the first MFMA, so the accumulators come out as exponents; each K fragment feeds TQ MFMAs
     f32x16 s[TQ][2];
+    auto scores = [&]() {
 #pragma unroll
-    for (int u = 0; u < 2; ++u)
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<ROWB>(u * 32 + l31, ks * 2 + hi));
+        for (int ks = 0; ks < KS; ++ks) {
+          const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<ROWB>(u * 32 + l31, ks * 2 + hi));
 #pragma unroll
-        for (int tq = 0; tq < TQ; ++tq)
-          s[tq][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[tq][ks], ks == 0 ? zero16 : s[tq][u], 0, 0, 0);
-      }
-
-    // ---- online softmax per q tile; accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7) ---------------------
+          for (int tq = 0; tq < TQ; ++tq)
+            s[tq][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[tq][ks], ks == 0 ? negm[tq] : s[tq][u], 0, 0, 0);
+        }
+    };
+    // P = exp2(S') packed to f16 (the PV B operand), returns this lane's part of the row sum (of the f16 values that enter PV);
+    // accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7)
     f16x8 pf[TQ][2][2];
-#pragma unroll
-    for (int tq = 0; tq < TQ; ++tq) {
-      if (need_mask) {
-        const int qrow = qw + 32 * tq;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
-            const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
-            s[tq][u][r] = dead ? -INFINITY : s[tq][u][r];
-          }
-      }
-      float mx = fmaxf(fmaxf(s[tq][0][0], s[tq][0][1]), s[tq][1][0]);
-      mx = fmaxf(mx, s[tq][1][1]);
-#pragma unroll
-      for (int r = 2; r < 16; r += 2) {
-        mx = fmaxf(fmaxf(mx, s[tq][0][r]), s[tq][0][r + 1]);
-        mx = fmaxf(fmaxf(mx, s[tq][1][r]), s[tq][1][r + 1]);
-      }
-      mx = pair_max(mx) * c;  // exponent units; -inf stays -inf (c > 0)
-      // deferred rescale: only when some row's max outgrew its reference by more than THR (wave-uniform)
-      if (__any(mx > m_run[tq] + THR)) {
-        const float m_new = fmaxf(m_run[tq], mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[tq] - m_new);
-        m_run[tq] = m_new;
-        l_run[tq] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[tq][dt][r] *= alpha;
-      }
-      const float nm = -m_run[tq];
-      float psum = 0.0f;
+    float psum[TQ];
+    auto exps = [&](int tq) {
+      float acc = 0.0f;
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
           f16x2 pp;
-          pp[0] = (f16)__builtin_amdgcn_exp2f(fmaf(s[tq][u][r], c, nm));
-          pp[1] = (f16)__builtin_amdgcn_exp2f(fmaf(s[tq][u][r + 1], c, nm));
-          psum = __builtin_amdgcn_fdot2(pp, ones, psum, false);
+          pp[0] = (f16)__builtin_amdgcn_exp2f(s[tq][u][r]);
+          pp[1] = (f16)__builtin_amdgcn_exp2f(s[tq][u][r + 1]);
+          acc = __builtin_amdgcn_fdot2(pp, ones, acc, false);
           pf[tq][u][r >> 3][r & 7] = pp[0];
           pf[tq][u][r >> 3][(r & 7) + 1] = pp[1];
         }
-      l_run[tq] += psum;
+      psum[tq] = acc;
+    };
+
+    scores();
+    const bool careful = need_mask || t == 0;  // block-uniform: these tiles always take the max-tracking path
+    bool redo = careful;
+    if (!careful) {
+      // optimistic path: no row max at all.  P <= 2^13 keeps f16 finite and exact enough (relative precision is scale-free; O and
+      // l carry the same factor); a lane sum beyond PLIM (or inf / NaN) means some score outgrew the reference by > 2^8
+      bool trig = false;
+#pragma unroll
+      for (int tq = 0; tq < TQ; ++tq) {
+        exps(tq);
+        trig |= !(psum[tq] <= PLIM);
+      }
+      redo = __any(trig);
+      if (redo) scores();  // the exponentials overwrote the scores: recompute them (rare)
     }
+    if (redo) {
+#pragma unroll
+      for (int tq = 0; tq < TQ; ++tq) {
+        if (need_mask) {
+          const int qrow = qw + 32 * tq;
+#pragma unroll
+          for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7);
+              const bool dead = (key >= p.Nk) || (p.causal && key > qrow);
+              s[tq][u][r] = dead ? -INFINITY : s[tq][u][r];
+            }
+        }
+        float mx = fmaxf(fmaxf(s[tq][0][0], s[tq][0][1]), s[tq][1][0]);
+        mx = fmaxf(mx, s[tq][1][1]);
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) {
+          mx = fmaxf(fmaxf(mx, s[tq][0][r]), s[tq][0][r + 1]);
+          mx = fmaxf(fmaxf(mx, s[tq][1][r]), s[tq][1][r + 1]);
+        }
+        mx = pair_max(mx);  // relative to the current reference; -inf for a row with no live key yet
+        // the reference only grows, except on the first tile where it is set (O and l are still zero there)
+        const float delta = mx == -INFINITY ? 0.0f : (t == 0 ? mx : fmaxf(mx, 0.0f));
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_run[tq] += delta;
+        l_run[tq] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[tq][dt][r] *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[tq][r] = -m_run[tq];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[tq][u][r] -= delta;
+        exps(tq);
+      }
+    }
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) l_run[tq] += psum[tq];
     // the next tile goes to the other LDS buffer here, not at the end of the iteration: its global loads (issued at the top) have
     // had the S^T MFMAs + softmax to land, and the ds_writes then retire under the P.V MFMAs instead of right in front of the barrier
     if (more) store_tile(cur ^ 1);
