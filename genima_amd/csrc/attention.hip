@@ -29,36 +29,9 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "attention_common.h"
 
 namespace {
-
-constexpr int KT = 64;       // keys per tile
-constexpr float PLIM = 8192.0f;  // a lane's 32-key sum of P beyond this means some P > 2^8: re-reference the row
-
-struct AttnParams {
-  const f16* q; const f16* k; const f16* vt; f16* o;
-  long q_bs, k_bs, vt_bs, o_bs;
-  int q_rs, k_rs, vt_rs, o_rs;
-  int heads, Nq, Nk, causal;
-  float scale_log2;  // scale * log2(e)
-  float* lse;        // optional [B][heads][Nq]: m + log2(l), so that P = exp2(s * scale_log2 - lse) (training)
-};
-
-__device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
-
-typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
-
-// max / sum over the lane pair {l, l ^ 32} that shares a query row: gfx950's v_permlane32_swap exchanges the wave's halves in the
-// VALU (the generic __shfl_xor lowers to ds_bpermute: an LDS round trip on the critical path of every key tile)
-__device__ __forceinline__ float pair_max(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float pair_sum(float v) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 template <int D, int NW, int TQ>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
@@ -78,8 +51,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * QB;
+  // XCD-aware block order: consecutive block ids go round-robin over the 8 XCDs (each with its own L2), so the query blocks that
+  // share one (batch, head)'s K / V^T get ids that land on ONE XCD, next to each other in dispatch order (+9 % at 8 x 5 x 4096^2).
+  // (the integer divisions run in the VALU: pin the results back to SGPRs, or the buffer descriptors below turn "divergent")
+  const int nqb = (p.Nq + QB - 1) / QB, total = gridDim.x;
+  const int slot = (total % 8 == 0) ? (blockIdx.x % 8) * (total / 8) + blockIdx.x / 8 : blockIdx.x;
+  const int bh = __builtin_amdgcn_readfirstlane(slot / nqb);
+  const int b = __builtin_amdgcn_readfirstlane(bh / p.heads), h = bh - b * p.heads;
+  const int q0 = (slot - bh * nqb) * QB;
   const int qw = q0 + wave * (TQ * 32) + l31;  // this lane's query row in q-tile 0 (+32 per further tile)
 
   const f16* qp = p.q + (long)b * p.q_bs + (long)h * D;
@@ -387,14 +366,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 template <int D, int NW, int TQ>
 void launch_attn(const AttnParams& p, int B, hipStream_t st) {
   constexpr int QB = NW * TQ * 32;
-  dim3 grid((p.Nq + QB - 1) / QB, p.heads, B);
+  dim3 grid(((p.Nq + QB - 1) / QB) * p.heads * B);
   hipLaunchKernelGGL((attn_fwd_kernel<D, NW, TQ>), grid, dim3(NW * 64), 0, st, p);
 }
 
 int attn_variant_override() {
   static int v = -2;
   if (v == -2) {
-    const char* e = getenv("GN_ATTN_VARIANT");  // tuning aid: 0 = 4 waves x 32 rows, 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows
+    // tuning aid: 0 = 4 waves x 32 rows (default), 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows, 3 = attention_pipe.hip
+    const char* e = getenv("GN_ATTN_VARIANT");
     v = e ? atoi(e) : -1;
   }
   return v;
@@ -421,13 +401,13 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   if (d->D == 32) {
     launch_attn<32, 4, 1>(p, d->B, ctx->stream);
   } else {
-    // measured on MI355X (tools/bench_attn.py): the three block shapes are within 5 % of each other on every hot-path shape
-    // (the per-wave softmax/MFMA dependency chain, not K/V staging, is the limiter), 4 waves x 32 rows is never worse.
-    int v = 0;
+    // measured on MI355X (tools/bench_attn.py): the three block shapes are within 5 % of each other on every hot-path shape, and
+    // so is the software-pipelined kernel of attention_pipe.hip (its in-wave MFMA / VALU overlap is paid back in barrier waits at
+    // 2 waves per SIMD -- DESIGN.md); 4 waves x 32 rows is never worse and stays the default.
     const int ov = attn_variant_override();
-    if (ov >= 0 && ov <= 2) v = ov;
-    if (v == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
-    else if (v == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
+    if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
+    else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
+    else if (ov == 3) gn_launch_attention_pipe(p, d->B, ctx->stream);
     else launch_attn<64, 4, 1>(p, d->B, ctx->stream);
   }
   GN_LAUNCH_CHECK();
