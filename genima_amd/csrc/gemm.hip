@@ -85,14 +85,14 @@ __device__ __forceinline__ float gemm_act(float x, int act) {
 }
 
 // ---- epilogue for 4 consecutive output channels [nb, nb+4) of row m -------------------------------------------------
-__device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int nb, float v0, float v1, float v2, float v3) {
-  float v[4] = {v0, v1, v2, v3};
+// bias / shift / residual / activation / scale of 4 consecutive output channels; bidx = batch index of row m (when needed)
+__device__ __forceinline__ void epilogue_vals4(const GemmParams& p, int m, int nb, float (&v)[4], int& bidx) {
   if (p.bias) {
     f16x4 b = *reinterpret_cast<const f16x4*>(p.bias + nb);
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)b[i];
   }
-  int bidx = 0;
+  bidx = 0;
   if (p.shift || p.out_mode == GN_OUT_BATCH_TRANSPOSED) bidx = m / p.rpb;
   if (p.shift) {
     f16x4 s = *reinterpret_cast<const f16x4*>(p.shift + (long)bidx * p.ldshift + nb);
@@ -117,6 +117,33 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] += (float)r[i];
   }
+}
+
+// Row-major f16 output, 16 bytes per lane.  The MFMA layout leaves a lane with channels 8g + 4hi + (0..3) of its row: 8-byte
+// pieces, and the write path is issue-bound on those (removing the stores took 8 % (K = 1280) to 26 % (K = 320) off the Linear
+// launches).  Lanes l and l + 32 hold the same row, so one v_permlane32_swap per dword trades group g of the upper half against
+// group g + 1 of the lower half: afterwards the lower lane owns channels 8g .. 8g + 7 and the upper lane 8(g+1) .. 8(g+1) + 7.
+__device__ __forceinline__ void epilogue_store8_pair(const GemmParams& p, int m, int nb8, int hi, const float* a, const float* b) {
+  // a: this lane's 4 values of group g (channels nb8 + 4 hi ..), b: of group g + 1 (channels nb8 + 8 + 4 hi ..)
+  float va[4] = {a[0], a[1], a[2], a[3]}, vb[4] = {b[0], b[1], b[2], b[3]};
+  int bidx;
+  if (nb8 + 4 * hi < p.N) epilogue_vals4(p, m, nb8 + 4 * hi, va, bidx);
+  if (nb8 + 8 + 4 * hi < p.N) epilogue_vals4(p, m, nb8 + 8 + 4 * hi, vb, bidx);
+  f16x4 ha, hb;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ha[i] = (f16)va[i]; hb[i] = (f16)vb[i]; }
+  uint2 ua = *reinterpret_cast<uint2*>(&ha), ub = *reinterpret_cast<uint2*>(&hb);
+  const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+  const uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+  const int col = nb8 + 8 * hi;
+  if (col < p.N) *reinterpret_cast<uint4*>(p.out + (long)m * p.ldo + col) = o;
+}
+
+__device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int nb, float v0, float v1, float v2, float v3) {
+  float v[4] = {v0, v1, v2, v3};
+  int bidx;
+  epilogue_vals4(p, m, nb, v, bidx);
   if (p.out_mode == GN_OUT_BATCH_TRANSPOSED) {
     const int ml = m - bidx * p.rpb;
     f16* o = p.out + ((long)bidx * p.N + nb) * p.ldo + ml;
@@ -157,6 +184,8 @@ __device__ __forceinline__ void epilogue_geglu4(const GemmParams& p, int m, int 
 template <int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi,
                                               int z) {
+  // plain f16 rows whose 8-channel groups are 16-byte aligned take the paired 16-byte stores
+  const bool wide = p.out_mode == GN_OUT_ROWMAJOR && (p.ldo & 7) == 0 && (p.N & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 32 + l31;
@@ -188,6 +217,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             }
           }
       }
+    } else if (wide) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const int nb8 = nbase + j * 32 + 8 * g;
+          if (nb8 < p.N) {  // wave-uniform
+            const float a[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+            const float b[4] = {acc[j][i][4 * g + 4], acc[j][i][4 * g + 5], acc[j][i][4 * g + 6], acc[j][i][4 * g + 7]};
+            epilogue_store8_pair(p, m, nb8, hi, a, b);
+          }
+        }
     } else {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
