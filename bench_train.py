@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--family", default="sd-turbo")
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--augmentations", default="crop,colorjitter", help="the reference's --augmentations list (README.md:204); '' disables")
+    ap.add_argument("--fp8", action="store_true", help="frozen UNet transformer Linears on the fp8 MFMA in the forward pass (configs[4])")
     ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
     args = ap.parse_args()
 
@@ -73,6 +74,7 @@ def main():
     text2_W = pack_state_dict(synth(schema.clip_text_schema(fam["text_2"]), 5), dev) if "text_2" in fam else None
     tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank,
                      text2_cfg=fam.get("text_2"), text2_W=text2_W, augmentations=args.augmentations or None)
+    n_fp8 = tr.enable_fp8_frozen() if args.fp8 else 0
 
     B, R = args.batch, args.resolution
     g = torch.Generator(device=dev).manual_seed(77 + rank)
@@ -113,15 +115,16 @@ def main():
         achieved = tf * B * args.steps / dt if tf else None
         line = {
             "metric": "ControlNet train steps/sec", "value": args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16 (+ fp8 e4m3 forward Linears of the frozen UNet)" if args.fp8 else "f16",
             "data": f"synthetic (seeded random-init {args.family} weights, uniform random images, fixed 14-token prompt)",
             "samples_per_sec": B * world * args.steps / dt,
-            "config": {"workload": ("BASELINE.json configs[4]: SDXL-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views), f16 (fp8 MFMA not built yet)"
+            "config": {"workload": ("BASELINE.json configs[4]: SDXL-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views)"
                                     if args.family == "sdxl-turbo" else
                                     "BASELINE.json configs[3]: SD-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views)"),
                        "family": args.family,
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master, f16 compute, loss scale",
-                       "trainable_params_padded": int(tr.cn.numel)},
+                       "trainable_params_padded": int(tr.cn.numel), "fp8_frozen_linears": n_fp8},
             "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "grad_norm_last": tr.last.get("grad_norm"),
             "loss_scale": tr.loss_scale, "applied_steps": tr.opt_step,
             "roofline": ({"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TF,

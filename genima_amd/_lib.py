@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
         ("batch", C.c_int32), ("batch_inner", C.c_int32),
         ("a_bs", C.c_int64), ("a_bs2", C.c_int64), ("w_bs", C.c_int64), ("w_bs2", C.c_int64),
         ("out_bs", C.c_int64), ("out_bs2", C.c_int64), ("res_bs", C.c_int64), ("res_bs2", C.c_int64),
-        ("accumulate", C.c_int32), ("reserved", C.c_int32),
+        ("accumulate", C.c_int32), ("fp8", C.c_int32), ("scale_a", C.c_void_p), ("scale_w", C.c_void_p),
     ]
 
 
@@ -101,6 +101,7 @@ SIGNATURES = {
     "gn_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_softmax_rows": (_I32, [_P, _P, _I64, _I32, _I32, _F]),
     "gn_softmax_rows_masked": (_I32, [_P, _P, _I64, _I32, _I32, _F, _I32]),
+    "gn_quantize_fp8_rows": (_I32, [_P, _P, _I64, _I64, _I32, _P, _I64, _P]),
     "gn_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_transpose2d": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
     "gn_im2col_t": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),

@@ -47,6 +47,8 @@ struct GemmParams {
   int accumulate;                        // GN_OUT_F32: out += result
   int nbatch, binner;                    // batched GEMM: blockIdx.z in [0, nbatch) = outer * binner + inner
   long a_bs, a_bs2, w_bs, w_bs2, o_bs, o_bs2, r_bs, r_bs2;  // batch strides (elements; o_* in output elements)
+  const float* sa;                       // fp8: per-row scales of A [M]
+  const float* sw;                       // fp8: per-row scales of W [N]
 };
 
 // batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
@@ -617,6 +619,141 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams 
   gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
 }
 
+// ======================================================================================================================
+// fp8 (OCP e4m3) Linear on v_mfma_scale_f32_32x32x64_f8f6f4 (the SDXL transformer GEMMs).
+//   out[m, n] = epilogue( sa[m] * sw[n] * sum_k Aq[m, k] * Wq[n, k] ),   Aq / Wq one byte per element, K contiguous,
+// with per-row (per-token) activation scales and per-output-channel weight scales (gn_quantize_fp8_rows makes both).
+// Same LDS-DMA tile machinery as gemm_dma_kernel: a 128-byte LDS row now holds 128 K elements (BK = 128), and a lane's MFMA
+// operand is 32 consecutive bytes of its row -- K bytes 64 kk + 32 hi .. + 32 -- i.e. two swizzled 16-byte chunks
+// (tools/probes/mfma_fp8_layout.hip pins the operand layout on the GPU).  One MFMA does 32 x 32 x 64 MACs, twice an f16 one.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_fp8_kernel(const GemmParams p) {
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+  constexpr int BKB = 128;  // K elements (= bytes) per tile
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nk = (p.K + BKB - 1) / BKB;
+
+  const int lr = lane >> 3;
+  const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+  int kcur = chunk * 16;
+  unsigned aoff[GA], woff[GB];
+#pragma unroll
+  for (int i = 0; i < GA; ++i) {
+    const int m = m0 + 8 * (wave + NW * i) + lr;
+    aoff[i] = (m < p.M) ? (unsigned)((long)m * p.lda) : kOOB;
+  }
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int n = n0 + 8 * (wave + NW * i) + lr;
+    woff[i] = (n < p.N) ? (unsigned)((long)n * p.ldw) : kOOB;
+  }
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  auto dma_tile = [&](int buf) {
+    const bool kok = kcur < p.K;  // K % 16 == 0: a chunk is all in or all out; out-of-range chunks land as zeros
+    unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+    unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const unsigned voff = (kok && aoff[i] != kOOB) ? aoff[i] + (unsigned)kcur : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const unsigned voff = (kok && woff[i] != kOOB) ? woff[i] + (unsigned)kcur : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+    }
+    kcur += BKB;
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  dma_tile(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  auto frag = [&](const unsigned char* T, int row, int kk) -> i32x8 {
+    const uint4 lo = *reinterpret_cast<const uint4*>(T + lds_swz<128>(row, kk * 4 + hi * 2));
+    const uint4 up = *reinterpret_cast<const uint4*>(T + lds_swz<128>(row, kk * 4 + hi * 2 + 1));
+    i32x8 f = {(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+    return f;
+  };
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma_tile(cur ^ 1);
+    const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      i32x8 fa[TM], fw[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = frag(As, wm * WTM + i * 32 + l31, kk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fw[j] = frag(Bs, wn * WTN + j * 32 + l31, kk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fw[j], fa[i], acc[j][i], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // dequantise: the lane holds D[n = 8g + 4hi + (r&3)][m = lane&31] of each 32x32 tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + l31;
+    const float sa = m < p.M ? p.sa[m] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = n0 + wn * WTN + j * 32 + 8 * g + 4 * hi;
+        f32x4 sw = {0.f, 0.f, 0.f, 0.f};
+        if (nb < p.N) sw = *reinterpret_cast<const f32x4*>(p.sw + nb);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[j][i][4 * g + x] *= sa * sw[x];
+      }
+  }
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_fp8(const GemmParams& p, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN, WM, WN>), dim3(p.tiles_m * p.tiles_n), dim3(WM * WN * 64), 0, st, p);
+}
+
 // split-K: sum the f32 partial slabs in a fixed order and apply the fused epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) {
   const long n4 = p.N >> 2;
@@ -744,7 +881,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
       if (sk < 1) sk = 1;
     }
   }
-  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1) sk = 1;
+  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8) sk = 1;
   int kper = (int)(cdiv64(cdiv64(K, sk), BK) * BK);
   sk = (int)cdiv64(K, kper);
   pl.splitk = sk;
@@ -790,6 +927,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.pad_t = d->pad_t; p.pad_l = d->pad_l; p.Ho = d->Ho; p.Wo = d->Wo; p.ups = d->upsample2x;
   p.act = d->act; p.out_mode = d->out_mode; p.res_first = d->residual_before_act;
   p.accumulate = d->accumulate;
+  p.sa = nullptr; p.sw = nullptr;
   p.nbatch = d->batch > 1 ? d->batch : 0;
   p.binner = p.nbatch ? (d->batch_inner > 0 ? d->batch_inner : 1) : 0;
   p.a_bs = d->a_bs; p.a_bs2 = d->a_bs2; p.w_bs = d->w_bs; p.w_bs2 = d->w_bs2;
@@ -828,6 +966,30 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.tiles_m = (int)cdiv64(d->M, pl.bm); p.tiles_n = (int)cdiv64(d->N, pl.bn);
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
 
+  if (d->fp8) {
+    GN_REQUIRE(!d->conv && d->batch <= 1 && d->out_mode == GN_OUT_ROWMAJOR,
+               "gn_gemm(fp8): dense row-major Linear only (no conv / batch / transposed or f32 output)");
+    GN_REQUIRE(d->scale_a && d->scale_w && ((uintptr_t)d->scale_w & 15) == 0, "gn_gemm(fp8): scale_a [M] and 16-byte aligned scale_w [N] are required");
+    GN_REQUIRE(d->K % 16 == 0 && d->lda % 16 == 0 && d->ldw % 16 == 0, "gn_gemm(fp8): K, lda, ldw must be multiples of 16 bytes");
+    GN_REQUIRE((uint64_t)d->M * d->lda < 0xFFFFFF00ull && (uint64_t)d->N * d->ldw < 0xFFFFFF00ull, "gn_gemm(fp8): operand too large for 32-bit buffer offsets");
+    p.sa = (const float*)d->scale_a; p.sw = (const float*)d->scale_w;
+    p.a_bytes = (unsigned)((uint64_t)d->M * d->lda); p.w_bytes = (unsigned)((uint64_t)d->N * d->ldw);
+    p.splitk = 1; p.kper = (int)d->K;
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7};
+    const int cfg = to_dma[pl.cfg];
+    const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
+    p.tiles_m = (int)cdiv64(d->M, bm); p.tiles_n = (int)cdiv64(d->N, bn);
+    switch (cfg) {
+      case 6: launch_fp8<256, 256, 2, 4>(p, ctx->stream); break;
+      case 7: launch_fp8<256, 128, 4, 2>(p, ctx->stream); break;
+      case 8: launch_fp8<128, 128, 2, 2>(p, ctx->stream); break;
+      case 9: launch_fp8<128, 64, 2, 2>(p, ctx->stream); break;
+      case 10: launch_fp8<64, 64, 2, 2>(p, ctx->stream); break;
+      default: launch_fp8<256, 64, 4, 1>(p, ctx->stream); break;
+    }
+    GN_LAUNCH_CHECK();
+    return GN_OK;
+  }
   const bool conv = d->conv != 0;
   switch (pl.cfg) {
     case 0: launch_cfg<256, 128, 4, 2>(p, conv, ctx->stream); break;

@@ -180,6 +180,8 @@ class Engine:
             key += f"|b{int(d.batch)}"
         if d.accumulate:
             key += "|acc"
+        if d.fp8:
+            key += "|fp8"
         return key
 
     def _autotune(self, d: GemmDesc, key: Optional[str] = None):
@@ -189,6 +191,8 @@ class Engine:
             return table[key]
         best, best_ms = 0, float("inf")
         cands = (1, 2, 5, 6, 7, 8, 9, 12) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
+        if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
+            cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         e0, e1 = self.event(), self.event()
         for c in cands:
             d.tile = c
@@ -298,6 +302,10 @@ class Engine:
         M = x.numel() // K
         N = w.shape[0]
         assert w.shape[1] == K, (w.shape, x.shape)
+        fp8w = self._fp8_weights.get(w.data_ptr()) if self._fp8_weights else None
+        if fp8w is not None and not transposed_out and splitk == 0 and M >= self.fp8_min_rows and not self.record:
+            xq, xs = self._fp8_activation(x)
+            return self.linear_fp8(xq, xs, fp8w[0], fp8w[1], bias, act=act, residual=residual, out=out, name=name)
         n_out = N // 2 if act == ACT_GEGLU else N
         d = GemmDesc()
         if transposed_out:
@@ -317,6 +325,66 @@ class Engine:
         d.ldr = residual.stride(-2) if residual is not None else 0
         d.act, d.splitk, d.out_scale = act, splitk, 1.0
         self._gemm(d, (x, w, bias, residual, out))
+        return out
+
+    # ---- fp8 (OCP e4m3) Linear: SURVEY section 8 a15 / BASELINE configs[4] "fp8 MFMA" -------------------------------------------
+    _fp8_weights = None   # {weight data_ptr: (bytes, scales, weight)} of the Linears that run on the fp8 MFMA (enable_fp8)
+    fp8_min_rows = 1024   # below this the Linear is launch-bound and the extra quantisation launch does not pay
+
+    def enable_fp8(self, weights):
+        """Route every later ``linear(x, w)`` whose ``w`` is one of ``weights`` ([N, K] f16, frozen) through the fp8 MFMA: the
+        weights are quantised once (per-output-channel scales), activations per call (per-token scales, cached while the same
+        tensor feeds several Linears, e.g. q / k / v).  Eager engines only."""
+        table = {} if self._fp8_weights is None else self._fp8_weights
+        for w in weights:
+            if w.dim() == 2 and w.shape[1] % 8 == 0 and w.shape[0] % 4 == 0 and w.data_ptr() not in table:
+                wq, ws = self.quantize_fp8(w)
+                table[w.data_ptr()] = (wq, ws, w)  # holding w keeps its address from being reused
+        self._fp8_weights = table
+        self._fp8_act = None
+
+    def _fp8_activation(self, x: torch.Tensor):
+        c = self._fp8_act
+        if c is not None and c[0] is x:  # the held reference keeps x's storage from being recycled under the cache
+            return c[1], c[2]
+        xq, xs = self.quantize_fp8(x)
+        self._fp8_act = (x, xq, xs)
+        return xq, xs
+
+    def quantize_fp8(self, x: torch.Tensor, *, name: Optional[str] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Row-wise dynamic e4m3 quantisation of x [..., K] f16 -> (bytes [..., round_up(K, 16)] uint8, scales [rows] f32).
+        Activations: per-token scales; a weight [N, K]: per-output-channel scales (quantise once, keep)."""
+        K = x.shape[-1]
+        rows = x.numel() // K
+        Kp = _round_up(K, 16)
+        q = self.buf(None if name is None else name + ".q", tuple(x.shape[:-1]) + (Kp,), dtype=torch.uint8)
+        s = self.buf(None if name is None else name + ".s", (_round_up(rows, 4),), dtype=torch.float32)
+        if self.record:
+            raise GenimaHipError("quantize_fp8 is an eager op (the fp8 Linear serves the training forward, which is not recorded)")
+        self._small("quantize_fp8_rows", (x, q, s), _ptr(x), x.stride(-2) if x.dim() > 1 else K, rows, K, _ptr(q), Kp, _ptr(s))
+        return q, s
+
+    def linear_fp8(self, xq: torch.Tensor, xs: torch.Tensor, wq: torch.Tensor, ws: torch.Tensor,
+                   bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE, residual: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, name: Optional[str] = None) -> torch.Tensor:
+        """y = act(dequant(xq) @ dequant(wq).T + bias) (+ residual) on the fp8 MFMA.  xq [..., Kp] / wq [N, Kp] uint8 e4m3 bytes
+        with their row scales xs / ws (quantize_fp8); y f16 [..., N]."""
+        Kp = xq.shape[-1]
+        M = xq.numel() // Kp
+        N = wq.shape[0]
+        assert wq.shape[1] == Kp and xq.dtype == torch.uint8 and wq.dtype == torch.uint8, (xq.shape, wq.shape)
+        n_out = N // 2 if act == ACT_GEGLU else N
+        if out is None:
+            out = self.buf(name, tuple(xq.shape[:-1]) + (n_out,))
+        d = GemmDesc()
+        d.a, d.w, d.bias, d.residual, d.out = _ptr(xq), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(out)
+        d.M, d.N, d.K = M, N, Kp
+        d.lda, d.ldw = xq.stride(-2) if xq.dim() > 1 else Kp, wq.stride(0)
+        d.ldo = out.stride(-2) if out.dim() > 1 else n_out
+        d.ldr = residual.stride(-2) if residual is not None else 0
+        d.act, d.out_mode, d.out_scale = act, OUT_ROWMAJOR, 1.0
+        d.fp8, d.scale_a, d.scale_w = 1, _ptr(xs), _ptr(ws)
+        self._gemm(d, (xq, xs, wq, ws, bias, residual, out))
         return out
 
     def conv2d(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, ksize: int = 3,

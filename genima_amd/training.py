@@ -542,6 +542,16 @@ class ControlNetTrainer:
         self._clip = torch.zeros(3, dtype=F32, device=E.device)
         self.last = {}
 
+    def enable_fp8_frozen(self) -> int:
+        """BASELINE configs[4] ("fp8 MFMA"): run the frozen UNet's transformer Linears (attention projections, GEGLU and FF-out:
+        68 % of the SDXL UNet's FLOPs) on the fp8 MFMA in the FORWARD pass -- weights quantised once with
+        per-output-channel scales, activations per call with per-token scales (engine.enable_fp8).  The data-gradient GEMMs keep
+        the f16 weight copies, and nothing of the trainable ControlNet changes.  Returns the number of weights switched."""
+        ws = [w for n, w in self.unet.W.items()
+              if isinstance(w, torch.Tensor) and w.dim() == 2 and n.endswith(".weight") and (".attn1." in n or ".attn2." in n or ".ff.net." in n)]
+        self.E.enable_fp8(ws)
+        return len(ws)
+
     # ---- forward + backward: fills self.cn.grad (loss-scaled) and returns the device loss scalar
     def forward_backward(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, c_valid: int = 4, added=None):
         """latents8 / noise8: f16 [B, h, w, 8] (channels >= c_valid zero); t_dev f32 [B] timesteps; sqrt_ac / sqrt_1mac f32 [B]

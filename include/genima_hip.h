@@ -82,12 +82,22 @@ typedef struct gn_gemm_desc {
   int32_t batch, batch_inner;
   int64_t a_bs, a_bs2, w_bs, w_bs2, out_bs, out_bs2, res_bs, res_bs2;
   int32_t accumulate;     /* GN_OUT_F32 only: out += result (gradient accumulation) */
-  int32_t reserved;
+  /* fp8 Linear (SURVEY section 8 a15 / BASELINE configs[4] "fp8 MFMA"; the reference side is the fp16 autocast Linear of
+   * diffusion/train_controlnet_sdxl_genima.py:1448-1471): 1 = a and w hold OCP e4m3 bytes (K contiguous; K, lda, ldw count bytes
+   * and are multiples of 16), out = epilogue(scale_a[m] * scale_w[n] * sum_k a*w) on v_mfma_scale_f32_32x32x64_f8f6f4.
+   * gn_quantize_fp8_rows produces the bytes and the per-row scales of both operands.  Dense row-major only. */
+  int32_t fp8;
+  const void* scale_a;    /* fp8: f32 [M] */
+  const void* scale_w;    /* fp8: f32 [N], 16-byte aligned */
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
 int32_t gn_set_gemm_tile_override(int32_t cfg);
 int32_t gn_gemm(gn_ctx* ctx, const gn_gemm_desc* d);
+/* fp8 operand preparation for gn_gemm_desc.fp8: q[r, k] = e4m3_rne(x[r, k] * 448 / amax_r), scales[r] = amax_r / 448 (1 for an
+ * all-zero row); x f16 [rows, ldx], q bytes [rows, ldq] with ldq % 16 == 0 and >= round_up(K, 16) (the pad bytes are written as
+ * zeros), scales f32 [rows].  Activations: rows = tokens; weights [N, K]: rows = output channels (done once per weight). */
+int32_t gn_quantize_fp8_rows(gn_ctx* ctx, const void* x, int64_t ldx, int64_t rows, int32_t K, void* q, int64_t ldq, void* scales);
 
 /* ---- K4/K5/K11: flash-style attention forward --------------------------------------------------------------------
  * o[b, i, h*D + :] = softmax_j(scale * q[b,i,h] . k[b,j,h]) v[b,j,h]; V is consumed TRANSPOSED (vt[b][h*D + d][j], produced
