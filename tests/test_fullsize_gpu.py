@@ -1,0 +1,74 @@
+"""-m gpu: the hot path at BASELINE.json's FULL sizes (SD-Turbo widths: 865.9 M + 364.2 M parameters).
+
+  * one denoise step (ControlNet + UNet) at full width on one 256x256 view (latent 32x32, configs[1]) against the CPU oracle --
+    the largest case the oracle finishes in seconds; it exercises every channel count / tile configuration of the real model;
+  * the 4-view tiled 512x512, batch-8, 5-step pipeline (configs[2]) through size-independent properties: bit-exact determinism,
+    bit-exact equivariance under a permutation of the episodes (every kernel is per-sample and deterministic), and the view
+    layout of the tiled output (the reference's untile_images crops, controller/utils/misc.py:22-47).
+"""
+import numpy as np
+import pytest
+import torch
+
+from genima_amd import configs, schema, weights
+from genima_amd.host import ControlNetModel, UNet2DConditionModel
+from oracle import sd_torch as O
+from util import q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FAM = configs.family("sd-turbo")
+
+
+def test_full_width_denoise_step_vs_oracle():
+    ucfg, ccfg = FAM["unet"], FAM["controlnet"]
+    usd = weights.round_to(weights.synth_state_dict(schema.unet_schema(ucfg), 21, device="cuda"), torch.float16)
+    csd = weights.round_to(weights.synth_state_dict(schema.controlnet_schema(ccfg), 22, device="cuda"), torch.float16)
+    unet, cn = UNet2DConditionModel(ucfg, usd).to("cuda"), ControlNetModel(ccfg, csd).to("cuda")
+    usd = {k: v.cpu() for k, v in usd.items()}
+    csd = {k: v.cpu() for k, v in csd.items()}
+    g = torch.Generator().manual_seed(0)
+    x, ctx = q16(torch.randn(1, 4, 32, 32, generator=g)), q16(torch.randn(1, 77, 1024, generator=g))
+    cond, t = q16(torch.rand(1, 3, 256, 256, generator=g)), torch.tensor([599.0])
+    down, mid = cn(x.half(), t, ctx.half(), cond.half(), return_dict=False)
+    eps = unet(x.half(), t, ctx.half(), down, mid).sample.float().cpu()
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    with torch.no_grad():
+        d32, m32 = O.controlnet_forward(csd, ccfg, x, t, ctx, cond)
+        e32 = O.unet_forward(usd, ucfg, x, t, ctx, d32, m32)
+    assert torch.isfinite(eps).all()
+    errs = [rel_l2(a.float().cpu(), b) for a, b in zip(down, d32)] + [rel_l2(mid.float().cpu(), m32)]
+    e = rel_l2(eps, e32)
+    print(f"full-width step: controlnet residuals rel-L2 max {max(errs):.2e}, unet eps rel-L2 {e:.2e} vs the fp32 oracle")
+    # f16 storage through ~100 layers (test_models_gpu.py: the f16-storage oracle itself sits at ~2e-3 from fp32)
+    assert max(errs) < 6e-3 and e < 6e-3
+
+
+def test_tiled_b8_pipeline_properties():
+    from genima_amd.pipeline import StableDiffusionControlNetPipeline
+    from genima_amd.tiling import untile_images
+
+    pipe = StableDiffusionControlNetPipeline.from_synthetic(FAM, seed=0, gen_device=torch.device("cuda"))
+    pipe.to("cuda")
+    B, H = 8, 512
+    img = torch.from_numpy(weights.counter_bytes(100, "full_ctrl", B * H * H * 3).reshape(B, H, H, 3))
+    ids = pipe.encode_ids(["tiled perspectives of a robot arm executing 'open box'"] * B)
+    lat = torch.randn(B, 4, 64, 64, generator=torch.Generator().manual_seed(2)).half()
+    a = pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=5, guidance_scale=0.0, output_type="np").images
+    assert a.shape == (B, H, H, 3) and a.dtype == np.uint8
+    assert pipe.scheduler.timesteps.to(torch.int64).tolist() == [999, 799, 599, 399, 199]
+    assert len({a[i].tobytes() for i in range(B)}) == B, "distinct episodes must give distinct images"
+    # determinism: a second call is bit-identical
+    b = pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=5, guidance_scale=0.0, output_type="np").images
+    assert np.array_equal(a, b)
+    # episodes are independent: permuting them permutes the output, bit for bit
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4])
+    c = pipe(prompt_ids=ids[perm], image=img[perm], latents=lat[perm], num_inference_steps=5, guidance_scale=0.0, output_type="np").images
+    assert np.array_equal(c, a[perm.numpy()])
+    # the four 256x256 views of an episode come back where the reference's untile_images crops them
+    from PIL import Image
+    cams = ["front", "wrist", "left_shoulder", "right_shoulder"]
+    views = untile_images([Image.fromarray(a[0])], cams, lambda im: im)
+    assert [views[c].shape for c in cams] == [(1, 3, 256, 256)] * 4
+    assert np.array_equal(views["wrist"][0].transpose(1, 2, 0), a[0][:256, 256:]), "cam 1 is the top-right quadrant (x = 256, y = 0)"
+    assert np.array_equal(views["left_shoulder"][0].transpose(1, 2, 0), a[0][256:, :256]), "cam 2 is the bottom-left quadrant"
