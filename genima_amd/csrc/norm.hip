@@ -261,52 +261,75 @@ int gn_pick_chunks(int B, int HW) {
 // ---- LayerNorm: one wave per row, the row lives in registers ---------------------------------------------------------
 constexpr int LN_MAXCH = 8;  // 16-byte chunks per lane -> C <= 4096
 
+// CH 16-byte chunks per lane (C <= 512 CH), ROWS rows per wave: the loads of all ROWS rows are issued before the first
+// reduction, so a wave keeps ROWS x C x 2 bytes in flight (at C = 320 one row is only 640 B: one row per wave is latency-bound).
+template <int CH, int ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma,
                                                         const f16* __restrict__ beta, f16* __restrict__ y, long M, int C,
                                                         float eps) {
   const int lane = threadIdx.x & 63;
-  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= M) return;
   const int CC = C >> 3;
-  const f16* xr = x + row * C;
-  f16x8 v[LN_MAXCH];
-  float s = 0.f;
+  f16x8 v[ROWS][CH];
+  float s[ROWS];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    const int cx = lane + 64 * i;
-    if (cx < CC) {
-      const uint4 raw = *reinterpret_cast<const uint4*>(xr + cx * 8);
-      v[i] = *reinterpret_cast<const f16x8*>(&raw);
+  for (int r = 0; r < ROWS; ++r) {
+    s[r] = 0.f;
+    const bool live = row0 + r < M;  // wave-uniform
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+    for (int i = 0; i < CH; ++i) {
+      const int cx = lane + 64 * i;
+      uint4 raw = make_uint4(0, 0, 0, 0);
+      if (live && cx < CC) raw = *reinterpret_cast<const uint4*>(x + (row0 + r) * C + cx * 8);
+      v[r][i] = *reinterpret_cast<const f16x8*>(&raw);
     }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float ss = 0.f;
+  float mean[ROWS], rstd[ROWS];
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
-    const int cx = lane + 64 * i;
-    if (cx < CC) {
+  for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { const float d = (float)v[i][e] - mean; ss += d * d; }
-    }
+    for (int i = 0; i < CH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[r] += (float)v[r][i][e];  // lanes past the row hold zeros
+    mean[r] = wave_sum(s[r]) / (float)C;
   }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-  f16* yr = y + row * C;
 #pragma unroll
-  for (int i = 0; i < LN_MAXCH; ++i) {
+  for (int r = 0; r < ROWS; ++r) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      if (lane + 64 * i < CC) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = (float)v[r][i][e] - mean[r]; ss += d * d; }
+      }
+    }
+    rstd[r] = rsqrtf(wave_sum(ss) / (float)C + eps);
+  }
+#pragma unroll
+  for (int i = 0; i < CH; ++i) {
     const int cx = lane + 64 * i;
     if (cx < CC) {
       const uint4 graw = *reinterpret_cast<const uint4*>(gamma + cx * 8);
       const uint4 braw = *reinterpret_cast<const uint4*>(beta + cx * 8);
       const f16x8 g = *reinterpret_cast<const f16x8*>(&graw);
       const f16x8 bb = *reinterpret_cast<const f16x8*>(&braw);
-      f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)v[i][e] - mean) * rstd * (float)g[e] + (float)bb[e]);
-      *reinterpret_cast<uint4*>(yr + cx * 8) = *reinterpret_cast<uint4*>(&o);
+      for (int r = 0; r < ROWS; ++r) {
+        if (row0 + r < M) {
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)v[r][i][e] - mean[r]) * rstd[r] * (float)g[e] + (float)bb[e]);
+          *reinterpret_cast<uint4*>(y + (row0 + r) * C + cx * 8) = *reinterpret_cast<uint4*>(&o);
+        }
+      }
     }
   }
+}
+
+template <int CH, int ROWS>
+void launch_layernorm(hipStream_t st, const f16* x, const f16* gamma, const f16* beta, f16* y, long M, int C, float eps) {
+  hipLaunchKernelGGL((layernorm_kernel<CH, ROWS>), dim3((unsigned)cdiv64(M, 4 * ROWS)), dim3(256), 0, st, x, gamma, beta, y, M, C, eps);
 }
 
 }  // namespace
@@ -379,8 +402,21 @@ extern "C" int32_t gn_layernorm_fwd(gn_ctx* ctx, const void* x, const void* gamm
   GN_REQUIRE(ctx && x && gamma && beta && y, "gn_layernorm_fwd: null pointer");
   GN_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LN_MAXCH, "gn_layernorm_fwd: C=%d must be a multiple of 8 and <= %d", C, 64 * 8 * LN_MAXCH);
   GN_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)gamma & 15) == 0 && ((uintptr_t)beta & 15) == 0, "gn_layernorm_fwd: 16-byte alignment");
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, ctx->stream, (const f16*)x,
-                     (const f16*)gamma, (const f16*)beta, (f16*)y, (long)M, C, eps);
+  const f16 *xp = (const f16*)x, *gp = (const f16*)gamma, *bp = (const f16*)beta;
+  const int ch = (C + 511) / 512;
+  // rows per wave: enough bytes in flight per wave for short rows, without starving the grid on small M
+  if (ch == 1) {
+    if (M >= 8192) launch_layernorm<1, 4>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+    else if (M >= 2048) launch_layernorm<1, 2>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+    else launch_layernorm<1, 1>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+  } else if (ch == 2) {
+    if (M >= 4096) launch_layernorm<2, 2>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+    else launch_layernorm<2, 1>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+  } else if (ch <= 4) {
+    launch_layernorm<4, 1>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+  } else {
+    launch_layernorm<LN_MAXCH, 1>(ctx->stream, xp, gp, bp, (f16*)y, (long)M, C, eps);
+  }
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
