@@ -212,7 +212,23 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GNParams p)
   src += (long)b * p.HW * cs + co;
   float s = 0.f, ss = 0.f;
   if (p0 < pstep) {
-    for (int r = p0; r < p.HW; r += pstep) {
+    // a group's channels are only 4-byte aligned inside a pixel (cpg * 2 bytes at offset g * cpg * 2), so the loads stay 4 bytes
+    // wide; what the loop needs is many of them in flight: 8 independent loads per thread and trip
+    int r = p0;
+    for (; r + 7 * pstep < p.HW; r += 8 * pstep) {
+      unsigned int raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const unsigned int*>(src + (long)(r + u * pstep) * cs);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        slab[(r + u * pstep) * hpg + j] = raw[u];
+        const f16x2 v = *reinterpret_cast<const f16x2*>(&raw[u]);
+        const float a = (float)v[0], bb = (float)v[1];
+        s += a + bb;
+        ss += a * a + bb * bb;
+      }
+    }
+    for (; r < p.HW; r += pstep) {
       const unsigned int raw = *reinterpret_cast<const unsigned int*>(src + (long)r * cs);
       slab[r * hpg + j] = raw;
       const f16x2 v = *reinterpret_cast<const f16x2*>(&raw);
@@ -365,14 +381,16 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   const bool saving = d->save_stats || d->save_scsh;
   {  // single-launch path when a (batch, group) slab fits in LDS
     static int fused_ok = -1;
+    static long fused_max = GNF_MAX_LDS;
     if (fused_ok < 0) {
-      const char* e = getenv("GN_GROUPNORM_FUSED");
+      const char* e = getenv("GN_GROUPNORM_FUSED");  // 0 = off; N > 1 = slab limit in KB (tuning aid)
       fused_ok = (e && e[0] == '0') ? 0 : 1;
+      if (e && atoi(e) > 1) fused_max = (long)atoi(e) * 1024;
       if (fused_ok)
-        GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, GNF_MAX_LDS));
+        GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_max));
     }
     const long slab = (long)d->HW * p.cpg * 2;
-    if (fused_ok && !saving && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= GNF_MAX_LDS &&
+    if (fused_ok && !saving && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= fused_max &&
         (long)d->B * d->groups >= 64) {
       hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups, d->B), dim3(GNF_THREADS), (size_t)slab, ctx->stream, p);
       GN_LAUNCH_CHECK();
