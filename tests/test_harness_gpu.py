@@ -39,6 +39,28 @@ def _obs(ccfg, fs=1):
     return obs
 
 
+def test_agent_resolves_the_latest_checkpoint_in_natural_order(tmp_path):
+    """controller/agent/sd_controlnet_agent.py:21-35: ``<diffusion_ckpt>/checkpoint-<max>/controlnet`` with natsort, so
+    checkpoint-10 wins over checkpoint-9 (a lexicographic sort would pick 9)."""
+    from genima_amd.host import ControlNetModel
+
+    fam = configs.family("tiny")
+    first = None
+    for step, seed in ((9, 101), (10, 102), (2, 103)):
+        sd = weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), seed)
+        ControlNetModel(fam["controlnet"], sd).save_pretrained(str(tmp_path / f"checkpoint-{step}" / "controlnet"))
+        if step == 10:
+            first = next(iter(sd.items()))
+    cfg = types.SimpleNamespace(diffusion_ckpt=str(tmp_path), sd_ckpt="synthetic:tiny", device="cuda", image_resolution=512,
+                                show_diffusion_progress=False)
+    agent = SDControlNetAgent(cfg)
+    got = agent.pipe.controlnet.state_dict()[first[0]].float().cpu()
+    assert torch.equal(got, first[1].float().cpu()), "the agent must load checkpoint-10"
+    from PIL import Image
+    assert agent.transform_to_half_resolution(Image.new("RGB", (256, 256))).size == (256, 256)
+    assert agent.transform_to_resolution(Image.new("RGB", (640, 512))).size == (512, 512)
+
+
 def test_control_step_contract():
     dagent, cagent, ccfg = _agents()
     obs, calls = _obs(ccfg), []
