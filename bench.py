@@ -45,10 +45,13 @@ WORKLOADS = {
 GFLOP_PER_CALL = {512: 8000.0, 256: 1888.0}
 
 
+PMC_TRAFFIC_FILE = "r01_v7_pmc_traffic_tiled_b8.json"
+
+
 def pmc_traffic_per_launch(family: str):
     """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
     collected as MI355X_MICROARCH.md prescribes).  None when the file is missing."""
-    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic_tiled_b8.json")
+    path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)  # tools/probes/pmc_traffic.sh re-collects it
     try:
         with open(path) as f:
             d = json.load(f)
@@ -290,7 +293,7 @@ def main():
                            "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
                            "traffic": pmc_traffic_per_launch("gemm") if args.workload == "tiled_b8" else None,
                            "traffic_note": "HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes of this "
-                                           "workload (profiles/r01_v3_pmc_traffic_tiled_b8.json: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; "
+                                           f"workload (profiles/{PMC_TRAFFIC_FILE}: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; "
                                            "the x2 is MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction); not re-collected by this run",
                            "launches_per_call": n_l, "avg_launch_ms": g_ms / max(1, n_l), "algorithmic_gflop_per_call": g_fl / 1e9,
                            "algorithmic_bytes_per_launch": sum(agg[k]["bytes"] for k in gemm_kinds) / max(1, n_l),

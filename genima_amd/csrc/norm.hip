@@ -196,12 +196,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
 // ControlNet levels, where the three dependent launches (~6 us each of launch + ramp + tail) cost more than the data movement.
 // Deterministic: fixed thread -> element mapping and a fixed-order block reduction.
 constexpr int GNF_THREADS = 512;
-constexpr int GNF_MAX_LDS = 48 * 1024;  // measured: an 82 KB slab per CU (320 ch @ 64x64) is latency-bound and loses to the 3-launch path
+constexpr int GNF_MAX_LDS = 96 * 1024;  // measured (tools/probes/gn_bench.py): with the XCD-aware group order an 80 KB slab per CU
+                                        // (320 ch @ 64x64: 22.4 vs 26.6 us; 1280 ch @ 32x32: 16.1 vs 25.6 us) beats the 3-launch path
 
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GNParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned int slab[];  // [HW][cpg/2] packed f16 pairs
   __shared__ float red[2 * (GNF_THREADS / 64)];
-  const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+  // XCD-aware group order: block x of a row of the grid runs on XCD x % 8.  Neighbouring groups share 128-byte lines of every pixel
+  // (a group is 20 .. 80 bytes of it), so XCD k takes the CONTIGUOUS groups [k G/8, (k+1) G/8) instead of every 8th one -- with
+  // the plain order each line was pulled into ~3 of the 8 L2s (PMC: 2.3x the bytes fetched that are written).
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int g = (p.G & 7) == 0 ? (int)(blockIdx.x & 7) * (p.G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   const int hpg = p.cpg >> 1;           // f16 pairs per pixel of this group
   const int j = tid % hpg, p0 = tid / hpg;
   const int pstep = GNF_THREADS / hpg;  // pixel lanes; threads >= hpg * pstep idle
