@@ -83,12 +83,25 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const AttnBwdParams p, 
 }
 
 // ---- dQ --------------------------------------------------------------------------------------------------------------------
+// XCD-aware block order (as in the forward kernel): consecutive block ids go round-robin over the 8 XCDs, so the blocks that stream
+// the same (batch, head)'s tiles get ids that land on ONE XCD's L2.  Returns (row block, head, batch) of this workgroup; the
+// divisions run in the VALU, so the results are pinned back to SGPRs (descriptors built from them must stay uniform).
+__device__ __forceinline__ void attn_bwd_block(int nblk, int heads, int& blk, int& h, int& b) {
+  const int total = gridDim.x;
+  const int slot = (total % 8 == 0) ? (int)(blockIdx.x % 8) * (total / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int bh = __builtin_amdgcn_readfirstlane(slot / nblk);
+  b = __builtin_amdgcn_readfirstlane(bh / heads);
+  h = bh - b * heads;
+  blk = slot - bh * nblk;
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int qrow = blockIdx.x * 128 + wave * 32 + l31;
+  int blk, h, b;
+  attn_bwd_block((p.Nq + 127) / 128, p.heads, blk, h, b);
+  const int qrow = blk * 128 + wave * 32 + l31;
   const bool qlive = qrow < p.Nq;
 
   const f16* kp = p.k + (long)b * p.k_bs + h * D;
@@ -199,8 +212,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int key = blockIdx.x * 128 + wave * 32 + l31;
+  int blk, h, b;
+  attn_bwd_block((p.Nk + 127) / 128, p.heads, blk, h, b);
+  const int key = blk * 128 + wave * 32 + l31;
   const bool klive = key < p.Nk;
 
   const f16* qp = p.q + (long)b * p.q_bs + h * D;
@@ -375,9 +389,9 @@ extern "C" int32_t gn_attention_bwd(gn_ctx* ctx, const gn_attn_bwd_desc* d) {
   const long nd = (long)d->B * d->Nq * d->heads;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, ctx->stream, p, d->B);
   GN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((d->Nq + 127) / 128, d->heads, d->B), dim3(256), 0, ctx->stream, p);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(((d->Nq + 127) / 128) * d->heads * d->B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((d->Nk + 127) / 128, d->heads, d->B), dim3(256), 0, ctx->stream, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(((d->Nk + 127) / 128) * d->heads * d->B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }
