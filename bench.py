@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 MFMA_PEAK_TF = 2500.0   # dense f16/bf16, MI355X_MICROARCH.md
+MFMA_SUSTAINED_TF = 1680.0  # measured: what a pure MFMA stream holds at the clock the chip sustains
 HBM_PEAK_GBS = 8000.0
 
 WORKLOADS = {
@@ -295,6 +296,10 @@ def main():
                            "traffic_note": "HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes of this "
                                            f"workload (profiles/{PMC_TRAFFIC_FILE}: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; "
                                            "the x2 is MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction); not re-collected by this run",
+                           "frac_of_sustained_mfma_rate": ach / MFMA_SUSTAINED_TF,
+                           "sustained_note": f"a pure v_mfma_f32_32x32x16_f16 stream sustains {MFMA_SUSTAINED_TF:.0f} TFLOP/s on MI355X "
+                                             "(19-21 ns per MFMA per SIMD at the ~1.6-1.7 GHz the chip holds under matrix load; "
+                                             "tools/probes/mfma_coissue.hip); `frac` stays quoted against the nominal dense peak",
                            "launches_per_call": n_l, "avg_launch_ms": g_ms / max(1, n_l), "algorithmic_gflop_per_call": g_fl / 1e9,
                            "algorithmic_bytes_per_launch": sum(agg[k]["bytes"] for k in gemm_kinds) / max(1, n_l),
                            "share_of_call_time": g_ms / sum(a["ms"] for a in agg.values())}
