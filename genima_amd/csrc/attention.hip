@@ -401,9 +401,9 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   if (d->D == 32) {
     launch_attn<32, 4, 1>(p, d->B, ctx->stream);
   } else {
-    // measured on MI355X (tools/bench_attn.py): the three block shapes are within 5 % of each other on every hot-path shape, and
-    // so is the software-pipelined kernel of attention_pipe.hip (its in-wave MFMA / VALU overlap is paid back in barrier waits at
-    // 2 waves per SIMD -- DESIGN.md); 4 waves x 32 rows is never worse and stays the default.
+    // measured on MI355X (tools/bench_attn.py, 8 x 5 x 4096^2 / 8 x 10 x 1024^2): 4 waves x 32 rows 220 / 39 us, 4 waves x 64 rows
+    // 268 / 52 (occupancy 1), 8 waves x 32 rows 252 / 46, the software-pipelined kernel of attention_pipe.hip 227-243 / 41 (its
+    // in-wave MFMA / VALU overlap is paid back in barrier waits at 2 waves per SIMD -- DESIGN.md).  4 waves x 32 rows is the default.
     const int ov = attn_variant_override();
     if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
     else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
