@@ -22,9 +22,10 @@
 //     reference (rescaling O^T and l) and re-bases the exponents -- on typical data once or twice per row;
 //   * P is packed with v_cvt_pk_f16_f32 and its row sum taken with v_dot2c_f32_f16 on the packed pairs (the sum then matches
 //     the f16 P that enters the PV MFMA exactly).
-// K/V tiles are double-buffered in LDS (one barrier per 64-key tile), global -> register loads of tile t+1 are in flight under
-// the MFMAs of tile t.  Block = NW waves x TQ x 32 query rows (template): more rows per block amortise the K/V staging and
-// LDS fragment reads over more MFMAs; the launcher picks the variant by problem size.
+// K/V tiles are double-buffered in LDS (one barrier per 64-key tile); at D = 64 tile t+1 arrives by LDS-DMA under the MFMAs of tile
+// t, at D = 32 through registers.  Block = NW waves x TQ x 32 query rows (template); 4 waves x 32 rows is the default, the other
+// shapes and the software-pipelined kernel of attention_pipe.hip stay selectable (GN_ATTN_VARIANT) for measurements.
+// Blocks are ordered XCD-aware: the query blocks of one (batch, head) share an L2.
 #include <stdlib.h>
 
 #include <type_traits>
