@@ -128,6 +128,7 @@ def main():
             "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "grad_norm_last": tr.last.get("grad_norm"),
             "loss_scale": tr.loss_scale, "applied_steps": tr.opt_step,
             "roofline": ({"bound": "mfma", "achieved": achieved, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": achieved / MFMA_PEAK_TF,
+                          "frac_of_sustained_mfma_rate": achieved / 1680.0,  # what a pure MFMA stream holds
                           "traffic": None, "note": f"whole step, algorithmic FLOPs of SURVEY.md section 8 ({tf} TFLOP per sample)"}
                          if achieved else None),
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
