@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgenima_hip.so")
 
 # enums of genima_hip.h
-ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_GEGLU = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_GEGLU, ACT_TANH3 = 0, 1, 2, 3, 4, 5, 6
 OUT_ROWMAJOR, OUT_BATCH_TRANSPOSED, OUT_F32 = 0, 1, 2
 
 

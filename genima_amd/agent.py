@@ -74,28 +74,55 @@ class DiffusionAgent:
         raise NotImplementedError()
 
 
+def _resolve_controlnet(eval_cfg):
+    """``<diffusion_ckpt>/checkpoint-<max>/controlnet`` by natural sort, else ``<diffusion_ckpt>`` itself
+    (controller/agent/sd_controlnet_agent.py:21-35).  Like the reference, a path that holds no ControlNet is an error -- never a
+    silently zero-initialised network.  Only the explicit synthetic setup (``sd_ckpt: 'synthetic:<family>'`` with an empty or
+    ``'synthetic:'`` ``diffusion_ckpt``) keeps the family's seeded synthetic ControlNet."""
+    ckpt = eval_cfg.diffusion_ckpt
+    if str(eval_cfg.sd_ckpt).startswith("synthetic:") and (not ckpt or str(ckpt).startswith("synthetic:")):
+        return None
+    if not ckpt or not os.path.isdir(str(ckpt)):
+        raise FileNotFoundError(f"diffusion_ckpt {ckpt!r} is not a directory (expected <dir>/checkpoint-N/controlnet or a ControlNet directory)")
+    dirs = sorted([d for d in os.listdir(ckpt) if "checkpoint" in d], key=_natural_key)
+    cn_dir = os.path.join(ckpt, dirs[-1], "controlnet") if dirs else ckpt
+    if not os.path.exists(os.path.join(cn_dir, "config.json")):
+        raise FileNotFoundError(f"no ControlNet checkpoint under {cn_dir} (config.json + diffusion_pytorch_model.safetensors)")
+    return ControlNetModel.from_pretrained(cn_dir)
+
+
+def _load_tiny_autoencoder(name: str):
+    from .host import AutoencoderTiny
+
+    if os.path.isdir(name):
+        return AutoencoderTiny.from_pretrained(name)
+    if name.startswith("synthetic:"):
+        return AutoencoderTiny.from_config(configs.TAESD, seed=7)
+    raise FileNotFoundError(f"autoencoder {name!r} is not a local AutoencoderTiny directory (no network access)")
+
+
 class SDControlNetAgent(DiffusionAgent):
     """SD-Turbo + ControlNet agent (controller/agent/sd_controlnet_agent.py:12-76)."""
 
+    pipeline_cls = StableDiffusionControlNetPipeline
+    tiny_tag = "taesd"
+
     def load_checkpoint(self):
         cfg = self.eval_cfg
-        ckpt = cfg.diffusion_ckpt
-        controlnet = None
-        if ckpt and os.path.isdir(ckpt):
-            dirs = sorted([d for d in os.listdir(ckpt) if "checkpoint" in d], key=_natural_key)
-            cn_dir = os.path.join(ckpt, dirs[-1], "controlnet") if dirs else ckpt
-            if os.path.exists(os.path.join(cn_dir, "config.json")):
-                controlnet = ControlNetModel.from_pretrained(cn_dir)
+        controlnet = _resolve_controlnet(cfg)
         if cfg.sd_ckpt and os.path.isdir(str(cfg.sd_ckpt)):
-            self.pipe = StableDiffusionControlNetPipeline.from_pretrained(cfg.sd_ckpt, controlnet=controlnet,
-                                                                          safety_checker=getattr(cfg, "safety_checker", None))
+            self.pipe = self.pipeline_cls.from_pretrained(cfg.sd_ckpt, controlnet=controlnet, variant="fp16",
+                                                          safety_checker=getattr(cfg, "safety_checker", None))
         elif str(cfg.sd_ckpt).startswith("synthetic:"):  # e.g. "synthetic:sd-turbo" / "synthetic:tiny" (no checkpoints offline)
-            self.pipe = StableDiffusionControlNetPipeline.from_synthetic(configs.family(str(cfg.sd_ckpt).split(":", 1)[1]))
+            self.pipe = self.pipeline_cls.from_synthetic(configs.family(str(cfg.sd_ckpt).split(":", 1)[1]))
             if controlnet is not None:
                 self.pipe.controlnet = controlnet
         else:
             raise FileNotFoundError(f"sd_ckpt {cfg.sd_ckpt!r} is not a local diffusers directory (no network access); "
                                     "use a local path or 'synthetic:<family>'")
+        autoencoder = str(getattr(cfg, "autoencoder", "") or "")
+        if self.tiny_tag in autoencoder:  # "taesd" also matches "taesdxl", exactly as the reference's substring test does
+            self.pipe.vae = _load_tiny_autoencoder(autoencoder)
 
     def infer(self, *args, **kwargs):
         return self.pipe(prompt=kwargs["prompts"], image=kwargs["images"], negative_prompt=kwargs.get("negative_prompts"),
@@ -105,27 +132,8 @@ class SDControlNetAgent(DiffusionAgent):
 
 class SDXLControlNetAgent(SDControlNetAgent):
     """SDXL-Turbo + ControlNet agent (controller/agent/sdxl_controlnet_agent.py:11-76): same checkpoint resolution and ``infer``
-    contract; the pipeline class carries the SDXL deltas.  ``autoencoder: taesdxl`` (AutoencoderTiny) is not built."""
+    contract; the pipeline class carries the SDXL deltas; ``autoencoder: taesdxl`` swaps in the AutoencoderTiny decoder (:44-49)."""
 
-    def load_checkpoint(self):
-        from .pipeline import StableDiffusionXLControlNetPipeline
+    from .pipeline import StableDiffusionXLControlNetPipeline as pipeline_cls  # noqa: E402
 
-        cfg = self.eval_cfg
-        if "taesdxl" in str(getattr(cfg, "autoencoder", "")):
-            raise NotImplementedError("AutoencoderTiny (taesdxl) is not built on the HIP path; use the SDXL AutoencoderKL")
-        ckpt = cfg.diffusion_ckpt
-        controlnet = None
-        if ckpt and os.path.isdir(ckpt):
-            dirs = sorted([d for d in os.listdir(ckpt) if "checkpoint" in d], key=_natural_key)
-            cn_dir = os.path.join(ckpt, dirs[-1], "controlnet") if dirs else ckpt
-            if os.path.exists(os.path.join(cn_dir, "config.json")):
-                controlnet = ControlNetModel.from_pretrained(cn_dir)
-        if cfg.sd_ckpt and os.path.isdir(str(cfg.sd_ckpt)):
-            self.pipe = StableDiffusionXLControlNetPipeline.from_pretrained(cfg.sd_ckpt, controlnet=controlnet)
-        elif str(cfg.sd_ckpt).startswith("synthetic:"):
-            self.pipe = StableDiffusionXLControlNetPipeline.from_synthetic(configs.family(str(cfg.sd_ckpt).split(":", 1)[1]))
-            if controlnet is not None:
-                self.pipe.controlnet = controlnet
-        else:
-            raise FileNotFoundError(f"sd_ckpt {cfg.sd_ckpt!r} is not a local diffusers directory (no network access); "
-                                    "use a local path or 'synthetic:<family>'")
+    tiny_tag = "taesdxl"

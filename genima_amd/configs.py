@@ -113,6 +113,26 @@ SD_TURBO_VAE = {
 TINY_VAE = dict(SD_TURBO_VAE, block_out_channels=[32, 64, 64, 64], sample_size=128)
 SDXL_VAE = dict(SD_TURBO_VAE, scaling_factor=0.13025, sample_size=1024)  # madebyollin/sdxl-vae-fp16-fix: same architecture
 
+TAESD = {  # madebyollin/taesd (SD-1.x / 2.x latents) and taesdxl: same architecture (diffusers AutoencoderTiny defaults)
+    "_class_name": "AutoencoderTiny",
+    "in_channels": 3,
+    "out_channels": 3,
+    "latent_channels": 4,
+    "encoder_block_out_channels": [64, 64, 64, 64],
+    "decoder_block_out_channels": [64, 64, 64, 64],
+    "block_out_channels": [64, 64, 64, 64],
+    "num_encoder_blocks": [1, 3, 3, 3],
+    "num_decoder_blocks": [3, 3, 3, 1],
+    "act_fn": "relu",
+    "upsample_fn": "nearest",
+    "upsampling_scaling_factor": 2,
+    "latent_magnitude": 3,
+    "latent_shift": 0.5,
+    "force_upcast": False,
+    "scaling_factor": 1.0,
+    "shift_factor": 0.0,
+}
+
 # ----------------------------------------------------------------------------- CLIP text towers
 SD_TURBO_TEXT = {  # OpenCLIP ViT-H/14 text tower truncated to 23 layers
     "_class_name": "CLIPTextModel",

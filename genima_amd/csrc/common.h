@@ -58,6 +58,7 @@ __device__ __forceinline__ float apply_act(float x, int act) {
     case GN_ACT_GELU: return act_gelu(x);
     case GN_ACT_QUICK_GELU: return act_quick_gelu(x);
     case GN_ACT_RELU: return fmaxf(x, 0.0f);
+    case GN_ACT_TANH3: return 3.0f * tanhf(x * (1.0f / 3.0f));
     default: return x;
   }
 }

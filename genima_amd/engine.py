@@ -170,7 +170,7 @@ class Engine:
     # recording engine times every configuration once per distinct problem and remembers the winner.  Tile choice does not
     # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
     # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
-    N_TILE_CFGS = 14  # 1..6 register-staged, 7..14 LDS-DMA (csrc/gemm.hip kCfg)
+    N_TILE_CFGS = 15  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256 (csrc/gemm.hip kCfg, csrc/gemm_pp.hip)
 
     @staticmethod
     def _tune_key(d: GemmDesc) -> str:

@@ -16,7 +16,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
 
-from ._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_SILU
+from ._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, ACT_TANH3
 from .engine import Engine
 
 
@@ -270,6 +270,39 @@ def emit_vae_encode_moments(E: Engine, W, cfg, x8: torch.Tensor) -> torch.Tensor
         h = E.groupnorm(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], G, 1e-6, act=ACT_SILU, name="norm_out")
         h = E.conv2d(h, W["encoder.conv_out.weight"], W["encoder.conv_out.bias"], name="conv_out")
         return E.conv2d(h, W["quant_conv.weight"], W["quant_conv.bias"], ksize=1, name="quant")
+
+
+# ------------------------------------------------------------------------------------------------ AutoencoderTiny (TAESD)
+def _emit_tiny_block(E: Engine, W, p: str, x):
+    """AutoencoderTinyBlock: relu(conv(relu(conv(relu(conv(x))))) + skip(x)); the skip is the identity at equal widths."""
+    with E.scope(p):
+        h = E.conv2d(x, W[p + ".conv.0.weight"], W[p + ".conv.0.bias"], act=ACT_RELU, name="c0")
+        h = E.conv2d(h, W[p + ".conv.2.weight"], W[p + ".conv.2.bias"], act=ACT_RELU, name="c2")
+        sk = E.conv2d(x, W[p + ".skip.weight"], None, ksize=1, name="skip") if (p + ".skip.weight") in W else x
+        return E.conv2d(h, W[p + ".conv.4.weight"], W[p + ".conv.4.bias"], residual=sk, act=ACT_RELU, residual_before_act=True, name="c4")
+
+
+def emit_taesd_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
+    """diffusers ``DecoderTiny.forward``: x = 3 tanh(x / 3); conv + relu; per stage {blocks, nearest-2x + bias-free conv}; last stage
+    {block, conv to RGB}; x * 2 - 1 (the affine is folded into the last conv: out_scale 2 and the pre-shifted bias
+    ``decoder.out_bias_shifted`` = bias - 0.5 that host.AutoencoderTiny packs).  z8 [B, h, w, 8] -> image [B, 8h, 8w, 8] in [-1, 1]."""
+    nb = cfg["num_decoder_blocks"]
+    with E.scope("taesd_dec"):
+        h = E.act(z8, ACT_TANH3, name="clamp")
+        h = E.conv2d(h, W["decoder.layers.0.weight"], W["decoder.layers.0.bias"], act=ACT_RELU, name="conv_in")
+        idx = 2
+        for i, n in enumerate(nb):
+            final = i == len(nb) - 1
+            for _ in range(n):
+                h = _emit_tiny_block(E, W, f"decoder.layers.{idx}", h)
+                idx += 1
+            if not final:
+                idx += 1
+                h = E.conv2d(h, W[f"decoder.layers.{idx}.weight"], None, upsample2x=True, name=f"up{i}")
+            else:
+                h = E.conv2d(h, W[f"decoder.layers.{idx}.weight"], W["decoder.out_bias_shifted"], out_scale=2.0, name="conv_out")
+            idx += 1
+        return h
 
 
 # ------------------------------------------------------------------------------------------------ CLIP text tower

@@ -65,6 +65,7 @@ class HipModule:
         self.W = None
         self.training = False
         self._engine: Optional[Engine] = None
+        self._pack_gen = 0  # bumped by every re-pack: recorded programs bake the packed tensors' addresses in (pipeline cache key)
 
     # ---- checkpoint / config surface --------------------------------------------------------------------------------
     def _check(self, sd):
@@ -82,7 +83,10 @@ class HipModule:
 
     @classmethod
     def from_pretrained(cls, path, subfolder: Optional[str] = None, torch_dtype=None, variant=None, **kw):
-        cfg, sd = weights.load_diffusers_dir(path, subfolder)
+        """``variant`` selects the weight file as diffusers does: None = the full-precision file, "fp16" = ``*.fp16.safetensors``
+        (the agents pass variant="fp16", the trainer None: controller/agent/sd_controlnet_agent.py:36-42,
+        diffusion/train_controlnet_genima.py:1042-1064)."""
+        cfg, sd = weights.load_diffusers_dir(path, subfolder, variant=variant)
         return cls(cfg, sd)
 
     def save_pretrained(self, path, **kw):
@@ -133,6 +137,7 @@ class HipModule:
     # ---- device ---------------------------------------------------------------------------------------------------
     def _pack(self):
         self.W = packing.pack_state_dict(self._sd, self.device)
+        self._pack_gen += 1
 
     def to(self, device=None, dtype=None, memory_format=None, **kw):
         if isinstance(device, torch.dtype):
@@ -268,6 +273,30 @@ class AutoencoderKL(HipModule):
         m = graphs.emit_vae_encode_moments(E, self.W, self.config, x8)
         dist = DiagonalGaussianDistribution(nhwc_to_nchw(m, 2 * self.config["latent_channels"]))
         return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
+
+
+class AutoencoderTiny(HipModule):
+    """diffusers ``AutoencoderTiny`` (TAESD): the fast decoder the agents swap in when ``autoencoder`` names a taesd checkpoint
+    (controller/agent/sd_controlnet_agent.py:45-49, sdxl_controlnet_agent.py:44-49).  Decode only: the trainer encodes with the
+    AutoencoderKL."""
+    schema_fn = staticmethod(schema.taesd_schema)
+
+    def _pack(self):
+        super()._pack()
+        last = max(int(k.split(".")[2]) for k in self._sd if k.startswith("decoder.layers.") and k.endswith(".bias"))
+        b = self._sd[f"decoder.layers.{last}.bias"]
+        self.W["decoder.out_bias_shifted"] = packing.pack_vec(b - 0.5, self.W[f"decoder.layers.{last}.weight"].shape[0]).to(self.device)
+
+    def decode(self, z, return_dict=True, **kw):
+        E = self.engine()
+        z8 = nchw_to_nhwc(z.to(self.device, torch.float16), 8)
+        img = graphs.emit_taesd_decode(E, self.W, self.config, z8)
+        out = nhwc_to_nchw(img, self.config["out_channels"])
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    def encode(self, x, return_dict=True):
+        raise NotImplementedError("AutoencoderTiny.encode is not on the Genima hot path (the trainer encodes with AutoencoderKL, "
+                                  "diffusion/train_controlnet_genima.py:1329-1332)")
 
 
 class CLIPTextModel(HipModule):

@@ -21,15 +21,30 @@ import torch
 
 from . import graphs
 from .engine import Engine
-from .host import AutoencoderKL, CLIPTextModel, ControlNetModel, UNet2DConditionModel
+from .host import AutoencoderKL, AutoencoderTiny, CLIPTextModel, ControlNetModel, UNet2DConditionModel
 from .scheduler import EulerDiscreteScheduler
 from ._lib import GenimaHipError
 
 
+def _load_tokenizer(path: str, subfolder: str, allow_hash: bool, vocab_size: int):
+    """The checkpoint's CLIP BPE tokenizer (genima_amd/tokenizer.py).  A pipeline with REAL weights must not fall back to hashed
+    ids -- the prompt embedding would be meaningless -- so a missing ``vocab.json`` / ``merges.txt`` raises unless the caller opts in
+    (``allow_hash_tokenizer=True``: synthetic-weight benchmarks and tests)."""
+    from .tokenizer import CLIPTokenizer
+
+    try:
+        return CLIPTokenizer.from_pretrained(path, subfolder)
+    except FileNotFoundError:
+        if allow_hash:
+            return HashTokenizer(vocab_size)
+        raise FileNotFoundError(f"{os.path.join(path, subfolder)} holds no CLIP BPE model (vocab.json + merges.txt): a checkpoint with real "
+                                "weights needs its real tokenizer; pass allow_hash_tokenizer=True only for synthetic weights") from None
+
+
 class HashTokenizer:
-    """Stand-in tokenizer: the CLIP BPE vocab/merges are not available offline, so words are hashed to
-    ids in [1000, vocab-3); BOS/EOS/pad ids and the pad-to-77 shape follow the SD-2.x tokenizer.  A real
-    ``transformers.CLIPTokenizer`` can be passed to the pipeline instead; with a released checkpoint it must be."""
+    """Stand-in tokenizer for SYNTHETIC weights only: the CLIP BPE vocab/merges are not available offline,
+    so words are hashed to ids in [1000, vocab-3); BOS/EOS/pad ids and the pad-to-77 shape follow the SD-2.x tokenizer.
+    ``from_pretrained`` loads the checkpoint's real BPE model (genima_amd/tokenizer.py) and refuses to fall back to this class."""
 
     model_max_length = 77
 
@@ -90,24 +105,18 @@ class StableDiffusionControlNetPipeline:
 
     # ---- construction ----------------------------------------------------------------------------------------------
     @classmethod
-    def from_pretrained(cls, path, controlnet=None, safety_checker=None, torch_dtype=None, variant=None, **kw):
-        """Reads the diffusers pipeline directory layout (``unet/``, ``vae/``, ``text_encoder/``, ``scheduler/``)."""
+    def from_pretrained(cls, path, controlnet=None, safety_checker=None, torch_dtype=None, variant=None,
+                        allow_hash_tokenizer: bool = False, **kw):
+        """Reads the diffusers pipeline directory layout (``unet/``, ``vae/``, ``text_encoder/``, ``tokenizer/``, ``scheduler/``);
+        ``variant`` selects ``*.fp16.safetensors`` as in the reference's call (controller/agent/sd_controlnet_agent.py:36-42)."""
         import json
-        import os
 
-        unet = UNet2DConditionModel.from_pretrained(path, "unet")
-        vae = AutoencoderKL.from_pretrained(path, "vae")
-        text = CLIPTextModel.from_pretrained(path, "text_encoder")
+        unet = UNet2DConditionModel.from_pretrained(path, "unet", variant=variant)
+        vae = AutoencoderKL.from_pretrained(path, "vae", variant=variant)
+        text = CLIPTextModel.from_pretrained(path, "text_encoder", variant=variant)
         with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
             sched = EulerDiscreteScheduler.from_config(json.load(f))
-        tok = None
-        try:  # a real CLIP tokenizer if its vocab is present
-            from transformers import CLIPTokenizer
-
-            if os.path.exists(os.path.join(path, "tokenizer", "vocab.json")):
-                tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
-        except Exception:
-            tok = None
+        tok = _load_tokenizer(path, "tokenizer", allow_hash_tokenizer, text.config["vocab_size"])
         if controlnet is None:
             controlnet = ControlNetModel.from_unet(unet)
         return cls(vae, text, tok, unet, controlnet, sched, safety_checker)
@@ -140,6 +149,9 @@ class StableDiffusionControlNetPipeline:
         return None  # q|k are always fused at pack time
 
     def upcast_vae(self):
+        """diffusers casts the VAE to fp32 here.  The HIP VAE stores activations in f16 and accumulates in f32: the SD-2.x VAE and
+        the SDXL fp16-fix VAE are in range in that format, so there is nothing to upcast; a VAE that needs fp32 activations
+        (``force_upcast``) is rejected when the SDXL pipeline is built, not silently run in f16."""
         return None
 
     def enable_vae_slicing(self):
@@ -231,7 +243,10 @@ class StableDiffusionControlNetPipeline:
                 io.ops_per_step = E.num_ops - io.first_step_op
         io.first_vae_op = E.num_ops
         z8 = E.scale_pad(io.latents, 1.0 / self.vae.config["scaling_factor"], 8, name="z8")
-        img = graphs.emit_vae_decode(E, self.vae.W, self.vae.config, z8)
+        if isinstance(self.vae, AutoencoderTiny):  # autoencoder: taesd (controller/agent/sd_controlnet_agent.py:45-49)
+            img = graphs.emit_taesd_decode(E, self.vae.W, self.vae.config, z8)
+        else:
+            img = graphs.emit_vae_decode(E, self.vae.W, self.vae.config, z8)
         io.out_u8 = E.image_f16_to_u8(img, name="out_u8")
         io.engine = E
         from .engine import save_tune_table
@@ -247,9 +262,17 @@ class StableDiffusionControlNetPipeline:
             io.stream = side
         return io
 
+    def _modules(self):
+        return (self.vae, self.text_encoder, self.unet, self.controlnet)
+
     def program(self, B, H, W, steps):
-        key = (B, H, W, steps)
+        # a recorded program bakes in the scheduler's tables and the packed weights' addresses: swapping pipe.scheduler /
+        # pipe.controlnet / pipe.vae or re-packing a module (load_state_dict) must not replay the stale program
+        sch = self.scheduler
+        key = (B, H, W, steps, id(sch), type(sch).__name__, getattr(sch.config, "timestep_spacing", None),
+               tuple((id(m), m._pack_gen) for m in self._modules()))
         if key not in self._progs:
+            self._progs = {k: v for k, v in self._progs.items() if k[4:] == key[4:]}  # drop programs of replaced modules
             if self.unet.W is None:
                 raise GenimaHipError("pipeline is not on a ROCm device: call pipe.to('cuda') first (no CPU fallback)")
             self._progs[key] = self._build(B, H, W, steps)
@@ -344,24 +367,32 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         self.tokenizer_2 = tokenizer_2 or HashTokenizer(text_encoder_2.config["vocab_size"])
 
     @classmethod
-    def from_pretrained(cls, path, controlnet=None, safety_checker=None, torch_dtype=None, variant=None, **kw):
-        """diffusers SDXL pipeline directory: ``unet/ vae/ text_encoder/ text_encoder_2/ scheduler/``."""
+    def from_pretrained(cls, path, controlnet=None, safety_checker=None, torch_dtype=None, variant=None,
+                        allow_hash_tokenizer: bool = False, allow_fp16_vae: bool = False, **kw):
+        """diffusers SDXL pipeline directory: ``unet/ vae/ text_encoder/ text_encoder_2/ tokenizer/ tokenizer_2/ scheduler/``."""
         import json
-        import os
 
         from .host import CLIPTextModelWithProjection
         from .scheduler import EulerAncestralDiscreteScheduler
 
-        unet = UNet2DConditionModel.from_pretrained(path, "unet")
-        vae = AutoencoderKL.from_pretrained(path, "vae")
-        text = CLIPTextModel.from_pretrained(path, "text_encoder")
-        text2 = CLIPTextModelWithProjection.from_pretrained(path, "text_encoder_2")
+        unet = UNet2DConditionModel.from_pretrained(path, "unet", variant=variant)
+        vae = AutoencoderKL.from_pretrained(path, "vae", variant=variant)
+        # diffusers' SDXL pipeline decodes in fp32 when vae.config.force_upcast is set (the stock SDXL VAE overflows f16 and yields
+        # NaN / black images); the HIP VAE keeps f16 activations, so such a VAE is refused here instead of producing garbage
+        if vae.config.get("force_upcast", True) and not allow_fp16_vae:
+            raise NotImplementedError(f"{os.path.join(path, 'vae')} sets force_upcast (the stock SDXL VAE overflows in f16); use the fp16-fix "
+                                      "VAE (madebyollin/sdxl-vae-fp16-fix, the trainer's --pretrained_vae_model_name_or_path) or a "
+                                      "taesdxl autoencoder, or pass allow_fp16_vae=True if this VAE is known to be f16-safe")
+        text = CLIPTextModel.from_pretrained(path, "text_encoder", variant=variant)
+        text2 = CLIPTextModelWithProjection.from_pretrained(path, "text_encoder_2", variant=variant)
         with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:
             cfg = json.load(f)
         sched_cls = EulerAncestralDiscreteScheduler if "Ancestral" in cfg.get("_class_name", "EulerAncestral") else EulerDiscreteScheduler
+        tok = _load_tokenizer(path, "tokenizer", allow_hash_tokenizer, text.config["vocab_size"])
+        tok2 = _load_tokenizer(path, "tokenizer_2", allow_hash_tokenizer, text2.config["vocab_size"])
         if controlnet is None:
             controlnet = ControlNetModel.from_unet(unet)
-        return cls(vae, text, text2, None, None, unet, controlnet, sched_cls.from_config(cfg))
+        return cls(vae, text, text2, tok, tok2, unet, controlnet, sched_cls.from_config(cfg))
 
     @classmethod
     def from_synthetic(cls, family: dict, seed: int = 0, gen_device="cpu"):
@@ -379,6 +410,9 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         if device is not None and not isinstance(device, torch.dtype):
             self.text_encoder_2.to(device)
         return super().to(device, *a, **k)
+
+    def _modules(self):
+        return super()._modules() + (self.text_encoder_2,)
 
     def _emit_prompt(self, E: Engine, io, B: int, L: int, H: int, W: int):
         io.ids2 = E.buf("in_ids2", (B, L), dtype=torch.int32, zero=True)

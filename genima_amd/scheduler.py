@@ -40,6 +40,9 @@ class EulerDiscreteScheduler:
         full = dict(SD_TURBO_SCHEDULER)
         full.update(cfg)
         self.config = _Config(**full)
+        if full.get("prediction_type", "epsilon") != "epsilon":  # the device step is x + eps * (sigma_next - sigma) only
+            raise NotImplementedError(f"{type(self).__name__}: prediction_type={full['prediction_type']!r} is not built "
+                                      "(SD-Turbo / SDXL-Turbo predict epsilon; SURVEY.md Appendix B)")
         self.alphas_cumprod = _alphas_cumprod(full)
         ac = self.alphas_cumprod
         self._train_sigmas = (((1 - ac) / ac) ** 0.5).numpy()

@@ -196,6 +196,49 @@ def vae_schema(cfg, encoder=True, decoder=True) -> "OrderedDict[str, Shape]":
     return s
 
 
+def _tiny_block(s, p, cin, cout):
+    for k in (0, 2, 4):
+        _conv(s, f"{p}.conv.{k}", cin if k == 0 else cout, cout, 3)
+    if cin != cout:
+        _conv(s, p + ".skip", cin, cout, 1, bias=False)
+
+
+def taesd_schema(cfg, encoder=True, decoder=True) -> "OrderedDict[str, Shape]":
+    """diffusers ``AutoencoderTiny`` (TAESD / TAESDXL; controller/agent/sd_controlnet_agent.py:45-49): ``nn.Sequential`` encoder /
+    decoder whose entries are convs, ``AutoencoderTinyBlock`` s (conv.0 / conv.2 / conv.4 + optional 1x1 ``skip``) and parameter-free
+    activations / upsamplers -- the sequential index of every entry is part of the key."""
+    s: "OrderedDict[str, Shape]" = OrderedDict()
+    lat = cfg["latent_channels"]
+    if encoder:
+        ch, nb = cfg["encoder_block_out_channels"], cfg["num_encoder_blocks"]
+        idx, cin = 0, cfg["in_channels"]
+        for i, n in enumerate(nb):
+            if i == 0:
+                _conv(s, f"encoder.layers.{idx}", cin, ch[i], 3)
+            else:
+                _conv(s, f"encoder.layers.{idx}", cin, ch[i], 3, bias=False)  # stride 2
+            idx += 1
+            for _ in range(n):
+                _tiny_block(s, f"encoder.layers.{idx}", ch[i], ch[i])
+                idx += 1
+            cin = ch[i]
+        _conv(s, f"encoder.layers.{idx}", cin, lat, 3)
+    if decoder:
+        ch, nb = cfg["decoder_block_out_channels"], cfg["num_decoder_blocks"]
+        _conv(s, "decoder.layers.0", lat, ch[0], 3)
+        idx = 2  # layers.1 is the activation
+        for i, n in enumerate(nb):
+            final = i == len(nb) - 1
+            for _ in range(n):
+                _tiny_block(s, f"decoder.layers.{idx}", ch[i], ch[i])
+                idx += 1
+            if not final:
+                idx += 1  # nn.Upsample
+            _conv(s, f"decoder.layers.{idx}", ch[i], cfg["out_channels"] if final else ch[i], 3, bias=final)
+            idx += 1
+    return s
+
+
 def clip_text_schema(cfg) -> "OrderedDict[str, Shape]":
     s: "OrderedDict[str, Shape]" = OrderedDict()
     d, ff = cfg["hidden_size"], cfg["intermediate_size"]

@@ -530,13 +530,20 @@ class ControlNetTrainer:
 
     def __init__(self, E: Engine, unet_cfg, controlnet_cfg, unet_W, controlnet_sd, *, lr: float = 1e-5, betas=(0.9, 0.999),
                  weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, loss_scale: float = 65536.0,
-                 growth_interval: int = 2000, allreduce=None):
+                 growth_interval: int = 2000, allreduce=None, gradient_accumulation_steps: int = 1, lr_lambda=None):
+        """``gradient_accumulation_steps``: micro-batches per optimizer step (``accelerator.accumulate`` + the 1/N loss scaling of
+        ``accelerator.backward``, diffusion/train_controlnet_genima.py:1319, :1402); ``lr_lambda``: step -> multiplier of ``lr``
+        (train_loop.get_scheduler = the reference's ``get_scheduler(args.lr_scheduler, ...)``, :1206-1213), advanced once per APPLIED
+        optimizer step as accelerate's scheduler wrapper does (a step skipped by the GradScaler does not advance it)."""
         self.E, self.unet_cfg, self.cn_cfg = E, unet_cfg, controlnet_cfg
         self.unet = FrozenParams(E, unet_W)
         self.cn = TrainParams(E, controlnet_sd)
         self.lr, self.betas, self.wd, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
         self.loss_scale, self.growth_interval, self._clean = float(loss_scale), growth_interval, 0
         self.opt_step = 0
+        self.grad_accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
+        self.lr_lambda, self.sched_step = lr_lambda, 0
+        self.sync_gradients = True  # accelerator.sync_gradients: did the last step() call apply an optimizer step?
         self.allreduce = allreduce  # callable(flat f32 grad buffer) -> None: mean over ranks (dist.allreduce_mean_flat)
         self._ss = torch.zeros(1, dtype=F32, device=E.device)
         self._clip = torch.zeros(3, dtype=F32, device=E.device)
@@ -563,7 +570,7 @@ class ControlNetTrainer:
         ctx_pad, L = pad_context(ctx), ctx.shape[1]
         down, mid = t_controlnet(g, self.cn, self.cn_cfg, noisy, t_dev, ctx_pad, L, cond8, added)
         pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid, added)
-        loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale)
+        loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale / self.grad_accum)
         pred.cell[0] = dpred
         g.backward()
         self.last["pred"] = pred.t
@@ -578,10 +585,13 @@ class ControlNetTrainer:
         T.sumsq(E, cn.grad, self._ss)
         T.clip_coef(E, self._ss, self._clip, self.max_grad_norm, inv)
         self.opt_step += 1
-        T.adamw(E, cn.master, cn.grad, cn.exp_avg, cn.exp_avg_sq, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.opt_step,
-                self._clip, inv)
+        T.adamw(E, cn.master, cn.grad, cn.exp_avg, cn.exp_avg_sq, self.current_lr(), self.betas[0], self.betas[1], self.eps, self.wd,
+                self.opt_step, self._clip, inv)
         cn.sync_half()
         cn.zero_grad()
+
+    def current_lr(self) -> float:
+        return self.lr * (float(self.lr_lambda(self.sched_step)) if self.lr_lambda is not None else 1.0)
 
     def update_scale(self) -> bool:
         """GradScaler.update(): one host read of the found-inf flag.  Returns True when the step was applied."""
@@ -592,6 +602,7 @@ class ControlNetTrainer:
             self._clean = 0
             self.opt_step -= 1  # the skipped step does not advance Adam's bias correction
             return False
+        self.sched_step += 1
         self._clean += 1
         if self._clean >= self.growth_interval:
             self.loss_scale *= 2.0
@@ -600,8 +611,11 @@ class ControlNetTrainer:
 
     def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=None) -> torch.Tensor:
         loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
-        self.optimizer_step()
-        self.update_scale()
+        self._micro += 1
+        self.sync_gradients = self._micro % self.grad_accum == 0
+        if self.sync_gradients:  # gradients of the micro-batches accumulate in the flat buffer until here
+            self.optimizer_step()
+            self.update_scale()
         return loss
 
     # ---- checkpoints: diffusers ControlNet directory + optimizer state (diffusion/train_controlnet_genima.py:1077-1105, 1416-1457, 1486)
@@ -622,7 +636,7 @@ class ControlNetTrainer:
         d = os.path.join(output_dir, f"checkpoint-{global_step}")
         self.save_pretrained(os.path.join(d, "controlnet"))
         save_file({"exp_avg": self.cn.exp_avg.cpu(), "exp_avg_sq": self.cn.exp_avg_sq.cpu(),
-                   "scalars": torch.tensor([self.opt_step, self.loss_scale, self._clean, global_step], dtype=torch.float64)},
+                   "scalars": torch.tensor([self.opt_step, self.loss_scale, self._clean, global_step, self.sched_step], dtype=torch.float64)},
                   os.path.join(d, "optimizer_flat.safetensors"))
         return d
 
@@ -639,8 +653,10 @@ class ControlNetTrainer:
         st = load_file(os.path.join(checkpoint_dir, "optimizer_flat.safetensors"))
         self.cn.exp_avg.copy_(st["exp_avg"])
         self.cn.exp_avg_sq.copy_(st["exp_avg_sq"])
-        self.opt_step, self.loss_scale, self._clean, gstep = (float(v) for v in st["scalars"])
-        self.opt_step, self._clean = int(self.opt_step), int(self._clean)
+        sc = [float(v) for v in st["scalars"]]
+        self.opt_step, self.loss_scale, self._clean, gstep = sc[:4]
+        self.sched_step = int(sc[4]) if len(sc) > 4 else int(gstep)
+        self.opt_step, self._clean, self._micro = int(self.opt_step), int(self._clean), 0
         self.cn.sync_half()
         self.cn.zero_grad()
         return int(gstep)
@@ -652,6 +668,9 @@ class ControlNetTrainer:
         SDXL: the second, projection tower of train_controlnet_sdxl_genima.py:1027-1071 as ``text2_*``)."""
         self.vae_cfg, self.vae_W, self.text_cfg, self.text_W, self.noise_scheduler = vae_cfg, vae_W, text_cfg, text_W, noise_scheduler
         self.text2_cfg, self.text2_W = text2_cfg, text2_W
+        pt = noise_scheduler.config.get("prediction_type", "epsilon")
+        if pt != "epsilon":  # the reference also handles v_prediction (:1391-1399 get_velocity); SD-Turbo / SDXL-Turbo are epsilon models
+            raise NotImplementedError(f"prediction_type={pt!r}: only the epsilon target (target = noise) of the Turbo checkpoints is built")
         self.augmentations = augmentations  # the reference's --augmentations comma list ("crop,colorjitter" in the README recipe)
         self._gen_dev = torch.Generator(device=self.E.device).manual_seed(seed)
         self._gen_cpu = torch.Generator().manual_seed(seed)

@@ -143,25 +143,45 @@ def round_to(sd: Dict[str, torch.Tensor], dtype: torch.dtype) -> "OrderedDict[st
 
 
 # ----------------------------------------------------------------------------- diffusers-style directories
-_WEIGHT_FILES = (
-    "diffusion_pytorch_model.fp16.safetensors", "diffusion_pytorch_model.safetensors",
-    "model.fp16.safetensors", "model.safetensors",
-)
+_WEIGHT_STEMS = ("diffusion_pytorch_model", "model")
 
 
-def load_diffusers_dir(path: str, subfolder: Optional[str] = None):
-    """Return (config dict, fp32 state dict) from a diffusers/transformers component directory."""
+def _load_safetensors(d: str, stem: str, variant: Optional[str]):
+    """One component's tensors from ``<stem>[.<variant>].safetensors`` or its sharded form (``<stem>[.<variant>].safetensors.index.json``
+    + ``<stem>-0000x-of-0000y[.<variant>].safetensors``); None if neither exists."""
     from safetensors.torch import load_file
 
+    suffix = f".{variant}" if variant else ""
+    single = os.path.join(d, f"{stem}{suffix}.safetensors")
+    if os.path.exists(single):
+        return load_file(single)
+    index = os.path.join(d, f"{stem}.safetensors.index{suffix}.json")  # diffusers' naming; transformers puts the variant first
+    if not os.path.exists(index):
+        index = os.path.join(d, f"{stem}{suffix}.safetensors.index.json")
+    if os.path.exists(index):
+        with open(index) as f:
+            shards = sorted(set(json.load(f)["weight_map"].values()))
+        sd = {}
+        for fn in shards:
+            sd.update(load_file(os.path.join(d, fn)))
+        return sd
+    return None
+
+
+def load_diffusers_dir(path: str, subfolder: Optional[str] = None, variant: Optional[str] = None):
+    """Return (config dict, fp32 state dict) from a diffusers/transformers component directory.  ``variant=None`` reads the
+    full-precision file and ``variant="fp16"`` the ``.fp16`` one, as diffusers does; when only the other one exists it is used
+    (diffusers would raise or warn depending on the version -- a directory saved by this repo always holds the plain name)."""
     d = os.path.join(path, subfolder) if subfolder else path
     with open(os.path.join(d, "config.json")) as f:
         cfg = json.load(f)
-    for fn in _WEIGHT_FILES:
-        p = os.path.join(d, fn)
-        if os.path.exists(p):
-            sd = load_file(p)
-            return cfg, OrderedDict((k, v.to(torch.float32)) for k, v in sd.items())
-    raise FileNotFoundError(f"no safetensors weight file under {d} (looked for {_WEIGHT_FILES})")
+    order = [variant, None] if variant else [None, "fp16"]
+    for v in order:
+        for stem in _WEIGHT_STEMS:
+            sd = _load_safetensors(d, stem, v)
+            if sd is not None:
+                return cfg, OrderedDict((k, t.to(torch.float32)) for k, t in sd.items())
+    raise FileNotFoundError(f"no safetensors weight file under {d} (looked for {_WEIGHT_STEMS} with variants {order}, single or sharded)")
 
 
 def save_diffusers_dir(path: str, cfg: dict, sd: Dict[str, torch.Tensor], dtype=torch.float32,

@@ -29,7 +29,8 @@ extern "C" {
 #define GN_ERR_UNSUPPORTED (-3)
 
 /* epilogue activations */
-enum { GN_ACT_NONE = 0, GN_ACT_SILU = 1, GN_ACT_GELU = 2, GN_ACT_QUICK_GELU = 3, GN_ACT_RELU = 4, GN_ACT_GEGLU = 5 };
+enum { GN_ACT_NONE = 0, GN_ACT_SILU = 1, GN_ACT_GELU = 2, GN_ACT_QUICK_GELU = 3, GN_ACT_RELU = 4, GN_ACT_GEGLU = 5,
+       GN_ACT_TANH3 = 6 /* 3*tanh(x/3): AutoencoderTiny's latent clamp (controller/agent/sd_controlnet_agent.py:45-49); gn_act only */ };
 /* output modes of the GEMM epilogue */
 enum { GN_OUT_ROWMAJOR = 0, GN_OUT_BATCH_TRANSPOSED = 1, GN_OUT_F32 = 2 /* row-major float output, ldo in floats */ };
 
@@ -72,7 +73,8 @@ typedef struct gn_gemm_desc {
   int32_t rows_per_batch; /* for shift / transposed output; 0 = M */
   int32_t splitk;         /* 0 = library heuristic, >=1 explicit */
   int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} register-staged block tile,
-                             7..14 = {256x256, 256x128, 128x128, 128x64, 64x64, 256x64, 128x320, 256x320} LDS-DMA block tile
+                             7..14 = {256x256, 256x128, 128x128, 128x64, 64x64, 256x64, 128x320, 256x320} LDS-DMA block tile,
+                             15 = 256x256 ping-pong (8-phase, counted vmcnt; K % 64 == 0, conv C1/C2 % 64 == 0, no GEGLU / batch)
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */

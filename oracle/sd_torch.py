@@ -288,6 +288,35 @@ def vae_encode_moments(sd, cfg, x: Tensor, q=_id) -> Tuple[Tensor, Tensor]:
     return mean, logvar.clamp(-30.0, 20.0)
 
 
+def _tiny_block(sd, p, x, q=_id):
+    h = q(F.relu(conv(sd, p + ".conv.0", x)))
+    h = q(F.relu(conv(sd, p + ".conv.2", h)))
+    sk = F.conv2d(x, _w(sd, p + ".skip")) if (p + ".skip.weight") in sd else x
+    return q(F.relu(conv(sd, p + ".conv.4", h) + sk))
+
+
+def taesd_decode(sd, cfg, z: Tensor, q=_id) -> Tensor:
+    """diffusers 0.29 ``AutoencoderTiny.decode`` = ``DecoderTiny.forward`` (models/autoencoders/vae.py): clamp by 3 tanh(x / 3), the
+    ``nn.Sequential`` of convs / AutoencoderTinyBlock s / nearest-2x upsamplers, then ``x.mul(2).sub(1)``."""
+    nb = cfg["num_decoder_blocks"]
+    h = q(torch.tanh(z / 3.0) * 3.0)
+    h = q(F.relu(conv(sd, "decoder.layers.0", h)))
+    idx = 2
+    for i, n in enumerate(nb):
+        final = i == len(nb) - 1
+        for _ in range(n):
+            h = _tiny_block(sd, f"decoder.layers.{idx}", h, q)
+            idx += 1
+        if not final:
+            idx += 1
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = q(F.conv2d(h, _w(sd, f"decoder.layers.{idx}"), None, padding=1))
+        else:
+            h = conv(sd, f"decoder.layers.{idx}", h)
+        idx += 1
+    return q(h * 2.0 - 1.0)
+
+
 def vae_postprocess_u8(img: Tensor) -> Tensor:
     """``VaeImageProcessor.postprocess(output_type="pil")`` numerics: NCHW float -> NHWC uint8
     (SURVEY Appendix D.6).  ``round`` is round-half-to-even like numpy's."""

@@ -1,0 +1,121 @@
+"""-m gpu: round-2 additions on the HIP path -- AutoencoderTiny (TAESD) decode, the agents' ``autoencoder: taesd`` switch, recorded
+program invalidation when a module or the scheduler is replaced, gradient accumulation + lr schedule of the fine-tune step."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from genima_amd import configs, schema, weights
+from oracle import sd_torch as O
+from tests.util import assert_close, q16
+
+pytestmark = pytest.mark.gpu
+
+
+def test_taesd_decode_matches_oracle():
+    """controller/agent/sd_controlnet_agent.py:45-49: ``AutoencoderTiny.decode`` at full TAESD width (it IS tiny: 1.22 M params)."""
+    from genima_amd.host import AutoencoderTiny
+
+    sd = weights.round_to(weights.synth_state_dict(schema.taesd_schema(configs.TAESD), 11), torch.float16)
+    vae = AutoencoderTiny(configs.TAESD, sd).to("cuda")
+    z = (torch.randn(2, 4, 16, 24, generator=torch.Generator().manual_seed(3)) * 2.5).half()
+    got = vae.decode(z).sample.float().cpu()
+    with torch.no_grad():
+        ref = O.taesd_decode(sd, configs.TAESD, z.float())
+        ref16 = O.taesd_decode(sd, configs.TAESD, z.float(), q16)
+    assert tuple(got.shape) == (2, 3, 128, 192)
+    e = assert_close(got, ref, rel=2e-3, what="taesd decode vs fp32 oracle")
+    from tests.util import rel_l2
+    assert e <= 1.5 * rel_l2(ref16, ref) + 5e-4, "HIP decode should be as close to fp32 as the f16-storage oracle is"
+
+
+def _agent_cfg(**kw):
+    base = dict(diffusion_ckpt="", sd_ckpt="synthetic:tiny", device="cuda", image_resolution=512, vae_slicing=False, upcast_vae=False,
+                fused_projections=True, enable_xformers_memory_efficient_attention=True, show_diffusion_progress=False,
+                torch_compile=False, autoencoder="")
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_agent_taesd_switch_and_program_invalidation(tmp_path):
+    from genima_amd.agent import SDControlNetAgent
+    from genima_amd.host import AutoencoderTiny, ControlNetModel
+
+    tdir = str(tmp_path / "taesd")
+    AutoencoderTiny.from_config(configs.TAESD, seed=5).save_pretrained(tdir)
+    agent = SDControlNetAgent(_agent_cfg(autoencoder=tdir))
+    assert isinstance(agent.pipe.vae, AutoencoderTiny)
+    pipe = agent.pipe
+    img = torch.from_numpy(weights.counter_bytes(9, "r2", 128 * 128 * 3).reshape(1, 128, 128, 3))
+    ids = pipe.encode_ids(["tiled perspectives of a robot arm executing 'open box'"])
+    lat = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(2)).half()
+    kw = dict(prompt_ids=ids, image=img, num_inference_steps=2, guidance_scale=0.0, latents=lat, output_type="np")
+    a = pipe(**kw).images
+    assert a.shape == (1, 128, 128, 3) and a.dtype == np.uint8
+    # oracle: same 2-step latents through the fp32 TAESD decoder
+    lat_out = pipe(**dict(kw, output_type="latent")).images.float().cpu()
+    with torch.no_grad():
+        ref = O.vae_postprocess_u8(O.taesd_decode(pipe.vae.state_dict(), configs.TAESD, lat_out / 1.0)).numpy()
+    assert np.abs(a.astype(np.int32) - ref.astype(np.int32)).max() <= 1
+    # replacing the ControlNet (new packed tensors) must not replay the recorded program of the old one
+    fam = configs.family("tiny")
+    pipe.controlnet = ControlNetModel(fam["controlnet"], weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), 77)).to("cuda")
+    b = pipe(**kw).images
+    assert not np.array_equal(a, b), "a stale recorded program was replayed after pipe.controlnet changed"
+    # ... nor after load_state_dict re-packs in place
+    pipe.controlnet.load_state_dict(weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), 78))
+    c = pipe(**kw).images
+    assert not np.array_equal(b, c)
+    # ... nor after the scheduler object is swapped (log_validation does exactly this, train_controlnet_genima.py:545-553)
+    from genima_amd.scheduler import EulerDiscreteScheduler
+    pipe.scheduler = EulerDiscreteScheduler.from_config(dict(configs.SD_TURBO_SCHEDULER, timestep_spacing="leading"))
+    d = pipe(**kw).images
+    assert not np.array_equal(c, d)
+    assert np.array_equal(d, pipe(**kw).images)  # and an unchanged pipeline still replays bit-identically
+
+
+def test_gradient_accumulation_and_lr_schedule():
+    """Two micro-batches of one sample under ``gradient_accumulation_steps=2`` = one step on the batch of two (same noise draws fed
+    explicitly): accelerate's 1/N loss scaling, diffusion/train_controlnet_genima.py:1319, :1402; the lr multiplier is applied and
+    advanced once per applied step (:1206-1213, :1407)."""
+    from genima_amd.engine import Engine
+    from genima_amd.host import UNet2DConditionModel, ControlNetModel
+    from genima_amd.train_loop import get_scheduler
+    from genima_amd.training import ControlNetTrainer
+
+    fam = configs.family("tiny")
+    E = Engine("cuda:0")
+    unet = UNet2DConditionModel.from_config(fam["unet"], 1).to("cuda")
+    cn_sd = weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), 2)
+    g = torch.Generator().manual_seed(0)
+    B, h = 2, 16
+    lat = (torch.randn(B, h, h, 8, generator=g) * 0.5).half().cuda()
+    noi = torch.randn(B, h, h, 8, generator=g).half().cuda()
+    lat[..., 4:] = 0
+    noi[..., 4:] = 0
+    t = torch.tensor([301.0, 744.0]).cuda()
+    sa, s1 = torch.tensor([0.8, 0.5]).cuda(), torch.tensor([0.6, 0.866]).cuda()
+    ctx = (torch.randn(B, 77, fam["unet"]["cross_attention_dim"], generator=g) * 0.3).half().cuda()
+    cond = torch.rand(B, 8 * h, 8 * h, 8, generator=g).half().cuda()
+    cond[..., 3:] = 0
+    lam = get_scheduler("constant_with_warmup", num_warmup_steps=4)
+    full = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet.W, cn_sd, lr=1e-3, lr_lambda=lambda s: lam(s + 1))
+    acc = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet.W, cn_sd, lr=1e-3, lr_lambda=lambda s: lam(s + 1),
+                            gradient_accumulation_steps=2)
+    full.step(lat, noi, t, sa, s1, ctx, cond)
+    for i in range(B):
+        sl = slice(i, i + 1)
+        acc.step(lat[sl], noi[sl], t[sl], sa[sl], s1[sl], ctx[sl], cond[sl])
+        assert acc.sync_gradients == (i == B - 1)
+    torch.cuda.synchronize()
+    assert full.opt_step == acc.opt_step == 1 and full.sched_step == acc.sched_step == 1
+    assert abs(full.current_lr() - 1e-3 * 2 / 4) < 1e-12  # after one applied step the warm-up multiplier is (1 + 1) / 4
+    gn_f, gn_a = full.last["grad_norm"], acc.last["grad_norm"]
+    assert abs(gn_f - gn_a) <= 2e-3 * gn_f, (gn_f, gn_a)
+    # Adam's first step is sign-like (|update| = lr wherever the gradient is not ~0), so the two runs agree except on the few elements
+    # whose tiny gradient changes sign with the summation order: compare in the mean, not in the max
+    init = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet.W, cn_sd).cn.master
+    upd = (full.cn.master - init).abs().mean().item()
+    d = (full.cn.master - acc.cn.master).abs().mean().item()
+    assert upd > 0 and d <= 0.02 * upd, (d, upd)
