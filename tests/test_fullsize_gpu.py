@@ -40,8 +40,9 @@ def test_full_width_denoise_step_vs_oracle():
     errs = [rel_l2(a.float().cpu(), b) for a, b in zip(down, d32)] + [rel_l2(mid.float().cpu(), m32)]
     e = rel_l2(eps, e32)
     print(f"full-width step: controlnet residuals rel-L2 max {max(errs):.2e}, unet eps rel-L2 {e:.2e} vs the fp32 oracle")
-    # f16 storage through ~100 layers (test_models_gpu.py: the f16-storage oracle itself sits at ~2e-3 from fp32)
-    assert max(errs) < 6e-3 and e < 6e-3
+    # f16 storage through ~100 layers; measured 1.4e-3 / 1.35e-3 (BASELINE north_star asks for 1e-3 "fp16 tolerance": the f16-storage
+    # ORACLE itself sits at this distance from fp32, test_models_gpu.py) -- the bar is what is measured plus margin, not 6e-3
+    assert max(errs) < 2e-3 and e < 2e-3
 
 
 def test_tiled_b8_pipeline_properties():
@@ -122,3 +123,86 @@ def test_full_width_train_step_is_deterministic_and_reaches_every_parameter():
     assert torch.isfinite(g0).all() and n0 is not None and np.isfinite(float(n0)) and float(n0) > 0
     dead = [name for name, (off, shape) in layout.items() if float(g0[off:off + int(np.prod(shape))].abs().max()) == 0.0]
     assert not dead, f"parameters without gradient: {dead[:5]}"
+
+
+def test_full_width_vae_decode_and_clip_h_vs_oracle():
+    """The two full-size networks the round-1 tests only covered at reduced width: the SD-2.1 VAE decoder (49.5 M parameters,
+    128 .. 512 channels) on one 256x256 view (latent 32x32) and the 23-layer OpenCLIP-H text tower (340.4 M), against the fp32 oracle."""
+    from genima_amd.host import AutoencoderKL, CLIPTextModel
+
+    torch.set_num_threads(max(1, min(32, torch.get_num_threads())))
+    vcfg = FAM["vae"]
+    vsd = weights.round_to(weights.synth_state_dict(schema.vae_schema(vcfg), 23, device="cuda"), torch.float16)
+    vae = AutoencoderKL(vcfg, vsd).to("cuda")
+    vsd = {k: v.cpu() for k, v in vsd.items()}
+    z = q16(torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(1)) * 3.0)
+    img = vae.decode(z.half()).sample.float().cpu()
+    with torch.no_grad():
+        ref = O.vae_decode(vsd, vcfg, z)
+    e_v = rel_l2(img, ref)
+    del vae
+    tcfg = FAM["text"]
+    tsd = weights.round_to(weights.synth_state_dict(schema.clip_text_schema(tcfg), 24, device="cuda"), torch.float16)
+    text = CLIPTextModel(tcfg, tsd).to("cuda")
+    tsd = {k: v.cpu() for k, v in tsd.items()}
+    V = tcfg["vocab_size"]
+    ids = torch.zeros(2, 77, dtype=torch.int64)
+    ids[0, :14] = torch.tensor([V - 2] + [320 + i for i in range(12)] + [V - 1])
+    ids[1, :6] = torch.tensor([V - 2, 4000, 17, 30000, 9, V - 1])
+    hs = text(ids)[0].float().cpu()
+    with torch.no_grad():
+        href = O.clip_text_forward(tsd, tcfg, ids)
+    e_t = rel_l2(hs, href)
+    print(f"full-width VAE decode 256x256 rel-L2 {e_v:.2e}; CLIP-H 23 layers last_hidden_state rel-L2 {e_t:.2e} (fp32 oracle)")
+    assert tuple(img.shape) == (1, 3, 256, 256) and e_v < 3e-3 and e_t < 3e-3
+
+
+def test_full_size_sdxl_train_step_with_and_without_fp8():
+    """BASELINE configs[4] at its real size: the SDXL-Turbo UNet (2.57 B parameters, frozen) and its ControlNet (1.25 B trainable), one
+    fine-tune step on one 512x512 tiled sample, in f16 and with the frozen UNet's 770 transformer Linears on the fp8 MFMA
+    (``enable_fp8_frozen``; reference step: diffusion/train_controlnet_sdxl_genima.py:1448-1471).  No CPU oracle finishes this size:
+    the checks are finiteness, every trainable tensor reached, bit-reproducibility of the fp8 step, and the fp8-vs-f16 distance."""
+    from genima_amd.engine import Engine
+    from genima_amd.packing import pack_state_dict
+    from genima_amd.training import ControlNetTrainer
+
+    X = configs.family("sdxl-turbo")
+    dev = torch.device("cuda")
+
+    def synth(sch, s):
+        return weights.synth_state_dict(sch, s, device=dev)
+
+    unet_W = pack_state_dict(synth(schema.unet_schema(X["unet"]), 1), dev)
+    csd = synth(schema.controlnet_schema(X["controlnet"]), 2)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    B, h = 1, 64
+    lat = torch.zeros(B, h, h, 8, dtype=torch.float16, device=dev)
+    lat[..., :4] = (torch.randn(B, h, h, 4, generator=g, device=dev) * 0.8).half()
+    noise = torch.zeros_like(lat)
+    noise[..., :4] = torch.randn(B, h, h, 4, generator=g, device=dev).half()
+    cond = torch.zeros(B, 8 * h, 8 * h, 8, dtype=torch.float16, device=dev)
+    cond[..., :3] = torch.rand(B, 8 * h, 8 * h, 3, generator=g, device=dev).half()
+    ctx = (torch.randn(B, 77, 2048, generator=g, device=dev) * 0.5).half()
+    added = ((torch.randn(B, 1280, generator=g, device=dev) * 0.5).half(), torch.tensor([[512.0, 512.0, 0.0, 0.0, 512.0, 512.0]] * B, device=dev))
+    t, sa, s1 = torch.tensor([501.0], device=dev), torch.tensor([0.7], device=dev), torch.tensor([0.714], device=dev)
+    out = {}
+    for tag in ("f16", "fp8", "fp8_again"):
+        tr = ControlNetTrainer(Engine(dev), X["unet"], X["controlnet"], unet_W, csd, lr=1e-5)
+        if tag != "f16":
+            assert tr.enable_fp8_frozen() == 770
+        loss = float(tr.forward_backward(lat, noise, t, sa, s1, ctx, cond, added=added).cpu())
+        grad = tr.cn.grad.clone()
+        layout = dict(tr.cn.layout)
+        tr.optimizer_step()
+        tr.update_scale()
+        out[tag] = (loss, grad, tr.last["grad_norm"])
+        del tr
+        torch.cuda.empty_cache()
+    (l16, g16, n16), (l8, g8, n8), (l8b, g8b, _) = out["f16"], out["fp8"], out["fp8_again"]
+    assert all(np.isfinite(v) and 0.05 < v < 20 for v in (l16, l8)) and torch.isfinite(g16).all() and torch.isfinite(g8).all()
+    assert l8 == l8b and torch.equal(g8, g8b), "the fp8 step must be bit-reproducible too"
+    dead = [n for n, (off, shape) in layout.items() if float(g8[off:off + int(np.prod(shape))].abs().max()) == 0.0]
+    assert not dead, dead[:5]
+    e = float((g8.double() - g16.double()).norm() / g16.double().norm())
+    print(f"full-size SDXL-Turbo step: loss f16 {l16:.5f} fp8 {l8:.5f}; |g| f16 {n16:.4f} fp8 {n8:.4f}; ControlNet gradient rel-L2 fp8 vs f16 {e:.3f}")
+    assert abs(l8 - l16) <= 3e-2 * l16 and 1e-4 < e < 0.35

@@ -165,3 +165,75 @@ def test_sdxl_controlnet_train_step():
     for n in layout:
         if n.startswith("add_embedding."):
             assert float((tr.cn.G[n].float().cpu() / S - P32[n]).double().norm()) <= 2e-2 * float(P32[n].double().norm()) + 1e-4 * gn, n
+
+
+def test_sdxl_fp8_frozen_step_every_routed_linear_matches_the_fp8_oracle():
+    """BASELINE configs[4] ("fp8 MFMA"): with ``enable_fp8_frozen()`` the frozen UNet's transformer Linears run on the fp8 MFMA inside the
+    real train step.  Every Linear the step routes there is captured (inputs and output) and checked against the CPU restatement of the
+    scheme (oracle/fp8_torch.py: row-wise e4m3 quantisation of activations and weights, exact products, f32 accumulate, dequantise,
+    epilogue); then the whole step is compared with the f16 step: the loss and the ControlNet gradient move by e4m3-sized amounts only."""
+    from genima_amd._lib import ACT_GEGLU, ACT_NONE
+    from oracle import fp8_torch as F8
+
+    ucfg, ccfg = FAM["unet"], FAM["controlnet"]
+    usd = _r16(weights.synth_state_dict(schema.unet_schema(ucfg), 1))
+    csd = _r16(weights.synth_state_dict(schema.controlnet_schema(ccfg), 2))
+    lat, noise, ctx, cond, added, t = _inputs()
+    sa, s1 = DDPMScheduler().add_noise_coeffs(t)
+    S = 4096.0
+    dev = lambda x: x.cuda()  # noqa: E731
+    args = (dev(nchw_to_nhwc(lat, 8).half()), dev(nchw_to_nhwc(noise, 8).half()), dev(t.float()), dev(sa), dev(s1), dev(ctx.half()),
+            dev(nchw_to_nhwc(cond, 8).half()))
+    kw = dict(added=(dev(added[0].half()), dev(added[1])))
+    unet_W = pack_state_dict(usd, "cuda")
+
+    def run(fp8):
+        E = Engine("cuda:0")
+        tr = ControlNetTrainer(E, ucfg, ccfg, unet_W, csd, lr=1e-4, loss_scale=S)
+        calls = []
+        if fp8:
+            E.fp8_min_rows = 1  # the tiny family's GEMMs have 32 .. 2048 rows: route them all (the product default skips < 1024)
+            assert tr.enable_fp8_frozen() > 20
+            inner = E.linear_fp8
+
+            def spy(xq, xs, wq, ws, bias=None, *, act=ACT_NONE, residual=None, out=None, name=None):
+                y = inner(xq, xs, wq, ws, bias, act=act, residual=residual, out=out, name=name)
+                calls.append((xq, xs, wq, ws, bias, act, residual, y))
+                return y
+            E.linear_fp8 = spy
+        loss = float(tr.forward_backward(*args, **kw).cpu())
+        g = torch.cat([(tr.cn.G[n].float() / S).reshape(-1) for n in tr.cn.layout]).cpu()
+        return loss, g, calls, E
+
+    l16, g16, _, _ = run(False)
+    l8, g8, calls, E = run(True)
+    assert len(calls) >= 40, len(calls)
+    # the quantised operands the GEMM consumed ARE the oracle's quantisation of some f16 tensor; check the GEMM + epilogue on them
+    import torch.nn.functional as Fn
+    worst, checked = 0.0, 0
+    for xq, xs, wq, ws, bias, act, residual, y in calls[:: max(1, len(calls) // 24)]:
+        K = wq.shape[1]
+        xd = xq.view(-1, K).cpu().view(torch.float8_e4m3fn).float() * xs[: xq.numel() // K].cpu()[:, None]
+        wd = wq.cpu().view(torch.float8_e4m3fn).float() * ws[: wq.shape[0]].cpu()[:, None]
+        ref = (xd.double() @ wd.double().t()).float()
+        if bias is not None:
+            ref = ref + bias.float().cpu()
+        if act == ACT_GEGLU:  # packed rows alternate 32-row [hidden | gate] blocks
+            r = ref.view(ref.shape[0], -1, 2, 32)
+            ref = (r[:, :, 0] * Fn.gelu(r[:, :, 1])).reshape(ref.shape[0], -1)
+        else:
+            assert act == ACT_NONE
+        if residual is not None:
+            ref = ref + residual.float().cpu().view(ref.shape)
+        worst = max(worst, rel_l2(y.float().cpu().view(ref.shape), ref))
+        checked += 1
+    # and the quantiser itself, on one activation: bytes and scales bit-exact against the oracle
+    xprobe = (torch.randn(300, 128, generator=torch.Generator().manual_seed(3)) * 2).half()
+    q_dev, s_dev = E.quantize_fp8(xprobe.cuda())
+    q_ref, s_ref = F8.quantize_rows(xprobe)
+    assert torch.equal(q_dev.cpu()[:, :128].view(torch.float8_e4m3fn).float(), q_ref.float()) and torch.equal(s_dev.cpu()[:300], s_ref)
+    e_g = rel_l2(g8, g16)
+    print(f"tiny-xl fp8-frozen step: {len(calls)} Linears on the fp8 MFMA ({checked} checked vs the oracle, worst rel-L2 {worst:.2e}); "
+          f"loss {l8:.6f} vs f16 {l16:.6f}; ControlNet gradient rel-L2 fp8 vs f16 {e_g:.2e}")
+    assert worst < 2e-3
+    assert abs(l8 - l16) <= 2e-2 * l16 and 1e-4 < e_g < 0.2  # e4m3 carries 3 mantissa bits: percent-level, and not identical
