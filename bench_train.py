@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-5)
     ap.add_argument("--augmentations", default="crop,colorjitter", help="the reference's --augmentations list (README.md:204); '' disables")
     ap.add_argument("--fp8", action="store_true", help="frozen UNet transformer Linears on the fp8 MFMA in the forward pass (configs[4])")
+    ap.add_argument("--exchange", default="buckets", choices=["buckets", "flat", "abi", "abi-bf16"],
+                    help="gradient exchange: bucketed RS+AG overlapped with the backward (default), one RS+AG after it, or the C-ABI "
+                         "RCCL communicator (gn_comm_*; -bf16: bf16 on the wire)")
     ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
     args = ap.parse_args()
 
@@ -68,8 +71,11 @@ def main():
     vae_W = pack_state_dict(synth(schema.vae_schema(fam["vae"]), 3), dev)
     text_W = pack_state_dict(synth(schema.clip_text_schema(fam["text"]), 4), dev)
     cn_sd = synth(schema.controlnet_schema(fam["controlnet"]), 2)
-    tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet_W, cn_sd, lr=args.lr,
-                           allreduce=dist.allreduce_mean_flat if world > 1 else None)
+    exchange = None
+    if world > 1:
+        exchange = {"buckets": lambda: dist.GradBuckets(n_buckets=8), "flat": lambda: dist.allreduce_sum_flat,
+                    "abi": lambda: dist.AbiComm(E, rank, world), "abi-bf16": lambda: dist.AbiComm(E, rank, world, bf16_wire=True)}[args.exchange]()
+    tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet_W, cn_sd, lr=args.lr, allreduce=exchange)
     del cn_sd
     text2_W = pack_state_dict(synth(schema.clip_text_schema(fam["text_2"]), 5), dev) if "text_2" in fam else None
     tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank,
@@ -123,7 +129,7 @@ def main():
                                     if args.family == "sdxl-turbo" else
                                     "BASELINE.json configs[3]: SD-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views)"),
                        "family": args.family,
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "optimizer": "AdamW fp32 master, f16 compute, loss scale",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "gradient_exchange": args.exchange if world > 1 else None, "optimizer": "AdamW fp32 master, f16 compute, loss scale",
                        "trainable_params_padded": int(tr.cn.numel), "fp8_frozen_linears": n_fp8},
             "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "grad_norm_last": tr.last.get("grad_norm"),
             "loss_scale": tr.loss_scale, "applied_steps": tr.opt_step,

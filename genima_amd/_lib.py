@@ -128,6 +128,12 @@ SIGNATURES = {
     "gn_latent_sample":(_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _F]),
     "gn_cast_f32_f16": (_I32, [_P, _P, _P, _I64]),
     "gn_fill_f32": (_I32, [_P, _P, _I64, _F]),
+    "gn_comm_unique_id": (_I32, [_P]),
+    "gn_comm_init": (_I32, [_P, _I32, _I32, _P, C.POINTER(_P)]),
+    "gn_comm_destroy": (_I32, [_P]),
+    "gn_comm_scratch_bytes": (_I64, [_P, _I64, _I32]),
+    "gn_comm_allreduce_grads": (_I32, [_P, _P, _I64, _I32, _P]),
+    "gn_comm_wait": (_I32, [_P]),
     "gn_program_create": (_I32, [_P, C.POINTER(_P)]),
     "gn_program_destroy": (_I32, [_P]),
     "gn_program_add_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgenima_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "attention_pipe.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "attention.hip", "attention_pipe.hip", "attention_bwd.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950's register file is unified, so keep MFMA accumulators in VGPRs -- the softmax / epilogue VALU
 # then works on them in place instead of through v_accvgpr_read/write copies (400 of them per attention tile otherwise).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(OUT, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print("[genima_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

@@ -137,6 +137,9 @@ class Graph:
     def __init__(self, E: Engine):
         self.E = E
         self.tape: List = []
+        self.first_use: Dict[str, int] = {}  # trainable parameter -> index of the FIRST tape entry that writes its gradient (the entry
+        #                                      that runs LAST in the reversed backward walk: after it the parameter's gradient is final)
+        self.on_entry_done = None            # callable(tape index) fired after each backward entry (dist.GradBuckets launches exchanges)
         self._xt = (None, None)  # one-entry cache: (activation, its transpose) shared by consecutive weight-gradient GEMMs
         self.flash_bwd = os.environ.get("GN_ATTN_BWD", "flash") != "gemm"  # "gemm": materialised batched-GEMM backward (cross-check)
 
@@ -147,9 +150,20 @@ class Graph:
         cur = v.cell[0]
         v.cell[0] = g if cur is None else self.E.add(cur, g.view(cur.shape))
 
+    def _note(self, net, *names):
+        if getattr(net, "G", None) is not None:
+            for n in names:
+                if n is not None:
+                    self.first_use.setdefault(n, len(self.tape))
+
     def backward(self):
-        for fn in reversed(self.tape):
-            fn()
+        hook = self.on_entry_done
+        if hook is not None:
+            hook(len(self.tape))  # parameters no entry touches are final before the walk starts
+        for i in range(len(self.tape) - 1, -1, -1):
+            self.tape[i]()
+            if hook is not None:
+                hook(i)
         self.tape.clear()
         self._xt = (None, None)
 
@@ -187,6 +201,7 @@ class Graph:
         assert x.t.shape[-1] == K and x.t.is_contiguous(), (wn, x.t.shape, w.shape)
         y = E.linear(x.t, w, W[bn] if bn else None, residual=residual.t if residual is not None else None)
         out = Var(y, x.needs or net.G is not None or (residual is not None and residual.needs))
+        self._note(net, wn, bn)
 
         def bw(dy):
             M = x.t.numel() // K
@@ -224,6 +239,7 @@ class Graph:
                      residual=residual.t if residual is not None else None, upsample2x=upsample2x)
         needs_in = x.needs or (x2 is not None and x2.needs)
         out = Var(y, needs_in or net.G is not None or (residual is not None and residual.needs))
+        self._note(net, wn, bn)
         C1 = x.t.shape[-1]
         C2 = x2.t.shape[-1] if x2 is not None else 0
 
@@ -265,6 +281,7 @@ class Graph:
         y, saved = T.groupnorm_fwd_train(E, x.t, W[wn], W[bn], groups, eps, act, x2=x2.t if x2 is not None else None)
         needs_in = x.needs or (x2 is not None and x2.needs)
         out = Var(y, needs_in or net.G is not None)
+        self._note(net, wn, bn)
 
         def bw(dy):
             tr = net.G is not None
@@ -278,6 +295,7 @@ class Graph:
     def layernorm(self, net: FrozenParams, x: Var, wn: str, bn: str, eps: float = 1e-5) -> Var:
         E, W = self.E, net.W
         out = Var(E.layernorm(x.t, W[wn], W[bn], eps), x.needs or net.G is not None)
+        self._note(net, wn, bn)
 
         def bw(dy):
             tr = net.G is not None
@@ -544,7 +562,11 @@ class ControlNetTrainer:
         self.grad_accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
         self.lr_lambda, self.sched_step = lr_lambda, 0
         self.sync_gradients = True  # accelerator.sync_gradients: did the last step() call apply an optimizer step?
-        self.allreduce = allreduce  # callable(flat f32 grad buffer) -> None: mean over ranks (dist.allreduce_mean_flat)
+        # data parallel: ``allreduce`` is either a callable(flat f32 grad buffer) that SUMS it over ranks in place and returns the
+        # number of ranks (dist.allreduce_sum_flat: one exchange after the backward), or a dist.GradBuckets that launches the exchange
+        # of each bucket of the flat buffer as soon as the backward walk has finished the last gradient in it (overlap with the rest)
+        self.allreduce = allreduce
+        self.world = 1
         self._ss = torch.zeros(1, dtype=F32, device=E.device)
         self._clip = torch.zeros(3, dtype=F32, device=E.device)
         self.last = {}
@@ -572,6 +594,10 @@ class ControlNetTrainer:
         pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid, added)
         loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale / self.grad_accum)
         pred.cell[0] = dpred
+        buckets = self.allreduce if hasattr(self.allreduce, "begin") else None
+        if buckets is not None and (self._micro + 1) % self.grad_accum == 0:  # exchange only the LAST micro-batch's (accumulated) gradient
+            buckets.begin(self.cn.grad, self.cn.layout, g.first_use, len(g.tape))
+            g.on_entry_done = buckets.entry_done
         g.backward()
         self.last["pred"] = pred.t
         return loss
@@ -579,9 +605,9 @@ class ControlNetTrainer:
     def optimizer_step(self):
         """all-reduce (data parallel) -> unscale + global-norm clip -> AdamW -> refresh f16 weights -> zero grads."""
         E, cn = self.E, self.cn
-        if self.allreduce is not None:
-            self.allreduce(cn.grad)
-        inv = 1.0 / self.loss_scale
+        if self.allreduce is not None:  # the SUM over ranks; the 1 / world of the mean is folded into the unscale factor below
+            self.world = int(self.allreduce.finish() if hasattr(self.allreduce, "finish") else self.allreduce(cn.grad))
+        inv = 1.0 / (self.loss_scale * self.world)
         T.sumsq(E, cn.grad, self._ss)
         T.clip_coef(E, self._ss, self._clip, self.max_grad_norm, inv)
         self.opt_step += 1

@@ -313,6 +313,20 @@ int32_t gn_event_record(gn_ctx* ctx, void* ev);
 int32_t gn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
 int32_t gn_stream_synchronize(gn_ctx* ctx);
 
+/* ---- data-parallel gradient exchange (SURVEY.md section 8b "comm"; replaces accelerate's DDP all-reduce under accelerator.backward,
+ * diffusion/train_controlnet_genima.py:1216-1218, :1402-1405).  One communicator per (process, GPU); the RCCL unique id (128 bytes) is
+ * created on rank 0 and carried to the other ranks by the caller.  gn_comm_allreduce_grads SUMS one flat f32 buffer over the ranks in
+ * place -- RCCL reduce-scatter + all-gather (+ a small all-reduce for a tail shorter than nranks) on the communicator's own HIP stream,
+ * ordered behind everything launched so far on ctx's stream -- and returns at once; gn_comm_wait makes ctx's stream wait for it.
+ * wire_bf16 = 1 sends bf16 on the links (the sum then rounds to bf16: opt-in).  scratch: device memory of gn_comm_scratch_bytes(). */
+typedef struct gn_comm gn_comm;
+int32_t gn_comm_unique_id(void* id128);
+int32_t gn_comm_init(gn_ctx* ctx, int32_t rank, int32_t nranks, const void* id128, gn_comm** out);
+int32_t gn_comm_destroy(gn_comm* comm);
+int64_t gn_comm_scratch_bytes(const gn_comm* comm, int64_t count, int32_t wire_bf16);
+int32_t gn_comm_allreduce_grads(gn_comm* comm, float* buf, int64_t count, int32_t wire_bf16, void* scratch);
+int32_t gn_comm_wait(gn_comm* comm);
+
 #ifdef __cplusplus
 }
 #endif

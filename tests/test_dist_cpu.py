@@ -28,6 +28,30 @@ def _worker(rank, world, port, q):
     tmax = gd.max_over_ranks(1.0 + rank)
     g = torch.arange(11, dtype=torch.float32) * (rank + 1)  # 11 % 2 != 0 exercises the tail path
     gd.allreduce_mean_flat(g)
+    # the trainer's form: SUM in place + the world size; reduce-scatter -> all-gather -> tail all-reduce is the same call sequence
+    # the RCCL backend runs (gloo's missing reduce-scatter is one `reduce` per destination rank)
+    h = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    assert gd.allreduce_sum_flat(h) == world and h.tolist() == (torch.arange(11, dtype=torch.float32) * 3).tolist()
+    # bucketed exchange driven by a (fake) backward walk: 10 "parameters" of 100 elements laid out in forward order, first used by
+    # tape entries 0..9; the walk runs 9 -> 0, so buckets become final from the END of the buffer towards its front
+    layout = {f"p{i}": (100 * i, (100,)) for i in range(10)}
+    first_use = {f"p{i}": i for i in range(9)}  # p9 is never touched: final before the walk starts
+    base = torch.arange(1000, dtype=torch.float32)
+    grad = base * (rank + 1)
+    bk = gd.GradBuckets(n_buckets=4, align=8)
+    bk.begin(grad, layout, first_use, 10)
+    order = []
+    bk.entry_done(10)
+    order.append(list(bk.fired))
+    for i in range(9, -1, -1):
+        bk.entry_done(i)
+        order.append(list(bk.fired))
+    assert bk.finish() == world
+    fired_at = {b: next(k for k, o in enumerate(order) if b in o) for b in range(len(bk.ranges))}
+    for b, (lo, hi) in enumerate(bk.ranges):
+        need = min(first_use.get(f"p{i}", 10) for i in range(10) if 100 * i < hi and 100 * i + 100 > lo)
+        assert fired_at[b] == 10 - need, (b, fired_at[b], need)  # order[k] is the state after entry 10 - k
+    assert torch.equal(grad, base * 3), "bucketed exchange must equal the one-shot sum"
     q.put((rank, (s, e), tmax, g.tolist()))
     gd.barrier()
     dist.destroy_process_group()
