@@ -124,39 +124,85 @@ def host_threads() -> int:
     return max(1, n)
 
 
-def cpu_baseline(max_seconds=30.0):
-    """fp32 torch-CPU oracle on a bounded sample of the same workload: one denoise step (ControlNet + UNet forward) at full
-    SD-Turbo width, B=1, latent 32x32 (one 256x256 view) -- 244.2 GFLOP algorithmic.  Scaled to the metric's unit by FLOPs:
-    a 5-step tiled call is 8000 GFLOP per 4 joint-target images."""
+def cpu_baseline(max_seconds=40.0):
+    """The fp32 torch-CPU oracle (oracle/sd_torch.py, the restatement of the reference's diffusers path -- diffusers itself is not
+    installable here) timed on the pieces of ONE tiled sample's 5-step call, each at the size the call runs it:
+      CLIP-H text tower (B = 1)  +  5 x [ControlNet + UNet at the 64x64 latent of a tiled 512x512 sample]  +  VAE decode.
+    The denoise step is timed once (the five steps are identical work); the VAE decode is timed on one 256x256 view (latent 32x32) and
+    counted four times for the 512x512 tile -- its convolutions are linear in pixels, only the single mid-block attention (1.4 % of
+    its FLOPs) is not.  One tiled sample = 4 joint-target images."""
     from genima_amd import configs, schema, weights
     from oracle import sd_torch as O
 
     cores = host_threads()
     torch.set_num_threads(cores)
     fam = configs.family("sd-turbo")
-    t0 = time.time()
     gdev = "cuda" if torch.cuda.is_available() else "cpu"  # draw on the GPU (same bits as the numpy path), copy to host
-    usd = {k: v.cpu() for k, v in weights.synth_state_dict(schema.unet_schema(fam["unet"]), 21, device=gdev).items()}
-    csd = {k: v.cpu() for k, v in weights.synth_state_dict(schema.controlnet_schema(fam["controlnet"]), 22, device=gdev).items()}
+
+    def synth(sch, seed):
+        return {k: v.cpu() for k, v in weights.synth_state_dict(sch, seed, device=gdev).items()}
+
+    t0 = time.time()
+    usd, csd = synth(schema.unet_schema(fam["unet"]), 21), synth(schema.controlnet_schema(fam["controlnet"]), 22)
+    vsd, tsd = synth(schema.vae_schema(fam["vae"], encoder=False), 23), synth(schema.clip_text_schema(fam["text"]), 24)
     gen_s = time.time() - t0
     g = torch.Generator().manual_seed(0)
-    x, ctx = torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, 77, 1024, generator=g)
-    cond, t = torch.rand(1, 3, 256, 256, generator=g), torch.tensor([999.0])
-    times = []
-    with torch.no_grad():
-        while sum(times) < max_seconds * 0.5 and len(times) < 3:
+    x, ctx = torch.randn(1, 4, 64, 64, generator=g), torch.randn(1, 77, 1024, generator=g)
+    cond, t = torch.rand(1, 3, 512, 512, generator=g), torch.tensor([999.0])
+    z = torch.randn(1, 4, 32, 32, generator=g)
+    V = fam["text"]["vocab_size"]
+    ids = torch.zeros(1, 77, dtype=torch.int64)
+    ids[0, :14] = torch.tensor([V - 2] + [320 + i for i in range(12)] + [V - 1])
+
+    def timed(fn, budget):
+        ts = []
+        while len(ts) < 2 and (not ts or sum(ts) + ts[-1] < budget):
             t0 = time.time()
-            down, mid = O.controlnet_forward(csd, fam["controlnet"], x, t, ctx, cond)
-            O.unet_forward(usd, fam["unet"], x, t, ctx, down, mid)
-            times.append(time.time() - t0)
-    best = min(times)
-    gflop = 181.1 + 63.1
-    gfs = gflop / best
-    img_s = gfs / (8000.0 / 4.0)
-    return {"value": img_s, "unit": "joint-target images/sec", "cores": cores, "kind": "port",
-            "sample": f"1 denoise step (ControlNet+UNet fwd, {gflop:.1f} GFLOP) B=1 latent 32x32, fp32 torch-CPU oracle at full "
-                      f"SD-Turbo width, best of {len(times)}: {best:.2f} s = {gfs:.0f} GFLOP/s on {cores} threads; scaled by "
-                      f"FLOPs to the 8000-GFLOP 5-step tiled call (weights drawn in {gen_s:.0f} s, untimed)"}
+            fn()
+            ts.append(time.time() - t0)
+        return min(ts)
+
+    def step():
+        down, mid = O.controlnet_forward(csd, fam["controlnet"], x, t, ctx, cond)
+        O.unet_forward(usd, fam["unet"], x, t, ctx, down, mid)
+
+    with torch.no_grad():
+        t_clip = timed(lambda: O.clip_text_forward(tsd, fam["text"], ids), 0.1 * max_seconds)
+        t_step = timed(step, 0.6 * max_seconds)
+        t_vae = timed(lambda: O.vae_decode(vsd, fam["vae"], z), 0.3 * max_seconds)
+    per_sample = t_clip + 5.0 * t_step + 4.0 * t_vae
+    return {"value": 4.0 / per_sample, "unit": "joint-target images/sec", "cores": cores, "kind": "port",
+            "seconds_per_tiled_sample": per_sample,
+            "sample": f"fp32 torch-CPU oracle at full SD-Turbo width on {cores} threads, pieces of one tiled 512x512 sample's 5-step call: "
+                      f"CLIP-H text {t_clip:.2f} s + 5 x (ControlNet + UNet @ 64x64 latent, 1088 GFLOP) {t_step:.2f} s + 4 x (VAE decode of "
+                      f"one 256x256 view, 622 GFLOP) {t_vae:.2f} s = {per_sample:.1f} s per tiled sample (= 4 joint-target images); "
+                      f"each piece best of <= 2 runs; weights drawn in {gen_s:.0f} s, untimed"}
+
+
+def single_view_latency(pipe, dev, denoise_steps, rank, calls=10):
+    """BASELINE.json configs[1] as the evaluation loop sees it (B = frame_stack = 1, one 256x256 view): latency of one 5-step call with
+    the whole recorded program replayed as ONE hipGraph (the HIP form of the reference's ``torch_compile`` reduce-overhead flag)."""
+    B, H, W, desc = WORKLOADS["single_b1"]
+    ids, img, lat = synthetic_inputs(pipe, B, H, W, dev, rank)
+    res = {}
+    for graph in (False, True):
+        pipe.enable_hip_graph(graph)
+        for _ in range(3):
+            pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=denoise_steps, guidance_scale=0.0, output_type="pt")
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(calls):
+            t0 = time.perf_counter()
+            pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=denoise_steps, guidance_scale=0.0, output_type="pt")
+            torch.cuda.synchronize(dev)
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        res["hip_graph" if graph else "stream_replay"] = 1000.0 * ts[len(ts) // 2]
+    pipe.enable_hip_graph(False)
+    best = min(res.values())
+    return {"workload": desc, "ms_per_call_median": res, "images_per_sec": 1000.0 / best,
+            "weight_streaming_ideal_ms": 13.1e9 / 8e12 * 1e3,  # SURVEY.md section 8d config 2: 13.1 GB of weights per call at 8 TB/s
+            "frac_of_hbm_roofline": (13.1e9 / 8e12 * 1e3) / best}
 
 
 def main():
@@ -170,6 +216,9 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay each call as one captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the `train` extra (BASELINE.json's second metric: ControlNet train steps/s)")
+    ap.add_argument("--no-single-view", action="store_true", help="skip the `single_view_b1` extra (configs[1] latency, hipGraph)")
+    ap.add_argument("--train-steps", type=int, default=5)
     ap.add_argument("--no-act", action="store_true", help="skip the ACT controller forward after each pipeline call")
     ap.add_argument("--dump-ops", default=None, help="write the per-(kernel, shape) HIP-event timing table of one call to this CSV")
     args = ap.parse_args()
@@ -181,7 +230,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        import datetime
+
+        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
     assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -315,8 +366,35 @@ def main():
                 row.update(bound="hbm", achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=gbs / HBM_PEAK_GBS)
             extra.append(row)
         out["roofline_extra"] = extra
+    if rank == 0 and world == 1 and not args.no_single_view:
+        try:
+            out["single_view_b1"] = single_view_latency(pipe, dev, args.denoise_steps, rank)
+        except Exception as e:  # an extra must never cost the headline line
+            out["single_view_b1"] = {"error": repr(e)[:300]}
+
+    # BASELINE.json's second metric on the same launch: the ControlNet fine-tune step (configs[3], per-GPU batch 8), N ranks data
+    # parallel with the bucketed RCCL reduce-scatter + all-gather of the flat gradient overlapped with the backward
+    if not args.no_train:
+        del pipe, act_agent
+        torch.cuda.empty_cache()
+        try:
+            import bench_train
+
+            targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "2"])
+            line = bench_train.run(targs)
+            if rank == 0 and line is not None:
+                out["train"] = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "samples_per_sec",
+                                                     "dtype", "config", "roofline", "peak_mem_gb", "loss_first", "loss_last", "scaling")}
+        except Exception as e:
+            if rank == 0:
+                out["train"] = {"error": repr(e)[:300]}
+        torch.cuda.empty_cache()
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:
+            out["cpu_baseline"] = {"error": repr(e)[:300]}
 
     if rank == 0:
         print(json.dumps(out))

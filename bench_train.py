@@ -34,7 +34,7 @@ TFLOP_PER_SAMPLE = {("sd-turbo", 512): 2.25 + 1.37,
                     ("sdxl-turbo", 512): 3.42 + 3.01}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -49,8 +49,11 @@ def main():
                     help="gradient exchange: bucketed RS+AG overlapped with the backward (default), one RS+AG after it, or the C-ABI "
                          "RCCL communicator (gn_comm_*; -bf16: bf16 on the wire)")
     ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
+
+def run(args, quiet: bool = False):
+    """One measurement; returns the JSON-line dict on rank 0 (None elsewhere).  bench.py calls this for its ``train`` extra key."""
     from genima_amd import configs, dist, schema, weights
     from genima_amd.engine import Engine, save_tune_table
     from genima_amd.packing import pack_state_dict
@@ -139,6 +142,13 @@ def main():
                          if achieved else None),
             "peak_mem_gb": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
         }
+        return line
+    return None
+
+
+def main():
+    line = run(parse_args())
+    if line is not None:
         print(json.dumps(line))
 
 

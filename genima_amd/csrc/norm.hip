@@ -395,8 +395,11 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
         GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_max));
     }
     const long slab = (long)d->HW * p.cpg * 2;
+    // few (batch, group) slabs leave most CUs idle -- unless the whole tensor is so small that the call is latency-bound anyway
+    // (batch 1: 32 slabs; one launch of ~6 us instead of three)
+    const bool small = (long)d->B * d->HW * C * 2 <= (4l << 20);
     if (fused_ok && !saving && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= fused_max &&
-        (long)d->B * d->groups >= 64) {
+        ((long)d->B * d->groups >= 64 || small)) {
       hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups, d->B), dim3(GNF_THREADS), (size_t)slab, ctx->stream, p);
       GN_LAUNCH_CHECK();
       return GN_OK;

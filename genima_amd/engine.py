@@ -170,6 +170,7 @@ class Engine:
     # recording engine times every configuration once per distinct problem and remembers the winner.  Tile choice does not
     # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
     # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
+    _retuned = set()  # shapes already re-raced in this process (GN_RETUNE)
     N_TILE_CFGS = 15  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256 (csrc/gemm.hip kCfg, csrc/gemm_pp.hip)
 
     @staticmethod
@@ -187,10 +188,14 @@ class Engine:
     def _autotune(self, d: GemmDesc, key: Optional[str] = None):
         key = key or self._tune_key(d)
         table = _tune_table()
-        if key in table:
+        challengers = [int(c) for c in os.environ.get("GN_RETUNE", "").split(",") if c.strip()]  # e.g. GN_RETUNE=15: race new tiles
+        if key in table and not (challengers and key not in self._retuned):                       # against each shape's incumbent
             return table[key]
         best, best_ms = 0, float("inf")
         cands = (1, 2, 5, 6, 7, 8, 9, 12) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
+        if key in table:
+            self._retuned.add(key)
+            cands = [table[key]] + [c for c in challengers if c != table[key] and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12))]
         if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         e0, e1 = self.event(), self.event()
@@ -200,7 +205,7 @@ class Engine:
             d.workspace = self._workspace(nb).data_ptr() if nb > 0 else None
             check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm(autotune)")
             ms = float("inf")
-            for _rep in range(2):  # min of two timed batches: one stray hiccup must not decide the table
+            for _rep in range(3 if challengers else 2):  # min of the timed batches: one stray hiccup must not decide the table
                 self.event_record(e0)
                 for _ in range(3):
                     check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm(autotune)")
