@@ -98,6 +98,8 @@ SIGNATURES = {
     "gn_program_add_argmax_rows_i32": (_I32, [_P, _P, _P, _I32, _I32]),
     "gn_add": (_I32, [_P, _P, _P, _P, _I64]),
     "gn_act": (_I32, [_P, _P, _P, _I64, _I32]),
+    "gn_film": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32]),
+    "gn_program_add_film": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32]),
     "gn_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_softmax_rows": (_I32, [_P, _P, _I64, _I32, _I32, _F]),
     "gn_softmax_rows_masked": (_I32, [_P, _P, _I64, _I32, _I32, _F, _I32]),

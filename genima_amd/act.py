@@ -6,8 +6,13 @@
 ResNet-18 (FrozenBatchNorm folded into the conv weights at pack time, ReLU and the identity add fused into the conv epilogue)
 per view -> 1x1 input_proj -> views along width -> sine positions -> DETR encoder(4)/decoder(6) on the same MFMA GEMM /
 flash-attention (head dim 32) / LayerNorm kernels as the diffusion path -> heads -- runs entirely in HIP; RoboBase itself is an
-unpinned absent dependency, so the module wiring follows the public ACT/DETR semantics restated in oracle/act_torch.py
-([VERIFY] items of SURVEY.md Appendix E stay open until a real ``latest.pt`` is available).
+unpinned absent dependency, so the module wiring follows the public ACT/DETR semantics restated in oracle/act_torch.py (pinned against
+transformers' ResNet / DETR layers: tests/golden/make_act_golden.py).  Language conditioning (``use_lang_cond: true``,
+controller/cfgs/method/genima_act.yaml:39; ``encoder_model(image, task_emb)``, genima_act.py:190) follows the MT-ACT / RoboAgent lineage
+RoboBase's ``ImageEncoderACT`` comes from: FiLM (gamma, beta from the 512-d CLIP embedding) after bn1 of every BasicBlock of layer2..4,
+plus the projected embedding as a third extra encoder token; ``frame_stack > 1`` stacks the frames of a view on channels in front of
+``projection_layer`` (genima_act.py:191-197).  Key names of the FiLM generators / token projection are [VERIFY] items of SURVEY.md
+Appendix E until a real ``latest.pt`` is available: ``robobase_key_map`` lists the aliases accepted.
 """
 from __future__ import annotations
 
@@ -51,6 +56,13 @@ def act_schema(cfg) -> "OrderedDict[str, tuple]":
                 bn(p + ".downsample.1", c)
         cin = c
     s["input_proj.weight"], s["input_proj.bias"] = (d, 512, 1, 1), (d,)
+    if cfg.get("use_lang_cond"):
+        # FiLM generators of the language-conditioned ResNet (MT-ACT / RoboAgent ``resnet_film``: ``film_config.use_in_layers = [1, 2, 3]``,
+        # i.e. layer2..layer4): one Linear per conditioned layer, lang_dim -> 2 (gamma, beta) x 2 blocks x planes
+        for j, (li, c, _) in enumerate(_RESNET18[1:]):
+            s[f"backbone.film_fcs.{j}.weight"], s[f"backbone.film_fcs.{j}.bias"] = (2 * 2 * c, cfg["lang_dim"]), (2 * 2 * c,)
+    if cfg.get("frame_stack", 1) > 1:  # ACTPolicy.projection_layer (controller/method/genima_act.py:193-197): fs * hidden -> hidden, 1x1
+        s["projection_layer.weight"], s["projection_layer.bias"] = (d, d * cfg["frame_stack"], 1, 1), (d,)
 
     def mha(p):
         s[p + ".in_proj_weight"], s[p + ".in_proj_bias"] = (3 * d, d), (3 * d,)
@@ -143,6 +155,10 @@ def emit_act_forward(E: Engine, W, Wclip, cfg, ccfg, img_u8_nhwc: torch.Tensor, 
             eot = E.argmax_rows(tokens, name="eot")
             pooled = E.gather_rows(xt, eot, name="pooled")
             task = E.linear(pooled, Wclip["text_projection.weight"], name="task_emb")
+        film = None
+        if task is not None and "backbone.film_fcs.0.weight" in W:
+            film = {li: E.linear(task, W[f"backbone.film_fcs.{j}.weight"], W[f"backbone.film_fcs.{j}.bias"], name=f"film{li}")
+                    for j, (li, _, _) in enumerate(_RESNET18[1:])}
         # ---- ResNet-18 per view (FrozenBN folded; ReLU / identity add in the conv epilogues) ---------------------------------
         x = E.image_normalize_u8(img_u8_nhwc.view(B * V, H, Wd, 3), IMAGENET_MEAN, IMAGENET_STD, 8, name="img")
         p = "backbone"
@@ -152,7 +168,15 @@ def emit_act_forward(E: Engine, W, Wclip, cfg, ccfg, img_u8_nhwc: torch.Tensor, 
             for bi in range(2):
                 q = f"{p}.layer{li}.{bi}"
                 st = stride if bi == 0 else 1
-                y = E.conv2d(h, W[q + ".conv1.weight"], W[q + ".conv1.bias"], stride=st, act=ACT_RELU, name=q + ".c1")
+                if film is not None and li >= 2:
+                    # relu((1 + gamma) * bn1(conv1(x)) + beta): the block's FiLM slice of this layer's generator output
+                    # (layout [B, 2, blocks = 2, planes], MT-ACT resnet_film.py) -- the same (gamma, beta) for every view / frame of a sample
+                    y = E.conv2d(h, W[q + ".conv1.weight"], W[q + ".conv1.bias"], stride=st, name=q + ".c1")
+                    ff = film[li]
+                    y = E.film(y, ff[:, bi * c:(bi + 1) * c], ff[:, (2 + bi) * c:(3 + bi) * c], V * y.shape[1] * y.shape[2], ACT_RELU,
+                               out=y)
+                else:
+                    y = E.conv2d(h, W[q + ".conv1.weight"], W[q + ".conv1.bias"], stride=st, act=ACT_RELU, name=q + ".c1")
                 idt = h
                 if (q + ".downsample.0.weight") in W:
                     idt = E.conv2d(h, W[q + ".downsample.0.weight"], W[q + ".downsample.0.bias"], ksize=1, stride=st,
@@ -161,6 +185,14 @@ def emit_act_forward(E: Engine, W, Wclip, cfg, ccfg, img_u8_nhwc: torch.Tensor, 
                              name=q + ".c2")
         f = E.conv2d(h, W["input_proj.weight"], W["input_proj.bias"], ksize=1, pad=(0, 0, 0, 0), name="input_proj")  # [B*V, fh, fw, d]
         fh, fw = f.shape[1], f.shape[2]
+        fs = cfg.get("frame_stack", 1)
+        if fs > 1:
+            # image index = camera * fs + frame (controller/eval_genima.py:167-173): the frames of a view go side by side on the CHANNEL
+            # axis and ``projection_layer`` (1x1 conv) brings fs * hidden back to hidden (genima_act.py:191-197)
+            V //= fs
+            stk = E.buf("fs_stack", (B * V, fh, fw, fs * d))
+            E.copy4d(f, stk, (B * V, fs, fh * fw, 1), (fs * fh * fw * d, fh * fw * d, d, 0), (fh * fw * fs * d, d, fs * d, 0), d)
+            f = E.conv2d(stk, W["projection_layer.weight"], W["projection_layer.bias"], ksize=1, pad=(0, 0, 0, 0), name="projection_layer")
         # ---- encoder sequence [latent, proprio, (task), image tokens]; views concatenated along WIDTH ----------------------
         n_extra = 3 if task is not None else 2
         n_img = fh * V * fw
@@ -227,6 +259,32 @@ def emit_act_forward(E: Engine, W, Wclip, cfg, ccfg, img_u8_nhwc: torch.Tensor, 
         return a_hat, is_pad, task
 
 
+_ROBOBASE_PREFIXES = (
+    # RoboBase ``ActBCAgent`` registers the same modules more than once: ``actor`` (GenimaACTPolicy: .actor_model, .encoder_model),
+    # ``actor_model`` and ``encoder`` at the top level -- ``ckpt["agent"]`` carries each weight under every path (eval_genima.py:91-103)
+    ("actor.encoder_model.backbone.0.body.", "backbone."), ("encoder.backbone.0.body.", "backbone."),   # DETR Joiner: backbone[0].body = ResNet
+    ("actor.encoder_model.backbone.0.", "backbone."), ("encoder.backbone.0.", "backbone."),
+    ("actor.encoder_model.", ""), ("encoder.", ""), ("actor.actor_model.", ""), ("actor_model.", ""), ("actor.", ""),
+)
+_ROBOBASE_ALIASES = {  # [VERIFY] names: the MT-ACT lineage calls the token projection ``proj_text_emb``
+    "proj_text_emb.weight": "task_proj.weight", "proj_text_emb.bias": "task_proj.bias",
+    "task_emb_proj.weight": "task_proj.weight", "task_emb_proj.bias": "task_proj.bias",
+}
+
+
+def robobase_key_map(key: str) -> Optional[str]:
+    """RoboBase ``latest.pt`` ``ckpt["agent"]`` key -> this module's key (None: not a weight of the inference forward, e.g. the CVAE
+    posterior encoder ``actor.actor_model.encoder.*`` / ``cls_embed`` / ``latent_proj``, optimizer-free buffers, duplicates)."""
+    for src, dst in _ROBOBASE_PREFIXES:
+        if key.startswith(src):
+            k = dst + key[len(src):]
+            k = _ROBOBASE_ALIASES.get(k, k)
+            if k.startswith("encoder.layers.") or k.startswith("backbone.fc.") or k.endswith("num_batches_tracked"):
+                return None  # "encoder.layers" under actor_model = the CVAE style encoder (training only)
+            return k
+    return _ROBOBASE_ALIASES.get(key, key)
+
+
 class GenimaACT:
     """Controller plugin (``method._target_: method.genima_act.GenimaACT``, controller/cfgs/method/genima_act.yaml:3-4)."""
 
@@ -263,8 +321,17 @@ class GenimaACT:
         return OrderedDict(("actor." + k, v) for k, v in self._sd.items())
 
     def load_state_dict(self, sd, strict: bool = False):
-        new = {k[len("actor."):] if k.startswith("actor.") else k: v for k, v in sd.items()}
+        """``agent.load_state_dict(ckpt["agent"], strict=False)`` (controller/eval_genima.py:91-103): RoboBase key families are mapped
+        by ``robobase_key_map``; with ``strict=False`` unknown keys are reported, not fatal -- but a checkpoint that fills NONE of the
+        forward's weights is an error (a silently random-initialised controller would act plausibly and wrongly)."""
+        new = {}
+        for k, v in sd.items():
+            m = robobase_key_map(k)
+            if m is not None and (m not in new or k.startswith("actor.")):  # duplicates carry the same tensor; prefer the actor.* path
+                new[m] = v
         missing = [k for k in self._schema if k not in new]
+        if len(missing) == len(self._schema):
+            raise KeyError(f"no key of the state dict maps onto the ACT forward (first keys: {list(sd)[:4]})")
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:4]}")
         for k in self._schema:

@@ -19,7 +19,7 @@ namespace {
 
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
-  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE,
+  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE, OP_FILM,
   OP_FORK, OP_MAIN, OP_JOIN  // stream control: ops after FORK go to the program's side stream until MAIN; JOIN makes main wait for it
 };
 
@@ -67,6 +67,7 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_U8_TO_F16: return gn_image_u8_to_f16(ctx, (const uint8_t*)g.p0, g.p3, g.n0, g.i0, g.f0, g.f1);
     case OP_ADD: return gn_add(ctx, g.p0, g.p1, g.p3, g.n0);
     case OP_ACT: return gn_act(ctx, g.p0, g.p3, g.n0, g.i0);
+    case OP_FILM: return gn_film(ctx, g.p0, g.p3, g.p1, g.p2, g.m[0], g.m[1], g.n0, g.i0, g.i1);
     case OP_EMBED: return gn_embedding(ctx, (const int32_t*)g.p0, g.p1, g.p2, g.p3, g.i0, g.i1, g.i2);
     case OP_SOFTMAX: return gn_softmax_rows(ctx, g.p3, g.n0, g.i0, g.i1, g.f0);
     case OP_MAXPOOL: return gn_maxpool3x3s2(ctx, g.p0, g.p3, g.i0, g.i1, g.i2, g.i3);
@@ -199,6 +200,12 @@ int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* o
 }
 int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n) {
   return push_generic(p, OP_ADD, a, b, nullptr, out, n, 0, 0, 0, 0, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_film(gn_program* p, const void* x, void* out, const void* gamma, const void* beta, int64_t ld_film,
+                            int64_t rows_per_film, int64_t rows, int32_t C, int32_t act) {
+  const int32_t rc = push_generic(p, OP_FILM, x, gamma, beta, out, rows, 0, C, act, 0, 0, 0.f, 0.f);
+  if (rc == GN_OK) { p->ops.back().g.m[0] = ld_film; p->ops.back().g.m[1] = rows_per_film; }
+  return rc;
 }
 int32_t gn_program_add_act(gn_program* p, const void* x, void* out, int64_t n, int32_t act) {
   return push_generic(p, OP_ACT, x, nullptr, nullptr, out, n, 0, act, 0, 0, 0, 0.f, 0.f);

@@ -145,6 +145,24 @@ __global__ void act_kernel(const uint4* __restrict__ a, uint4* __restrict__ out,
   out[i] = *reinterpret_cast<uint4*>(&o);
 }
 
+// FiLM: out[r, c] = act((1 + gamma[b, c]) * x[r, c] + beta[b, c]),  b = r / rows_per_film  (language conditioning inside the ACT image
+// encoder's ResNet blocks: after bn1, before the ReLU).  gamma / beta are rows of one [B, ld_film] feature buffer.
+__global__ void film_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, const f16* __restrict__ gamma, const f16* __restrict__ beta,
+                            long ld_film, long rows_per_film, long rows, int C8, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C8) return;
+  const long r = i / C8;
+  const int c = (int)(i - r * C8) * 8;
+  const long b = r / rows_per_film;
+  const uint4 rx = x[i];
+  const uint4 rg = *reinterpret_cast<const uint4*>(gamma + b * ld_film + c), rb = *reinterpret_cast<const uint4*>(beta + b * ld_film + c);
+  const f16x8 vx = *reinterpret_cast<const f16x8*>(&rx), vg = *reinterpret_cast<const f16x8*>(&rg), vb = *reinterpret_cast<const f16x8*>(&rb);
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)apply_act((1.0f + (float)vg[e]) * (float)vx[e] + (float)vb[e], act);
+  out[i] = *reinterpret_cast<uint4*>(&o);
+}
+
 __global__ void embedding_kernel(const int32_t* __restrict__ ids, const f16* __restrict__ tok, const f16* __restrict__ pos,
                                  f16* __restrict__ out, int B, int L, int D) {
   const int DC = D >> 3;
@@ -326,6 +344,18 @@ int32_t gn_image_f16_to_u8(gn_ctx* ctx, const void* in, uint8_t* out, int64_t pi
 int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n) {
   GN_REQUIRE(ctx && a && b && out && n > 0 && n % 8 == 0, "gn_add: n must be a positive multiple of 8");
   hipLaunchKernelGGL(add_kernel, dim3(nblk(n / 8)), dim3(256), 0, ctx->stream, (const uint4*)a, (const uint4*)b, (uint4*)out, (long)(n / 8));
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_film(gn_ctx* ctx, const void* x, void* out, const void* gamma, const void* beta, int64_t ld_film, int64_t rows_per_film,
+                int64_t rows, int32_t C, int32_t act) {
+  GN_REQUIRE(ctx && x && out && gamma && beta && rows > 0 && rows_per_film > 0 && C > 0 && C % 8 == 0 && ld_film % 8 == 0,
+             "gn_film: C (%d) and ld_film must be multiples of 8", C);
+  GN_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "gn_film: 16-byte alignment");
+  const long n8 = rows * (C / 8);
+  hipLaunchKernelGGL(film_kernel, dim3(nblk(n8)), dim3(256), 0, ctx->stream, (const uint4*)x, (uint4*)out, (const f16*)gamma, (const f16*)beta,
+                     (long)ld_film, (long)rows_per_film, (long)rows, C / 8, act);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -553,6 +553,17 @@ class Engine:
         self._small("act", (x, out), _ptr(x), _ptr(out), x.numel(), act)
         return out
 
+    def film(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, rows_per_film: int, act: int = ACT_NONE, *, out=None, name=None):
+        """out = act((1 + gamma[b]) * x + beta[b]) with b = row // rows_per_film; x [..., C] f16, gamma / beta [B, C] views (row stride =
+        the FiLM feature buffer's width) of one tensor."""
+        Cc = x.shape[-1]
+        rows = x.numel() // Cc
+        assert gamma.stride(0) == beta.stride(0) and gamma.stride(-1) == 1 and rows % rows_per_film == 0
+        if out is None:
+            out = self.buf(name, x.shape)
+        self._small("film", (x, gamma, beta, out), _ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), gamma.stride(0), rows_per_film, rows, Cc, act)
+        return out
+
     def embedding(self, ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor, *, name=None):
         """ids int32 [B, L] -> tok[ids] + pos[:L]  f16 [B, L, D]."""
         B, L = ids.shape

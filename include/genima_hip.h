@@ -194,6 +194,11 @@ int32_t gn_copy4d(gn_ctx* ctx, const void* in, void* out, const int64_t* sizes, 
 /* ---- misc elementwise / gather ------------------------------------------------------------------------------------ */
 int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n);              /* f16, n % 8 == 0 */
 int32_t gn_act(gn_ctx* ctx, const void* x, void* out, int64_t n, int32_t act);                /* f16, n % 8 == 0 */
+/* FiLM (controller/method/genima_act.py:190: ``encoder_model(image, task_emb)`` with use_lang_cond, genima_act.yaml:39):
+ * out[r, :] = act((1 + gamma[r / rows_per_film, :]) * x[r, :] + beta[r / rows_per_film, :]); x / out f16 [rows, C], gamma / beta f16 rows of
+ * stride ld_film (slices of the per-layer FiLM feature buffer); out may alias x */
+int32_t gn_film(gn_ctx* ctx, const void* x, void* out, const void* gamma, const void* beta, int64_t ld_film, int64_t rows_per_film,
+                int64_t rows, int32_t C, int32_t act);
 int32_t gn_embedding(gn_ctx* ctx, const int32_t* ids, const void* tok, const void* pos, void* out, int32_t B,
                      int32_t L, int32_t D);                                                   /* CLIP token + position */
 int32_t gn_softmax_rows(gn_ctx* ctx, void* x, int64_t rows, int32_t cols, int32_t ld, float scale); /* in place, f16 */
@@ -290,6 +295,8 @@ int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* ou
 int32_t gn_program_add_add_noise(gn_program* p, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac,
                                  void* out, int32_t B, int64_t per_sample);
 int32_t gn_program_add_act(gn_program* p, const void* x, void* out, int64_t n, int32_t act);
+int32_t gn_program_add_film(gn_program* p, const void* x, void* out, const void* gamma, const void* beta, int64_t ld_film,
+                            int64_t rows_per_film, int64_t rows, int32_t C, int32_t act);
 int32_t gn_program_add_embedding(gn_program* p, const int32_t* ids, const void* tok, const void* pos, void* out,
                                  int32_t B, int32_t L, int32_t D);
 int32_t gn_program_add_softmax_rows(gn_program* p, void* x, int64_t rows, int32_t cols, int32_t ld, float scale);

@@ -6,8 +6,12 @@ dependency, README.md:40-46; call sites controller/method/genima_act.py:2-18, :2
 (SURVEY.md Appendix E): ResNet-18 with FrozenBatchNorm per view -> 1x1 input_proj -> views concatenated along width -> sine
 positional embedding -> post-norm DETR encoder(4)/decoder(6) over [latent, proprio, task] + image tokens with 20 learned queries
 -> action / is_pad heads; plus the reference-owned pieces: ImageNet normalisation (genima_act.py:146-148, :188), the 2-layer
-state MLP (:237-241), z = 0 prior at inference (:70-75).  Language conditioning is restated as a projected task token
-([VERIFY] against a real latest.pt: FiLM inside the ResNet is not restated).
+state MLP (:237-241), z = 0 prior at inference (:70-75).
+
+Pinned: ResNet-18 + FrozenBN, the sine positions, the DETR encoder / decoder stack and the heads equal transformers' ``ResNetModel`` /
+``DetrSinePositionEmbedding`` / ``DetrEncoderLayer`` / ``DetrDecoderLayer`` to 1e-6 (tests/golden/act_golden.npz, tests/test_golden_cpu.py).
+UNPINNED ([VERIFY] against a real latest.pt): language conditioning -- FiLM after bn1 in the BasicBlocks of layer2..4 and a projected task
+token, restated from the MT-ACT / RoboAgent lineage -- and the frame-stack ``projection_layer``.
 """
 from __future__ import annotations
 
@@ -27,22 +31,34 @@ def frozen_bn(sd, p, x, eps=1e-5):
     return x * scale[None, :, None, None] + shift[None, :, None, None]
 
 
-def basic_block(sd, p, x, stride, q=_id):
+def basic_block(sd, p, x, stride, q=_id, film=None):
+    """torchvision BasicBlock with FrozenBatchNorm; ``film`` = (gamma, beta) [N, planes]: the MT-ACT ``resnet_film`` block applies
+    out = (1 + gamma) * out + beta after bn1, before the ReLU."""
     idt = x
-    h = q(F.relu(frozen_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1))))
+    h = frozen_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1))
+    if film is not None:
+        h = (1.0 + film[0][:, :, None, None]) * q(h) + film[1][:, :, None, None]
+    h = q(F.relu(h))
     h = frozen_bn(sd, p + ".bn2", F.conv2d(h, sd[p + ".conv2.weight"], None, 1, 1))
     if (p + ".downsample.0.weight") in sd:
         idt = q(frozen_bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0)))
     return q(F.relu(h + idt))
 
 
-def resnet18_features(sd, x, q=_id):
+def resnet18_features(sd, x, q=_id, task_emb=None, per_sample: int = 1):
+    """``task_emb`` [B, lang_dim] with x = [B * per_sample, 3, H, W]: FiLM features per conditioned layer (layer2..4) come from
+    ``backbone.film_fcs.j`` and are laid out [B, 2 (gamma, beta), blocks, planes] (MT-ACT ``_extract_film_features_for_layer``)."""
     p = "backbone"
     h = q(F.relu(frozen_bn(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"], None, 2, 3))))
     h = F.max_pool2d(h, 3, 2, 1)
-    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
-        h = basic_block(sd, f"{p}.layer{li}.0", h, stride, q)
-        h = basic_block(sd, f"{p}.layer{li}.1", h, 1, q)
+    for j, (li, stride) in enumerate(((1, 1), (2, 2), (3, 2), (4, 2))):
+        films = [None, None]
+        if task_emb is not None and li >= 2 and f"{p}.film_fcs.{li - 2}.weight" in sd:
+            ff = q(F.linear(task_emb, sd[f"{p}.film_fcs.{li - 2}.weight"], sd[f"{p}.film_fcs.{li - 2}.bias"]))
+            ff = ff.view(ff.shape[0], 2, 2, -1).repeat_interleave(per_sample, dim=0)
+            films = [(ff[:, 0, b], ff[:, 1, b]) for b in range(2)]
+        h = basic_block(sd, f"{p}.layer{li}.0", h, stride, q, films[0])
+        h = basic_block(sd, f"{p}.layer{li}.1", h, 1, q, films[1])
     return h
 
 
@@ -88,9 +104,15 @@ def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: 
     mean = torch.tensor(IMAGENET_MEAN)[None, :, None, None]
     std = torch.tensor(IMAGENET_STD)[None, :, None, None]
     x = q((images_u8.float().flatten(0, 1) / 255.0 - mean) / std)
-    f = resnet18_features(sd, x, q)                                        # [B*V, 512, h, w]
+    lang = cfg.get("use_lang_cond") and task_emb is not None
+    f = resnet18_features(sd, x, q, task_emb if lang else None, V)          # [B*V, 512, h, w]
     f = q(F.conv2d(f, sd["input_proj.weight"], sd["input_proj.bias"]))     # [B*V, d, h, w]
     h, w = f.shape[-2:]
+    fs = cfg.get("frame_stack", 1)
+    if fs > 1:  # image index = camera * fs + frame; the frames of a view are stacked on channels, then projection_layer (1x1)
+        V //= fs
+        f = f.view(B * V, fs * d, h, w)
+        f = q(F.conv2d(f, sd["projection_layer.weight"], sd["projection_layer.bias"]))
     f = f.view(B, V, d, h, w).permute(0, 2, 3, 1, 4).reshape(B, d, h, V * w)   # views along width
     pos = sine_pos_embed(h, w, d).repeat(1, 1, V)                           # [d, h, V*w]
     src = f.flatten(2).transpose(1, 2)                                      # [B, N, d]
