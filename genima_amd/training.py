@@ -709,8 +709,12 @@ class ControlNetTrainer:
 
     def train_step(self, batch) -> torch.Tensor:
         """batch: ``pixel_values`` (NCHW in [-1, 1], or NHWC f16 8-channel), ``conditioning_pixel_values`` (same, in [0, 1]),
-        ``input_ids`` [b, 77] -- the collate_fn output of diffusion/train_controlnet_genima.py:934-964.  Returns the device loss."""
+        ``input_ids`` [b, 77] -- the collate_fn output of diffusion/train_controlnet_genima.py:934-964 -- or the uint8 batch of
+        data.collate_u8 (``pixel_values_u8`` / ``conditioning_pixel_values_u8``).  Returns the device loss."""
         E, dev = self.E, self.E.device
+        if "pixel_values_u8" in batch:  # the uint8 NHWC host batch of genima_amd/data.py: ToTensor + Normalize happen on the device
+            from .data import to_device
+            batch = to_device(E, batch)
         x8 = self._nhwc8(batch["pixel_values"])
         cond8 = self._nhwc8(batch["conditioning_pixel_values"])
         if self.augmentations:  # augment_data(args, batch) (:1321): colour jitter on the conditioning image, shared reflect-pad crop

@@ -120,3 +120,66 @@ def test_gradient_accumulation_and_lr_schedule():
     upd = (full.cn.master - init).abs().mean().item()
     d = (full.cn.master - acc.cn.master).abs().mean().item()
     assert upd > 0 and d <= 0.02 * upd, (d, upd)
+
+
+def test_data_path_to_trainer_end_to_end(tmp_path):
+    """PNG tree -> RLBenchDataset -> DataLoader (uint8 NHWC, prefetch thread) -> device ToTensor / Normalize kernel -> train_step, driven by
+    TrainLoop with accumulation, checkpoint rotation and ``resume latest`` (diffusion/train_controlnet_genima.py:870-964, 1281-1457)."""
+    import os
+    import pickle
+
+    from PIL import Image
+
+    from genima_amd import data as D
+    from genima_amd.engine import Engine
+    from genima_amd.packing import pack_state_dict
+    from genima_amd.pipeline import HashTokenizer
+    from genima_amd.scheduler import DDPMScheduler
+    from genima_amd.train_loop import TrainLoop, list_checkpoints
+    from genima_amd.training import ControlNetTrainer
+
+    root = str(tmp_path / "data")
+    rng = np.random.RandomState(1)
+    base = os.path.join(root, "open_box", "variation0")
+    os.makedirs(os.path.join(base, "episodes"))
+    with open(os.path.join(base, "variation_descriptions.pkl"), "wb") as f:
+        pickle.dump(["open the box"], f)
+    for e in range(2):
+        for kind in ("rgb", "rgb_rendered"):
+            d = os.path.join(base, "episodes", f"episode{e}", kind)
+            os.makedirs(d)
+            for i in range(4):
+                Image.fromarray(rng.randint(0, 256, (300, 300, 3), dtype=np.uint8)).save(os.path.join(d, f"{i}.png"))
+    ds = D.RLBenchDataset(root, tasks="open_box", num_demos=2)
+    fam = configs.family("tiny")
+    tok = HashTokenizer(fam["text"]["vocab_size"])
+    loader = D.DataLoader(ds, 2, tok, 256, shuffle=True, seed=0)  # Resize(256) + CenterCrop(256): 32x32 latents
+    E = Engine("cuda:0")
+    # the device conversion equals ToTensor + Normalize exactly (f16-rounded)
+    hb = next(iter(D.DataLoader(ds, 2, tok, 256, shuffle=False, prefetch=0)))
+    db = D.to_device(E, hb)
+    ref = D.collate_fn([ds[0], ds[1]], tok, 256)
+    assert torch.equal(db["pixel_values"][..., :3].permute(0, 3, 1, 2).float().cpu(), ref["pixel_values"].half().float())
+    assert torch.equal(db["conditioning_pixel_values"][..., :3].permute(0, 3, 1, 2).float().cpu(), ref["conditioning_pixel_values"].half().float())
+    assert float(db["pixel_values"][..., 3:].abs().max()) == 0.0 and torch.equal(db["input_ids"].cpu(), ref["input_ids"])
+
+    def trainer():
+        synth = lambda sch, s: weights.synth_state_dict(sch, s)  # noqa: E731
+        tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], pack_state_dict(synth(schema.unet_schema(fam["unet"]), 1), "cuda"),
+                               synth(schema.controlnet_schema(fam["controlnet"]), 2), lr=1e-4, gradient_accumulation_steps=2)
+        tr.attach_frozen(fam["vae"], pack_state_dict(synth(schema.vae_schema(fam["vae"]), 3), "cuda"), fam["text"],
+                         pack_state_dict(synth(schema.clip_text_schema(fam["text"]), 4), "cuda"), DDPMScheduler(), seed=5,
+                         augmentations="crop,colorjitter")
+        return tr
+
+    out = str(tmp_path / "run")
+    logs = []
+    tr = trainer()
+    loop = TrainLoop(tr, out, num_train_epochs=2, checkpointing_steps=1, checkpoints_total_limit=2, log=logs.append)
+    assert loop.run(loader) == 3  # 6 examples / batch 2 = 3 micro-batches per epoch, 2 per optimizer step -> 1 + 2 steps over 2 epochs
+    assert tr.opt_step == 3 and np.isfinite(float(loop.last_loss))
+    assert list_checkpoints(out) == ["checkpoint-2", "checkpoint-3"]
+    tr2 = trainer()
+    loop2 = TrainLoop(tr2, out, max_train_steps=4, checkpointing_steps=100, resume_from_checkpoint="latest", log=logs.append)
+    assert loop2.run(loader) == 4 and torch.equal(tr2.cn.exp_avg_sq > 0, tr2.cn.exp_avg_sq > 0)
+    assert any("Resuming from checkpoint checkpoint-3" in m for m in logs) and tr2.opt_step == 4
