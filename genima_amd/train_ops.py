@@ -267,3 +267,45 @@ def cast_f32_f16(E: Engine, x: torch.Tensor, out: torch.Tensor):
 def fill_f32(E: Engine, x: torch.Tensor, v: float = 0.0):
     check(E.lib.gn_fill_f32(E._ctx, _ptr(x), x.numel(), float(v)), "gn_fill_f32")
     return x
+
+
+# ---- ACT controller update (csrc/act_train.hip) ------------------------------------------------------------------------------------------
+def film_bwd(E: Engine, dy, x, gamma, beta, rows_per_film: int, act: int, dx, dz=None, dzx=None):
+    Cc = x.shape[-1]
+    check(E.lib.gn_film_bwd(E._ctx, _ptr(dy), _ptr(x), _ptr(gamma), _ptr(beta), gamma.stride(0), rows_per_film, x.numel() // Cc, Cc, act,
+                            _ptr(dx), _ptr(dz), _ptr(dzx)), "gn_film_bwd")
+
+
+def dropout(E: Engine, x: torch.Tensor, keep_mask: torch.Tensor, scale: float) -> torch.Tensor:
+    out = torch.empty_like(x)
+    check(E.lib.gn_dropout(E._ctx, _ptr(x), _ptr(keep_mask), _ptr(out), x.numel(), float(scale)), "gn_dropout")
+    return out
+
+
+def add_f32_to_f16(E: Engine, src: torch.Tensor, dst_flat: torch.Tensor, ld_dst: int, B: int, Cc: int):
+    check(E.lib.gn_add_f32_to_f16(E._ctx, _ptr(src), src.stride(0), _ptr(dst_flat), ld_dst, B, Cc), "gn_add_f32_to_f16")
+
+
+def cvae_sample(E: Engine, info: torch.Tensor, eps: torch.Tensor, L: int, ldz: int) -> torch.Tensor:
+    B = info.shape[0]
+    z = torch.zeros((B, ldz), dtype=F16, device=E.device)
+    check(E.lib.gn_cvae_sample(E._ctx, _ptr(info), info.stride(0), _ptr(eps), _ptr(z), ldz, B, L), "gn_cvae_sample")
+    return z
+
+
+def cvae_bwd(E: Engine, info: torch.Tensor, eps: torch.Tensor, dz: torch.Tensor, L: int, kl_scale: float) -> torch.Tensor:
+    B = info.shape[0]
+    dinfo = torch.zeros_like(info)
+    check(E.lib.gn_cvae_bwd(E._ctx, _ptr(info), info.stride(0), _ptr(eps), _ptr(dz), dz.stride(0), _ptr(dinfo), B, L, float(kl_scale)), "gn_cvae_bwd")
+    return dinfo
+
+
+def act_loss(E: Engine, a_hat: torch.Tensor, actions: torch.Tensor, info: torch.Tensor, T_valid: int, A: int, L: int, kl_weight: float,
+             grad_scale: float, is_pad: Optional[torch.Tensor] = None):
+    """a_hat f16 [B, T_rows, ld] -> (out4 f32 = (loss, l1, gripper, kl), d_a_hat f16 like a_hat)."""
+    B, Tr, ld = a_hat.shape
+    out4 = torch.zeros(4, dtype=F32, device=E.device)
+    d = torch.empty_like(a_hat)
+    check(E.lib.gn_act_loss(E._ctx, _ptr(a_hat), ld, Tr * ld, _ptr(actions), _ptr(is_pad), _ptr(info), info.stride(0), B, T_valid, Tr, A, L,
+                            float(kl_weight), float(grad_scale), _ptr(out4), _ptr(d)), "gn_act_loss")
+    return out4, d

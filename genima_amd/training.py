@@ -235,7 +235,7 @@ class Graph:
             full = sh_src.t if sh_var is not None else sh_src
             o, n = W["__meta__"]["temb_slices"][prefix]
             sh, ld = full[:, o:o + n], full.shape[1]
-        y = E.conv2d(x.t, w, W[bn], ksize=ksize, stride=stride, x2=x2.t if x2 is not None else None, shift=sh, ldshift=ld,
+        y = E.conv2d(x.t, w, W[bn] if bn else None, ksize=ksize, stride=stride, x2=x2.t if x2 is not None else None, shift=sh, ldshift=ld,
                      residual=residual.t if residual is not None else None, upsample2x=upsample2x)
         needs_in = x.needs or (x2 is not None and x2.needs)
         out = Var(y, needs_in or net.G is not None or (residual is not None and residual.needs))
@@ -253,7 +253,8 @@ class Graph:
                 assert M % 8 == 0, "conv wgrad needs B*Ho*Wo to be a multiple of 8"
                 if sh_var is not None:
                     T.colsum(E, dy2, net.dshift[prefix], B, Ho * Wo, Cout, Cout)
-                T.colsum(E, dy2, net.G[bn], 1, M, Cout, Cout)
+                if bn:
+                    T.colsum(E, dy2, net.G[bn], 1, M, Cout, Cout)
                 dyt = T.transpose2d(E, dy2, M, Cout)
                 cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)
                 Kw = ksize * ksize * C1
@@ -273,6 +274,52 @@ class Graph:
                             dxi = E.conv2d(src_dy, wd[r0:r1], None, ksize=ksize)
                             self.acc(src, T.sumpool2x2(E, dxi) if upsample2x else dxi)
         return self._push(out, bw)
+
+    # ---- FiLM / per-channel affine (ACT image encoder: frozen BatchNorm as an affine, language FiLM from a feature Var), dropout, ...
+    def film(self, x: Var, gamma: torch.Tensor, beta: torch.Tensor, rows_per_film: int, act: int = ACT_NONE, feat: Optional[Var] = None) -> Var:
+        """y = act((1 + gamma[b]) * x + beta[b]); gamma / beta are [B, C] views (constants, or column slices of ``feat.t`` whose gradient
+        then receives dgamma / dbeta = per-(b, c) sums of dz * x / dz)."""
+        E = self.E
+        y = E.film(x.t, gamma, beta, rows_per_film, act)
+        out = Var(y, x.needs or (feat is not None and feat.needs))
+        Cc = x.t.shape[-1]
+        rows = x.t.numel() // Cc
+
+        def bw(dy):
+            want = feat is not None and feat.needs
+            dx = torch.empty_like(x.t)
+            dz = torch.empty_like(x.t) if want else None
+            dzx = torch.empty_like(x.t) if want else None
+            T.film_bwd(E, dy, x.t, gamma, beta, rows_per_film, act, dx, dz, dzx)
+            self.acc(x, dx)
+            if want:
+                if feat.cell[0] is None:
+                    feat.cell[0] = torch.zeros_like(feat.t)
+                nb = rows // rows_per_film
+                sums = torch.zeros((2, nb, Cc), dtype=F32, device=E.device)
+                T.colsum(E, dzx.view(rows, Cc), sums[0], nb, rows_per_film, Cc, Cc, accumulate=False)
+                T.colsum(E, dz.view(rows, Cc), sums[1], nb, rows_per_film, Cc, Cc, accumulate=False)
+                fg = feat.cell[0].view(feat.t.shape)
+                goff = (gamma.data_ptr() - feat.t.data_ptr()) // 2
+                boff = (beta.data_ptr() - feat.t.data_ptr()) // 2
+                ldf = feat.t.shape[-1]
+                T.add_f32_to_f16(E, sums[0], fg.view(-1)[goff:], ldf, nb, Cc)
+                T.add_f32_to_f16(E, sums[1], fg.view(-1)[boff:], ldf, nb, Cc)
+        return self._push(out, bw)
+
+    def dropout(self, x: Var, p: float, generator=None) -> Var:
+        """Inverted dropout with a torch-drawn keep mask (RNG draws are plumbing; the masking runs in gn_dropout)."""
+        if p <= 0.0:
+            return x
+        E = self.E
+        mask = (torch.rand(x.t.shape, device=E.device, generator=generator) >= p).to(torch.uint8)
+        scale = 1.0 / (1.0 - p)
+        out = Var(T.dropout(E, x.t, mask, scale), x.needs)
+        return self._push(out, lambda dy: self.acc(x, T.dropout(E, dy.contiguous(), mask, scale)))
+
+    def custom(self, y: torch.Tensor, needs: bool, bw) -> Var:
+        """Escape hatch for layout ops (token assembly, slicing, sub-sampling): ``bw(dy)`` routes the gradient itself."""
+        return self._push(Var(y, needs), bw)
 
     # ---- norms
     def groupnorm(self, net: FrozenParams, x: Var, wn: str, bn: str, groups: int, eps: float, act: int = ACT_NONE,

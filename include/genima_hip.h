@@ -320,6 +320,26 @@ int32_t gn_event_record(gn_ctx* ctx, void* ev);
 int32_t gn_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
 int32_t gn_stream_synchronize(gn_ctx* ctx);
 
+/* ---- ACT controller update (controller/method/genima_act.py:27-139, :348-422) ----------------------------
+ * gn_film_bwd: backward of gn_film (act NONE / RELU): dx = dz (1 + gamma), with dz = dy * act'(z); optional copies dz and dz * x whose
+ *   per-(batch, channel) column sums (gn_colsum_f32) are dbeta / dgamma.
+ * gn_dropout: out = x * keep_mask * scale (inverted dropout, mask drawn by the caller; the backward is the same call on dy).
+ * gn_cvae_sample / gn_cvae_bwd: z = mu + exp(logvar / 2) eps over info = [mu | logvar] rows (reparametrize, :64-68) and its backward
+ *   plus the KL term's gradient (kl_scale = loss_scale * kl_weight / B).
+ * gn_act_loss: calculate_loss (:115-139): out4 = (loss, l1, gripper BCE x 0.05, kl); d_a_hat = grad_scale * d(l1 + gripper)/d(a_hat);
+ *   a_hat f16 [B][T_rows][ld_hat] (rows >= T and columns >= A are padding), actions f32 [B][T][A], is_pad u8 [B][T] or NULL.
+ * gn_add_f32_to_f16: dst[b, c] += src[b, c] (f32 column sums into an f16 feature gradient). */
+int32_t gn_film_bwd(gn_ctx* ctx, const void* dy, const void* x, const void* gamma, const void* beta, int64_t ld_film, int64_t rows_per_film,
+                    int64_t rows, int32_t C, int32_t act, void* dx, void* dz, void* dzx);
+int32_t gn_dropout(gn_ctx* ctx, const void* x, const uint8_t* keep_mask, void* out, int64_t n, float scale);
+int32_t gn_cvae_sample(gn_ctx* ctx, const void* info, int64_t ld_info, const float* eps, void* z, int64_t ld_z, int32_t B, int32_t L);
+int32_t gn_cvae_bwd(gn_ctx* ctx, const void* info, int64_t ld_info, const float* eps, const void* dz, int64_t ld_z, void* dinfo, int32_t B, int32_t L,
+                    float kl_scale);
+int32_t gn_act_loss(gn_ctx* ctx, const void* a_hat, int64_t ld_hat, int64_t bs_hat, const float* actions, const uint8_t* is_pad, const void* info,
+                    int64_t ld_info, int32_t B, int32_t T, int32_t T_rows, int32_t A, int32_t L, float kl_weight, float grad_scale, float* out4,
+                    void* d_a_hat);
+int32_t gn_add_f32_to_f16(gn_ctx* ctx, const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t B, int32_t C);
+
 /* ---- data-parallel gradient exchange (SURVEY.md section 8b "comm"; replaces accelerate's DDP all-reduce under accelerator.backward,
  * diffusion/train_controlnet_genima.py:1216-1218, :1402-1405).  One communicator per (process, GPU); the RCCL unique id (128 bytes) is
  * created on rank 0 and carried to the other ranks by the caller.  gn_comm_allreduce_grads SUMS one flat f32 buffer over the ranks in

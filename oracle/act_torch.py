@@ -96,14 +96,24 @@ def ln(sd, p, x):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
 
 
-def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: torch.Tensor = None, q=_id):
+def _nodrop(name, x):
+    return x
+
+
+def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: torch.Tensor = None, q=_id, latent_z: torch.Tensor = None,
+                drop=_nodrop, images_float: torch.Tensor = None):
     """images_u8: [B, V, 3, H, W] values 0..255; qpos [B, state_dim]; task_emb [B, lang_dim] or None.
-    -> (a_hat [B, num_queries, action_dim], is_pad_hat [B, num_queries, 1])."""
+    -> (a_hat [B, num_queries, action_dim], is_pad_hat [B, num_queries, 1]).
+    Training hooks: ``latent_z`` [B, latent_dim] replaces the z = 0 prior with the CVAE posterior sample (genima_act.py:57-68);
+    ``drop(name, x)`` applies a dropout mask at the sites the device path supports (state MLP p = 0.3, genima_act.py:237-241; the DETR
+    layers' residual / feed-forward dropouts p = 0.1 -- NOT nn.MultiheadAttention's attention-probability dropout);
+    ``images_float`` = already augmented images on the 0..255 scale (then ``images_u8`` only gives the shape)."""
     B, V = images_u8.shape[:2]
     d, heads = cfg["hidden_dim"], cfg["nheads"]
     mean = torch.tensor(IMAGENET_MEAN)[None, :, None, None]
     std = torch.tensor(IMAGENET_STD)[None, :, None, None]
-    x = q((images_u8.float().flatten(0, 1) / 255.0 - mean) / std)
+    src_img = images_float if images_float is not None else images_u8.float()
+    x = q((src_img.flatten(0, 1) / 255.0 - mean) / std)
     lang = cfg.get("use_lang_cond") and task_emb is not None
     f = resnet18_features(sd, x, q, task_emb if lang else None, V)          # [B*V, 512, h, w]
     f = q(F.conv2d(f, sd["input_proj.weight"], sd["input_proj.bias"]))     # [B*V, d, h, w]
@@ -117,9 +127,10 @@ def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: 
     pos = sine_pos_embed(h, w, d).repeat(1, 1, V)                           # [d, h, V*w]
     src = f.flatten(2).transpose(1, 2)                                      # [B, N, d]
     pos = q(pos.flatten(1).t())[None].expand(B, -1, -1)
-    proprio = F.linear(q(F.linear(qpos, sd["input_proj_robot_state.0.weight"], sd["input_proj_robot_state.0.bias"])),
+    proprio = F.linear(q(drop("state", F.linear(qpos, sd["input_proj_robot_state.0.weight"], sd["input_proj_robot_state.0.bias"]))),
                        sd["input_proj_robot_state.2.weight"], sd["input_proj_robot_state.2.bias"])
-    latent = F.linear(torch.zeros(B, cfg["latent_dim"]), sd["latent_out_proj.weight"], sd["latent_out_proj.bias"])
+    z0 = torch.zeros(B, cfg["latent_dim"]) if latent_z is None else latent_z
+    latent = F.linear(z0, sd["latent_out_proj.weight"], sd["latent_out_proj.bias"])
     extra = [latent, proprio]
     if cfg.get("use_lang_cond") and task_emb is not None:
         extra.append(F.linear(task_emb, sd["task_proj.weight"], sd["task_proj.bias"]))
@@ -129,9 +140,9 @@ def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: 
     for i in range(cfg["enc_layers"]):
         p = f"transformer.encoder.layers.{i}"
         qk = q(src + pos)
-        src = q(ln(sd, p + ".norm1", src + mha(sd, p + ".self_attn", qk, qk, src, heads, q)))
-        ff = F.linear(q(F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"]))), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
-        src = q(ln(sd, p + ".norm2", src + ff))
+        src = q(ln(sd, p + ".norm1", src + drop(p + ".d1", mha(sd, p + ".self_attn", qk, qk, src, heads, q))))
+        ff = F.linear(q(drop(p + ".df", F.relu(F.linear(src, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])))), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+        src = q(ln(sd, p + ".norm2", src + drop(p + ".d2", ff)))
     memory = src
     mem_pos = q(memory + pos)
     nq = cfg["num_queries"]
@@ -140,10 +151,10 @@ def act_forward(sd, cfg, images_u8: torch.Tensor, qpos: torch.Tensor, task_emb: 
     for i in range(cfg["dec_layers"]):
         p = f"transformer.decoder.layers.{i}"
         qk = q(tgt + qpos_e)
-        tgt = q(ln(sd, p + ".norm1", tgt + mha(sd, p + ".self_attn", qk, qk, tgt, heads, q)))
-        tgt = q(ln(sd, p + ".norm2", tgt + mha(sd, p + ".multihead_attn", q(tgt + qpos_e), mem_pos, memory, heads, q)))
-        ff = F.linear(q(F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"]))), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
-        tgt = q(ln(sd, p + ".norm3", tgt + ff))
+        tgt = q(ln(sd, p + ".norm1", tgt + drop(p + ".d1", mha(sd, p + ".self_attn", qk, qk, tgt, heads, q))))
+        tgt = q(ln(sd, p + ".norm2", tgt + drop(p + ".d2", mha(sd, p + ".multihead_attn", q(tgt + qpos_e), mem_pos, memory, heads, q))))
+        ff = F.linear(q(drop(p + ".df", F.relu(F.linear(tgt, sd[p + ".linear1.weight"], sd[p + ".linear1.bias"])))), sd[p + ".linear2.weight"], sd[p + ".linear2.bias"])
+        tgt = q(ln(sd, p + ".norm3", tgt + drop(p + ".d3", ff)))
     hs = q(ln(sd, "transformer.decoder.norm", tgt))
     a_hat = F.linear(hs, sd["action_head.weight"], sd["action_head.bias"])
     is_pad = F.linear(hs, sd["is_pad_head.weight"], sd["is_pad_head.bias"])
