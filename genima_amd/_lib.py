@@ -136,6 +136,7 @@ SIGNATURES = {
     "gn_cvae_bwd": (_I32, [_P, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _F]),
     "gn_act_loss": (_I32, [_P, _P, _I64, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _F, _P, _P]),
     "gn_add_f32_to_f16": (_I32, [_P, _P, _I64, _P, _I64, _I32, _I32]),
+    "gn_warp_bilinear": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_comm_unique_id": (_I32, [_P]),
     "gn_comm_init": (_I32, [_P, _I32, _I32, _P, C.POINTER(_P)]),
     "gn_comm_destroy": (_I32, [_P]),

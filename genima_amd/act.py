@@ -395,8 +395,46 @@ class GenimaACT:
         io = self._run(img, low_dim_state.to(self.device).flatten(1), None if lang_tokens is None else lang_tokens.to(self.device))
         return io.a_hat[..., : self.config["action_dim"]]
 
+    def update(self, replay_iter, step: int = 0, replay_buffer=None, **trainer_kw) -> Dict[str, float]:
+        """``GenimaACT.update`` (controller/method/genima_act.py:348-422): one behaviour-cloning step on ``next(replay_iter)`` -- a dict
+        with ``action`` [B, T, A], ``low_dim_state`` [B, fs, S], the ``*rgb*`` camera tensors [B, fs, 3, H, W] (``tp1`` keys ignored),
+        ``lang_tokens`` [B, fs, 77] and ``reward``.  The trainer (act_training.ACTTrainer: CVAE posterior, loss, tape backward, two-group
+        AdamW) is built on first use from this agent's weights; train-time augmentation runs when ``data_augmentation`` is on."""
+        from .act_training import ACTTrainer, act_augment, act_train_schema
+
+        if getattr(self, "_trainer", None) is None:
+            sch = act_train_schema(self.config)
+            sd = dict(self._sd)
+            extra = weights.synth_state_dict(OrderedDict((k, v) for k, v in sch.items() if k not in sd), 77)  # CVAE encoder: fresh init
+            sd.update(extra)
+            self._trainer = ACTTrainer(Engine(self.device), self.config, sd, self.clip_config, self.Wclip, **trainer_kw)
+            self._aug_gen = torch.Generator().manual_seed(0)
+        batch = next(replay_iter)
+        batch = {k: torch.as_tensor(v) for k, v in batch.items()}
+        qpos = batch["low_dim_state"].flatten(1).float()
+        keys = [k for k in batch if re.match(r".*rgb(?!.*?tp1)", k) and "tp1" not in k]
+        image = torch.stack([batch[k] for k in keys], dim=1)  # [B, V, fs, 3, H, W]
+        B = image.shape[0]
+        image = image.reshape(B, -1, 3, image.shape[-2], image.shape[-1]).to(self.device)
+        img_u8 = (image if image.dtype == torch.uint8 else image.round().clamp(0, 255).to(torch.uint8)).permute(0, 1, 3, 4, 2).contiguous()
+        task = None
+        if self.config.get("use_lang_cond"):
+            task, _ = self.encode_clip_text(batch["lang_tokens"])
+        tr = self._trainer
+        imgs = act_augment(tr.E, img_u8, self._aug_gen) if self.config.get("data_augmentation", True) else img_u8
+        metrics = tr.update(imgs, qpos, task, batch["action"].float())
+        if "reward" in batch:
+            metrics["batch_reward"] = float(batch["reward"].float().mean())
+        # the eval path reads the packed inference weights: refresh them from the trainer's masters
+        self._sd.update({k: v.cpu() for k, v in tr.state_dict().items() if k in self._sd})
+        self._dirty = True
+        return metrics
+
     def act(self, obs: Dict[str, torch.Tensor], step: int = 0, eval_mode: bool = True) -> torch.Tensor:
         """obs: {'<cam>_rgb': uint8/float [B, fs, 3, H, W], 'low_dim_state': f32 [B, fs, state], 'lang_tokens': int [B, fs, 77]}."""
+        if getattr(self, "_dirty", False):  # weights moved by update(): re-pack once before acting
+            self.W = pack_act(self._sd, self.device)
+            self._progs, self._dirty = {}, False
         qpos = obs["low_dim_state"].to(self.device).flatten(1)
         rgb_keys = [k for k in obs if re.match(r"rgb.*|.*_rgb$", k)]  # obs-dict key order == RoboBase camera enumeration
         image = torch.stack([obs[k].to(self.device) for k in rgb_keys], dim=1)  # [B, V, fs, 3, H, W]

@@ -358,6 +358,59 @@ class ACTTrainer:
         return unpack_state_dict(self.cn.packed_master(), OrderedDict((k, sch[k]) for k in self.names))
 
 
+def elastic_displacement(H: int, W: int, alpha: float = 80.0, sigma: float = 10.0, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """torchvision v2.ElasticTransform._get_params: per axis, uniform [-1, 1) noise, Gaussian blur (kernel int(8 sigma + 1) made odd,
+    reflect padding) and a scale of alpha / size -- in the normalised [-1, 1] grid units, converted here to pixels (x (size - 1) / 2).
+    Host work on one [H, W] field per call (the transform is called on the whole batch: one field for every image)."""
+    k = int(8 * sigma + 1)
+    k += (k % 2 == 0)
+    half = (k - 1) * 0.5
+    pdf = torch.exp(-0.5 * (torch.linspace(-half, half, k) / sigma) ** 2)
+    ker = (pdf / pdf.sum()).double()
+    out = []
+    for size, n in ((W, (H, W)), (H, (H, W))):
+        f = (torch.rand([1, 1] + list(n), generator=generator) * 2 - 1).double()
+        pad = k // 2
+        f = torch.nn.functional.pad(f, (pad, pad, pad, pad), mode="reflect")
+        f = torch.nn.functional.conv2d(f, ker.view(1, 1, 1, k))
+        f = torch.nn.functional.conv2d(f, ker.view(1, 1, k, 1))
+        out.append((f[0, 0] * alpha / size) * (size - 1) * 0.5)
+    return torch.stack(out, dim=-1).float().contiguous()  # [H, W, 2] = (dx, dy) in pixels
+
+
+def act_augment(E: Engine, images_u8: torch.Tensor, generator: Optional[torch.Generator] = None, p: float = 0.5, noise_std: float = 5.0):
+    """``GenimaACTPolicy.aug_transforms`` (controller/method/genima_act.py:150-163) on uint8 [B, V, H, W, 3] device images:
+    RandomApply(p)[ElasticTransform(80, 10)], RandomApply(p)[ColorJitter(0.2, 0.2, 0.1, 0.05)], RandomApply(p)[RandomCrop(size, padding
+    = 4)] -- each called on the whole batch tensor, so ONE draw per call -- then AddGaussianNoise(0, 5.0) on the 0..255 scale
+    (controller/utils/misc.py:50-65).  Returns f16 [B, V, H, W, 8] on the 0..1 scale (the trainer's float-image input).  The random
+    draws use ``generator`` (a CPU generator) in torchvision's order; the pixel work runs in HIP kernels."""
+    from . import augment as A
+    from ._lib import check
+
+    B, V, H, W, _ = images_u8.shape
+    x = E.image_u8_to_f16(images_u8.view(B * V, H, W, 3), 8, 1.0, 0.0)
+    if float(torch.rand(1, generator=generator)) < p:
+        disp = elastic_displacement(H, W, generator=generator).to(E.device)
+        y = torch.empty_like(x)
+        check(E.lib.gn_warp_bilinear(E._ctx, x.data_ptr(), y.data_ptr(), disp.data_ptr(), B * V, H, W, 8), "gn_warp_bilinear")
+        x = y
+    if float(torch.rand(1, generator=generator)) < p:
+        x = A.color_jitter(E, x, *A.draw_color_jitter(generator))
+    if float(torch.rand(1, generator=generator)) < p:  # RandomCrop(padding=4): constant (zero) padding, then a crop back to H x W
+        i = int(torch.randint(0, 9, size=(1,), generator=generator))
+        j = int(torch.randint(0, 9, size=(1,), generator=generator))
+        y = torch.zeros_like(x)  # out[r, c] = padded[r + i, c + j], padded = x at offset (4, 4): a shifted copy (layout only)
+        r0, r1 = max(0, 4 - i), min(H, H + 4 - i)
+        c0, c1 = max(0, 4 - j), min(W, W + 4 - j)
+        y[:, r0:r1, c0:c1] = x[:, r0 + i - 4:r1 + i - 4, c0 + j - 4:c1 + j - 4]
+        x = y
+    noise = torch.zeros_like(x)
+    noise[..., :3] = torch.randn((B * V, H, W, 3), device=E.device, dtype=torch.float32, generator=None).to(F16)
+    one = torch.ones(B * V, dtype=F32, device=E.device)
+    x = E.add_noise(x, noise, one, one * (noise_std / 255.0))
+    return x.view(B, V, H, W, 8)
+
+
 def _scatter_row(like: torch.Tensor, row: int, dy: torch.Tensor) -> torch.Tensor:
     out = torch.zeros_like(like)
     out[:, row] = dy

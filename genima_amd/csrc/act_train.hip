@@ -113,7 +113,39 @@ __global__ __launch_bounds__(256) void act_loss_kernel(const f16* __restrict__ a
   }
 }
 
-// x[r, c] *= scale[c]?  no: f32 flat buffers.  y[i] += a * x[i] is not needed; what IS needed: f32 -> f16 add of per-(b, c) sums into a feature gradient
+// ElasticTransform's warp (torchvision v2.ElasticTransform -> grid_sample bilinear, zero fill): out[b, y, x, :] = bilinear(in[b], x + dx, y + dy)
+// with ONE displacement field (pixels) shared by every image of the batch, as when the transform is called on a batched tensor.
+__global__ void warp_bilinear_kernel(const f16* __restrict__ in, f16* __restrict__ out, const float* __restrict__ disp, int B, int H, int W, int C8) {
+  const long i = gtid();
+  if (i >= (long)B * H * W * C8) return;
+  const int c = (int)(i % C8) * 8;
+  long r = i / C8;
+  const int x = (int)(r % W);
+  r /= W;
+  const int y = (int)(r % H), b = (int)(r / H);
+  const float sx = (float)x + disp[((long)y * W + x) * 2], sy = (float)y + disp[((long)y * W + x) * 2 + 1];
+  const float fx = floorf(sx), fy = floorf(sy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float ax = sx - fx, ay = sy - fy;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
+    const float w = ((t & 1) ? ax : 1.0f - ax) * ((t >> 1) ? ay : 1.0f - ay);
+    if (xx >= 0 && xx < W && yy >= 0 && yy < H && w != 0.0f) {
+      const uint4 rv = *reinterpret_cast<const uint4*>(in + (((long)b * H + yy) * W + xx) * (C8 * 8) + c);
+      const f16x8 v = *reinterpret_cast<const f16x8*>(&rv);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += w * (float)v[e];
+    }
+  }
+  f16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (f16)acc[e];
+  *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<uint4*>(&o);
+}
+
+// f32 -> f16 add of per-(b, c) sums into a feature gradient  y[i] += a * x[i] is not needed; what IS needed: f32 -> f16 add of per-(b, c) sums into a feature gradient
 __global__ void add_f32_to_f16_kernel(const float* __restrict__ src, long ld_src, f16* __restrict__ dst, long ld_dst, int B, int C) {
   const long i = gtid();
   if (i >= (long)B * C) return;
@@ -167,6 +199,14 @@ int32_t gn_act_loss(gn_ctx* ctx, const void* a_hat, int64_t ld_hat, int64_t bs_h
              "gn_act_loss: bad arguments");
   hipLaunchKernelGGL(act_loss_kernel, dim3(1), dim3(256), 0, ctx->stream, (const f16*)a_hat, (long)ld_hat, (long)bs_hat, actions, is_pad, (const f16*)info,
                      (long)ld_info, B, T, T_rows, A, L, kl_weight, grad_scale, out4, (f16*)d_a_hat);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_warp_bilinear(gn_ctx* ctx, const void* in, void* out, const float* disp, int32_t B, int32_t H, int32_t W, int32_t C) {
+  GN_REQUIRE(ctx && in && out && disp && in != out && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, "gn_warp_bilinear: bad arguments (C %% 8, no aliasing)");
+  const long n = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(warp_bilinear_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, disp, B, H, W, C / 8);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -339,6 +339,9 @@ int32_t gn_act_loss(gn_ctx* ctx, const void* a_hat, int64_t ld_hat, int64_t bs_h
                     int64_t ld_info, int32_t B, int32_t T, int32_t T_rows, int32_t A, int32_t L, float kl_weight, float grad_scale, float* out4,
                     void* d_a_hat);
 int32_t gn_add_f32_to_f16(gn_ctx* ctx, const float* src, int64_t ld_src, void* dst, int64_t ld_dst, int32_t B, int32_t C);
+/* train-time ElasticTransform of the ACT policy (controller/method/genima_act.py:150-163): bilinear warp of NHWC f16 [B, H, W, C] by one
+ * displacement field disp f32 [H][W][2] = (dx, dy) in pixels shared by the batch; samples outside the image read 0 */
+int32_t gn_warp_bilinear(gn_ctx* ctx, const void* in, void* out, const float* disp, int32_t B, int32_t H, int32_t W, int32_t C);
 
 /* ---- data-parallel gradient exchange (SURVEY.md section 8b "comm"; replaces accelerate's DDP all-reduce under accelerator.backward,
  * diffusion/train_controlnet_genima.py:1216-1218, :1402-1405).  One communicator per (process, GPU); the RCCL unique id (128 bytes) is

@@ -79,3 +79,41 @@ def test_act_update_with_dropout_and_uint8_pipeline_trains():
     losses = [tr.update(img, qpos, task, actions)["actor_l1_loss"] for _ in range(12)]
     print("l1 over 12 updates with dropout:", [f"{v:.4f}" for v in losses])
     assert all(v == v for v in losses) and min(losses[-3:]) < 0.9 * losses[0] and tr.opt_step == 12
+
+
+def test_agent_update_surface_and_augmentations():
+    """``GenimaACT.update(replay_iter, step, replay_buffer)`` from a RoboBase-shaped replay batch, with the train-time augmentation
+    pipeline (elastic warp / colour jitter / zero-padded crop / Gaussian noise); then ``act`` sees the updated weights."""
+    import numpy as np
+
+    from genima_amd.act import GenimaACT, act_schema
+    from genima_amd.act_training import act_augment, elastic_displacement
+
+    cfg, ccfg = dict(configs.TINY_ACT_POLICY, data_augmentation=True), configs.TINY_ACT_CLIP_TEXT
+    agent = GenimaACT(cfg, None, ccfg, None, device="cuda", seed=4)
+    B, S, Tq = 2, cfg["image_size"], cfg["num_queries"]
+    g = torch.Generator().manual_seed(8)
+    cams = ["left_shoulder", "right_shoulder", "front", "wrist"]
+    Vc = ccfg["vocab_size"]
+    toks = np.zeros((B, 1, 77), dtype=np.int32)
+    toks[:, 0, :5] = [Vc - 2, 3, 4, 5, Vc - 1]
+    batch = {f"{c}_rgb": torch.randint(0, 256, (B, 1, 3, S, S), generator=g, dtype=torch.uint8).numpy() for c in cams}
+    batch.update({f"{c}_rgb_tp1": batch[f"{c}_rgb"] for c in cams})  # next-step observations must be ignored (rgb(?!.*?tp1))
+    batch.update(low_dim_state=torch.randn(B, 1, cfg["state_dim"], generator=g).numpy(), lang_tokens=toks, reward=np.ones((B,), np.float32),
+                 action=torch.rand(B, Tq, cfg["action_dim"], generator=g).numpy())
+    obs = {k: torch.as_tensor(v) for k, v in batch.items() if "tp1" not in k and k not in ("action", "reward")}
+    before = agent.act(obs).cpu()
+    m = [agent.update(iter([batch]), i, lr=1e-3, lr_backbone=1e-4) for i in range(3)]
+    assert set(m[0]) == {"actor_loss", "actor_l1_loss", "actor_gripper_loss", "actor_kl_loss", "batch_reward"} and m[0]["batch_reward"] == 1.0
+    assert all(np.isfinite(list(x.values())).all() for x in m)
+    after = agent.act(obs).cpu()
+    assert not torch.equal(before, after), "act() must use the weights update() moved"
+    # the augmentation pieces: identity displacement leaves the image alone; the field has the published scale (alpha / size * smoothing)
+    E = agent._trainer.E
+    img = torch.randint(0, 256, (1, 2, 64, 64, 3), generator=g, dtype=torch.uint8).cuda()
+    disp = elastic_displacement(64, 64, generator=torch.Generator().manual_seed(1))
+    assert tuple(disp.shape) == (64, 64, 2) and 0.01 < float(disp.abs().mean()) < 10.0
+    out = act_augment(E, img, torch.Generator().manual_seed(5))
+    assert out.shape == (1, 2, 64, 64, 8) and out.dtype == torch.float16 and float(out[..., 3:].abs().max()) == 0.0
+    clean = act_augment(E, img, torch.Generator().manual_seed(5), p=0.0, noise_std=0.0)
+    assert torch.equal(clean[..., :3].float().cpu(), (img.float() / 255.0).half().float().cpu())
