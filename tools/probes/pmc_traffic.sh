@@ -5,12 +5,12 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_traffic; mkdir -p $O
 cd $R
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/$c -o p --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-roofline --no-act > $O/$c.log 2>&1 || echo "pass $c failed"
+  timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/$c -o p --output-format csv -- python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-roofline --no-act --no-train --no-single-view > $O/$c.log 2>&1 || echo "pass $c failed"
 done
 python - <<'PY'
 import csv, glob, json, os
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/pmc_traffic"
-fams = [("gemm", ("gemm_dma_kernel", "gemm_kernel", "gemm_fp8_kernel", "splitk_reduce")), ("attn", ("attn_fwd",)), ("layernorm", ("layernorm_kernel",)),
+fams = [("gemm", ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_kernel", "gemm_fp8_kernel", "splitk_reduce")), ("attn", ("attn_fwd",)), ("layernorm", ("layernorm_kernel",)),
         ("gn_stats", ("gn_stats_kernel",)), ("gn_apply", ("gn_apply_kernel",)), ("gn_fused", ("gn_fused_kernel",)), ("gn_finalize", ("gn_finalize_kernel",))]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
