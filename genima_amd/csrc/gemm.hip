@@ -577,9 +577,12 @@ constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, fa
                         // 320-wide N tiles: the 64x64-latent UNet level (N = 320) without padded-tile waste
                         {128, 320, 0.0, false, true},  {256, 320, 0.0, false, true},
                         // ping-pong 256x256 (gemm_pp.hip): counted-vmcnt 8-phase K loop
-                        {256, 256, 0.0, false, true}};
-constexpr int kNumCfg = 15;
+                        {256, 256, 0.0, false, true},
+                        // 3-stage LDS-DMA ring (gemm_s3.hip): two K tiles in flight, counted vmcnt -- the latency-bound mid-size launches
+                        {128, 128, 0.0, true, true},   {128, 64, 0.0, false, true},   {64, 64, 0.0, false, true},    {256, 64, 0.0, true, true}};
+constexpr int kNumCfg = 19;
 constexpr int kCfgPP = 14;
+constexpr int kCfgS3 = 15;  // first of the four 3-stage configurations
 
 // the ping-pong kernel's extra restrictions on top of dma_eligible (gemm_pp.hip header)
 bool pp_eligible(const gn_gemm_desc* d) {
@@ -647,7 +650,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (geglu && !kCfg[best].geglu) best = 1;
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
-    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0};
+    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4};
     best = fallback[best];
   }
   pl.cfg = best;
@@ -763,7 +766,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     p.sa = (const float*)d->scale_a; p.sw = (const float*)d->scale_w;
     p.a_bytes = (unsigned)((uint64_t)d->M * d->lda); p.w_bytes = (unsigned)((uint64_t)d->N * d->ldw);
     p.splitk = 1; p.kper = (int)d->K;
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11};
     const int cfg = to_dma[pl.cfg];
     const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
     p.tiles_m = (int)cdiv64(d->M, bm); p.tiles_n = (int)cdiv64(d->N, bn);
@@ -794,7 +797,8 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 11: launch_dma<256, 64, 4, 1>(p, conv, ctx->stream); break;
     case 12: launch_dma<128, 320, 2, 2>(p, conv, ctx->stream); break;
     case 13: launch_dma<256, 320, 4, 2>(p, conv, ctx->stream); break;
-    default: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, 1, ctx->stream); break;
+    case 14: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, 1, ctx->stream); break;
+    default: gn_launch_gemm_s3(&p, pl.cfg - kCfgS3, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;
   }
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {

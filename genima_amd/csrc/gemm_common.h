@@ -234,3 +234,5 @@ constexpr unsigned kOOB = 0xFFFFFFF0u;  // out-of-range buffer offset: the hardw
 
 // the ping-pong 256x256 kernel lives in its own translation unit (gemm_pp.hip); `params` is a GemmParams
 void gn_launch_gemm_pp(const void* params, bool conv, int grid_x, int grid_y, int grid_z, hipStream_t st);
+// the 3-stage ring variants (gemm_s3.hip); cfg 0..3 = {128x128, 128x64, 64x64, 256x64}
+void gn_launch_gemm_s3(const void* params, int cfg, bool conv, int grid_x, int grid_y, int grid_z, hipStream_t st);

@@ -1,0 +1,231 @@
+// 3-stage LDS-DMA ring for the LATENCY-BOUND mid-size launches (Linears / small convs with one workgroup per CU and 5..40 K tiles):
+// the 2-stage kernel of gemm.hip has one K tile in flight and drains it (`vmcnt(0)` + barrier) every iteration, so each iteration costs
+// a full L2 / MALL round trip; here two tiles are in flight and the wait is counted.  Same tiles, loaders, swizzle and epilogue as
+// gemm_dma_kernel (gemm.hip); the per-lane validity selects become OR-masks so that every path issues the same number of VMEM
+// instructions (the counted vmcnt depends on it).  Tiles 16..19 of gn_gemm_desc::tile.
+#include "gemm_common.h"
+
+namespace {
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_s3_kernel(const GemmParams pin) {
+  const GemmParams p = batch_offset(pin);
+  constexpr int NW = WM * WN;
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM >= 1 && TN >= 1, "wave tile >= 32x32");
+  static_assert(NW % 2 == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile rows must split into 8-row DMA groups per wave");
+  constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // DMA instructions per wave per tile
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (A_BYTES + B_BYTES)];  // ONE LDS object (a second one makes hipcc drain vmcnt)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform (LDS-DMA bases live in M0)
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int z = blockIdx.y;
+  const int kbeg = z * p.kper;
+  const int kend = min(p.K, kbeg + p.kper);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+
+  // ---- loader state: this lane's row inside each 8-row group and its (swizzled) logical chunk -----------------------------
+  const int lr = lane >> 3;
+  const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+  int kcur = kbeg + chunk * 8;
+
+  const int Cin = p.C1 + p.C2;
+  const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
+  int iy0[GA], ix0[GA], pbase[GA], pix[GA];
+  unsigned aoff[GA], amask[GA];  // dense: byte offset of the row start (kOOB if the row is out of range)
+  int cc = 0, dy = 0, dx = 0;
+  int cu = 0;         // wave-uniform channel offset of the tile inside its tap (selects the concat source)
+
+  auto set_tap = [&]() {
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+      const bool ok = (unsigned)iy < (unsigned)Hin && (unsigned)ix < (unsigned)Win;
+      const int sy = p.ups ? (iy >> 1) : iy, sx = p.ups ? (ix >> 1) : ix;
+      pix[i] = ok ? pbase[i] + sy * p.W + sx : -1;
+    }
+  };
+
+  if constexpr (CONV) {
+    const int hw = p.Ho * p.Wo;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int m = m0 + 8 * (wave + NW * i) + lr;
+      if (m < p.M) {
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        iy0[i] = oy * p.stride - p.pad_t;
+        ix0[i] = ox * p.stride - p.pad_l;
+        pbase[i] = b * p.H * p.W;
+      } else {
+        iy0[i] = -(1 << 28);
+        ix0[i] = -(1 << 28);
+        pbase[i] = 0;
+      }
+    }
+    const int tap = kcur / Cin;
+    cc = kcur - tap * Cin;
+    dy = tap / p.KW;
+    dx = tap - dy * p.KW;
+    cu = kbeg % Cin;
+    set_tap();
+  } else {
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int m = m0 + 8 * (wave + NW * i) + lr;
+      aoff[i] = (m < p.M) ? (unsigned)((long)m * p.lda * 2) : 0u;
+      amask[i] = (m < p.M) ? 0u : kOOB;
+    }
+  }
+  unsigned woff[GB], wmask[GB];
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int n = n0 + 8 * (wave + NW * i) + lr;
+    woff[i] = (n < p.N) ? (unsigned)((long)n * p.ldw * 2) : 0u;
+    wmask[i] = (n < p.N) ? 0u : kOOB;
+  }
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+  auto dma_tile = [&](int buf) {
+    const unsigned kmask = kcur < kend ? 0u : kOOB;  // OR-masks, not selects: every path must issue the same VMEM instructions
+    unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+    unsigned char* Bs = As + A_BYTES;
+    if constexpr (CONV) {
+      const bool first = cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
+      const int cs = first ? p.C1 : p.C2;
+      const int co = first ? cc : cc - p.C1;
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const unsigned voff = ((unsigned)(pix[i] * cs + co) * 2u) | ((unsigned)(pix[i] >> 31) & kOOB) | kmask;
+        lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
+        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const unsigned voff = (aoff[i] + (unsigned)kcur * 2u) | amask[i] | kmask;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const unsigned voff = (woff[i] + (unsigned)kcur * 2u) | wmask[i] | kmask;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+    }
+    kcur += BK;
+    if constexpr (CONV) {
+      cu += BK;
+      while (cu >= Cin) cu -= Cin;
+      cc += BK;
+      if (cc >= Cin) {
+        do {
+          cc -= Cin;
+          if (++dx == p.KW) { dx = 0; ++dy; }
+        } while (cc >= Cin);
+        set_tap();
+      }
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  // 3-slot ring: tiles t+1 and t+2 are in flight while tile t is multiplied.  The wait is COUNTED -- vmcnt(GA + GB) retires tile t+1's
+  // pieces and leaves tile t+2's in flight across the barrier -- and the barrier is the raw s_barrier (a __syncthreads() behind an
+  // outstanding LDS-DMA drains vmcnt(0)).  WAR: slot (t+2) % 3 was last read in iteration t-1, before the barrier that ended it.
+  constexpr int NIN = GA + GB;  // DMA instructions per wave per tile
+  dma_tile(0);
+  dma_tile(1);  // past the last K tile the offsets are out of range: zero fill, no fetch -- the count stays the same on every path
+  if constexpr (NIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (NIN == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (NIN == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (NIN == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (NIN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (NIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int nxt2 = cur >= 1 ? cur - 1 : 2;  // (cur + 2) % 3
+    dma_tile(nxt2);
+    const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      f16x8 fa[TM], fw[TN];
+      const int c = kk * 2 + hi;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const f16x8*>(As + lds_swz<128>(wm * WTM + i * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fw[j] = *reinterpret_cast<const f16x8*>(Bs + lds_swz<128>(wn * WTN + j * 32 + l31, c));
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (NIN == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if constexpr (NIN == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (NIN == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if constexpr (NIN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (NIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead zero fills
+
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_s3(const GemmParams& p, bool conv, dim3 grid, hipStream_t st) {
+  if (conv)
+    hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
+  else
+    hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
+}
+
+}  // namespace
+
+void gn_launch_gemm_s3(const void* params, int cfg, bool conv, int grid_x, int grid_y, int grid_z, hipStream_t st) {
+  const GemmParams& p = *static_cast<const GemmParams*>(params);
+  const dim3 grid(grid_x, grid_y, grid_z);
+  switch (cfg) {
+    case 0: launch_s3<128, 128, 2, 2>(p, conv, grid, st); break;
+    case 1: launch_s3<128, 64, 2, 2>(p, conv, grid, st); break;
+    case 2: launch_s3<64, 64, 2, 2>(p, conv, grid, st); break;
+    default: launch_s3<256, 64, 4, 1>(p, conv, grid, st); break;
+  }
+}

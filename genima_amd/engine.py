@@ -171,7 +171,7 @@ class Engine:
     # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
     # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
     _retuned = set()  # shapes already re-raced in this process (GN_RETUNE)
-    N_TILE_CFGS = 15  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256 (csrc/gemm.hip kCfg, csrc/gemm_pp.hip)
+    N_TILE_CFGS = 19  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..19 3-stage ring (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip)
 
     @staticmethod
     def _tune_key(d: GemmDesc) -> str:
@@ -192,10 +192,10 @@ class Engine:
         if key in table and not (challengers and key not in self._retuned):                       # against each shape's incumbent
             return table[key]
         best, best_ms = 0, float("inf")
-        cands = (1, 2, 5, 6, 7, 8, 9, 12) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
+        cands = (1, 2, 5, 6, 7, 8, 9, 12, 16, 19) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
         if key in table:
             self._retuned.add(key)
-            cands = [table[key]] + [c for c in challengers if c != table[key] and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12))]
+            cands = [table[key]] + [c for c in challengers if c != table[key] and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19))]
         if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         e0, e1 = self.event(), self.event()

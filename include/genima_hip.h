@@ -74,7 +74,8 @@ typedef struct gn_gemm_desc {
   int32_t splitk;         /* 0 = library heuristic, >=1 explicit */
   int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} register-staged block tile,
                              7..14 = {256x256, 256x128, 128x128, 128x64, 64x64, 256x64, 128x320, 256x320} LDS-DMA block tile,
-                             15 = 256x256 ping-pong (8-phase, counted vmcnt; K % 64 == 0, conv C1/C2 % 64 == 0, no GEGLU / batch)
+                             15 = 256x256 ping-pong (8-phase, counted vmcnt; K % 64 == 0, conv C1/C2 % 64 == 0, no GEGLU / batch),
+                             16..19 = {128x128, 128x64, 64x64, 256x64} with a 3-stage LDS-DMA ring (two K tiles in flight, counted vmcnt)
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */
