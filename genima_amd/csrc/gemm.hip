@@ -24,7 +24,7 @@
 namespace {
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams pin) {
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 128, WM* WN)) void gemm_kernel(const GemmParams pin) {
   const GemmParams p = batch_offset(pin);
   constexpr int NT = WM * WN * 64;
   constexpr int RPP = NT / 8;  // tile rows staged per pass (8 lanes x 16 B cover one 128-byte row)
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(const GemmParams pin)
 // costs nothing.  Freed registers allow 128x64 wave tiles (256x256 block, 8 waves).
 
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams pin) {
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 128, WM* WN)) void gemm_dma_kernel(const GemmParams pin) {
   const GemmParams p = batch_offset(pin);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -393,7 +393,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams 
     cur ^= 1;
   }
 
-  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+  // registers: accumulators + every bias vector + two bands of shift / residual vectors + working set, against this occupancy's budget
+  constexpr bool RICH = TM * TN * 16 + TN * 8 * 3 + 96 <= 512 / gemm_waves_per_simd(2 * (A_BYTES + B_BYTES), NW);
+  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
 }
 
 // ======================================================================================================================
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_dma_kernel(const GemmParams 
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_fp8_kernel(const GemmParams p) {
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 128, WM* WN)) void gemm_fp8_kernel(const GemmParams p) {
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -579,8 +581,14 @@ constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, fa
                         // ping-pong 256x256 (gemm_pp.hip): counted-vmcnt 8-phase K loop
                         {256, 256, 0.0, false, true},
                         // 3-stage LDS-DMA ring (gemm_s3.hip): two K tiles in flight, counted vmcnt -- the latency-bound mid-size launches
-                        {128, 128, 0.0, true, true},   {128, 64, 0.0, false, true},   {64, 64, 0.0, false, true},    {256, 64, 0.0, true, true}};
-constexpr int kNumCfg = 19;
+                        {128, 128, 0.0, true, true},   {128, 64, 0.0, false, true},   {64, 64, 0.0, false, true},    {256, 64, 0.0, true, true},
+                        // exact-fit ring tiles: N = 640 / 1280 / 320 problems whose 128x64 / 128x128 grids leave the 256 CUs 1.25 .. 2.5
+                        // workgroups each (the K loop of those launches is bound by L2 -> LDS bytes per CU: bigger tile, fewer bytes)
+                        {128, 160, 0.0, false, true},  {64, 160, 0.0, false, true},   {64, 320, 0.0, false, true},
+                        // 2-stage 128x160 (two workgroups per CU)
+                        {128, 160, 0.0, false, true}};
+constexpr int kNumCfg = 23;
+constexpr int kCfgS3End = 22;  // one past the last 3-stage configuration
 constexpr int kCfgPP = 14;
 constexpr int kCfgS3 = 15;  // first of the four 3-stage configurations
 
@@ -650,7 +658,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (geglu && !kCfg[best].geglu) best = 1;
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
-    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4};
+    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1};
     best = fallback[best];
   }
   pl.cfg = best;
@@ -766,7 +774,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     p.sa = (const float*)d->scale_a; p.sw = (const float*)d->scale_w;
     p.a_bytes = (unsigned)((uint64_t)d->M * d->lda); p.w_bytes = (unsigned)((uint64_t)d->N * d->ldw);
     p.splitk = 1; p.kper = (int)d->K;
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11, 8, 9, 9, 8};
     const int cfg = to_dma[pl.cfg];
     const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
     p.tiles_m = (int)cdiv64(d->M, bm); p.tiles_n = (int)cdiv64(d->N, bn);
@@ -798,6 +806,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 12: launch_dma<128, 320, 2, 2>(p, conv, ctx->stream); break;
     case 13: launch_dma<256, 320, 4, 2>(p, conv, ctx->stream); break;
     case 14: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, 1, ctx->stream); break;
+    case 22: launch_dma<128, 160, 4, 1>(p, conv, ctx->stream); break;
     default: gn_launch_gemm_s3(&p, pl.cfg - kCfgS3, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;
   }
   GN_LAUNCH_CHECK();

@@ -3,6 +3,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -103,27 +105,6 @@ __device__ __forceinline__ void epilogue_vals4(const GemmParams& p, int m, int n
   }
 }
 
-// Row-major f16 output, 16 bytes per lane.  The MFMA layout leaves a lane with channels 8g + 4hi + (0..3) of its row: 8-byte
-// pieces, and the write path is issue-bound on those (removing the stores took 8 % (K = 1280) to 26 % (K = 320) off the Linear
-// launches).  Lanes l and l + 32 hold the same row, so one v_permlane32_swap per dword trades group g of the upper half against
-// group g + 1 of the lower half: afterwards the lower lane owns channels 8g .. 8g + 7 and the upper lane 8(g+1) .. 8(g+1) + 7.
-__device__ __forceinline__ void epilogue_store8_pair(const GemmParams& p, int m, int nb8, int hi, const float* a, const float* b) {
-  // a: this lane's 4 values of group g (channels nb8 + 4 hi ..), b: of group g + 1 (channels nb8 + 8 + 4 hi ..)
-  float va[4] = {a[0], a[1], a[2], a[3]}, vb[4] = {b[0], b[1], b[2], b[3]};
-  int bidx;
-  if (nb8 + 4 * hi < p.N) epilogue_vals4(p, m, nb8 + 4 * hi, va, bidx);
-  if (nb8 + 8 + 4 * hi < p.N) epilogue_vals4(p, m, nb8 + 8 + 4 * hi, vb, bidx);
-  f16x4 ha, hb;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { ha[i] = (f16)va[i]; hb[i] = (f16)vb[i]; }
-  uint2 ua = *reinterpret_cast<uint2*>(&ha), ub = *reinterpret_cast<uint2*>(&hb);
-  const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
-  const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-  const uint4 o = make_uint4(r0[0], r1[0], r0[1], r1[1]);
-  const int col = nb8 + 8 * hi;
-  if (col < p.N) *reinterpret_cast<uint4*>(p.out + (long)m * p.ldo + col) = o;
-}
-
 __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int nb, float v0, float v1, float v2, float v3) {
   float v[4] = {v0, v1, v2, v3};
   int bidx;
@@ -146,35 +127,227 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
   }
 }
 
-// GEGLU: 4 consecutive packed hidden rows at nh and the matching gate rows at ng -> 4 output columns at oc.
-__device__ __forceinline__ void epilogue_geglu4(const GemmParams& p, int m, int nh, int ng, int oc, const float* h,
-                                                const float* g) {
-  float hv[4], gv[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { hv[i] = h[i]; gv[i] = g[i]; }
-  if (p.bias) {
-    f16x4 bh = *reinterpret_cast<const f16x4*>(p.bias + nh);
-    f16x4 bg = *reinterpret_cast<const f16x4*>(p.bias + ng);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { hv[i] += (float)bh[i]; gv[i] += (float)bg[i]; }
+// ---- wave-level epilogue: the lane holds D[n = 8g + 4hi + (r&3)][m = lane&31] of each 32x32 tile ----------------------------
+// The epilogue of a K = 320..1280 launch is a visible share of its time and it is LATENCY-bound when written store by store:
+// a load that follows a store cannot be hoisted over it (may alias), and gfx9's single vmcnt retires loads and stores in order,
+// so "load bias/residual -> wait -> store" per 8 channels costs one memory round trip each (tools/probes/gemm_ksweep.py: the
+// K -> 0 intercept of a 128x64 tile launch was 8.8 us against a 4.3 us store-only kernel; 27 us for the 128x320 tile).  The f16
+// row-major path therefore batches: every bias vector up front, then per 32-row band all shift / residual vectors of the NEXT band
+// are requested before the current band's stores are issued.
+
+// compile-time loop: indices are template constants whatever the unroller's size thresholds decide (a `#pragma unroll` loop whose
+// unrolled body passes -pragma-unroll-threshold stays a loop, and ONE dynamic index sends the whole accumulator array to scratch)
+template <int N>
+struct static_for {
+  template <class F>
+  __device__ __forceinline__ static void run(F&& f) {
+    static_for<N - 1>::run(f);
+    f(std::integral_constant<int, N - 1>{});
   }
-  f16x4 o;
+};
+template <>
+struct static_for<0> {
+  template <class F>
+  __device__ __forceinline__ static void run(F&&) {}
+};
+
+// One 32x32 tile at a time: its 16 values go through whole-tile passes (bias / shift / residual / activation / scale: one
+// wave-uniform branch per pass instead of one per 4 channels -- the activation switch inside the store loop compiled to a thicket
+// of ~10 branches per 4 channels), then its stores are issued back to back.
+__device__ __forceinline__ void epilogue_tile_math(const GemmParams& p, float (&v)[16], const f16x4 (&b)[4], const f16x4 (&a)[4],
+                                                   const f16x4 (&r)[4], bool add_a_pre, bool add_r_pre, bool add_a_post, bool add_r_post) {
+  if (p.bias) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (f16)(hv[i] * gelu_fast(gv[i]));
-  *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + oc) = o;
+    for (int e = 0; e < 16; ++e) v[e] += (float)b[e >> 2][e & 3];
+  }
+  if (add_a_pre) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += (float)a[e >> 2][e & 3];
+  }
+  if (add_r_pre) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += (float)r[e >> 2][e & 3];
+  }
+  switch (p.act) {
+    case GN_ACT_SILU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = act_silu(v[e]);
+      break;
+    case GN_ACT_GELU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = gelu_fast(v[e]);
+      break;
+    case GN_ACT_QUICK_GELU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = act_quick_gelu(v[e]);
+      break;
+    case GN_ACT_RELU:
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = fmaxf(v[e], 0.0f);
+      break;
+    default: break;
+  }
+  if (p.out_scale != 1.0f) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] *= p.out_scale;
+  }
+  if (add_a_post) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += (float)a[e >> 2][e & 3];
+  }
+  if (add_r_post) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v[e] += (float)r[e >> 2][e & 3];
+  }
 }
 
-// ---- wave-level epilogue: the lane holds D[n = 8g + 4hi + (r&3)][m = lane&31] of each 32x32 tile ----------------------------
-template <int TM, int TN>
+// RICH (registers to spare: small wave tiles, or one wave per SIMD): every bias vector up front and the shift / residual vectors of
+// the NEXT 32-row band requested before the current band's stores.  Otherwise the vectors are fetched tile by tile.
+template <int TM, int TN, bool RICH>
+__device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31,
+                                                     int hi) {
+  constexpr bool PIPE = RICH && TM * TN <= 8;
+  const bool has_shift = p.shift != nullptr, has_res = p.res != nullptr;
+  const bool both = has_shift && has_res;  // rare: the residual is then read tile by tile
+  const bool aux_is_res = has_res && !has_shift;
+  const bool a_pre = has_shift || (aux_is_res && p.res_first), a_post = aux_is_res && !p.res_first;
+  const bool r_pre = both && p.res_first, r_post = both && !p.res_first;
+  const f16x4 zero = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+  f16x4 bv[RICH ? TN : 1][4];
+  auto load_bias = [&](int j, f16x4 (&b)[4]) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+      b[g] = (p.bias && nb < p.N) ? *reinterpret_cast<const f16x4*>(p.bias + nb) : zero;
+    }
+  };
+  if (RICH) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) load_bias(j, bv[RICH ? j : 0]);
+  }
+  f16x4 ax[PIPE ? 2 : 1][RICH ? TN : 1][4];
+  auto load_aux1 = [&](int i, int j, f16x4 (&a)[4]) {
+    const int m = mbase + i * 32 + l31;
+    const f16* row = nullptr;
+    if (m < p.M) row = aux_is_res ? p.res + (long)m * p.ldr : p.shift + (long)(m / p.rpb) * p.ldshift;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+      a[g] = (row && nb < p.N) ? *reinterpret_cast<const f16x4*>(row + nb) : zero;
+    }
+  };
+  auto load_aux = [&](int i, f16x4 (&a)[RICH ? TN : 1][4]) {
+    const int m = mbase + i * 32 + l31;
+    const f16* row = nullptr;
+    if (m < p.M) row = aux_is_res ? p.res + (long)m * p.ldr : p.shift + (long)(m / p.rpb) * p.ldshift;
+#pragma unroll
+    for (int j = 0; j < (RICH ? TN : 1); ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+        a[j][g] = (row && nb < p.N) ? *reinterpret_cast<const f16x4*>(row + nb) : zero;
+      }
+  };
+  const bool wide = p.out_mode == GN_OUT_ROWMAJOR && (p.ldo & 7) == 0 && (p.N & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
+  if (PIPE && (has_shift || has_res)) load_aux(0, ax[0]);
+  static_for<TM>::run([&](auto I) {
+    constexpr int i = decltype(I)::value;
+    constexpr int kOne = PIPE ? 1 : 0;
+    if (has_shift || has_res) {
+      if (PIPE) { if (i + 1 < TM) load_aux(i + 1, ax[(i + 1) & kOne]); }
+      else if (RICH) load_aux(i, ax[0]);
+    }
+    const int m = mbase + i * 32 + l31;
+    const bool mok = m < p.M;
+    const int bidx = p.out_mode == GN_OUT_BATCH_TRANSPOSED ? m / p.rpb : 0;
+    static_for<TN>::run([&](auto J) {
+      constexpr int j = decltype(J)::value;
+      float v[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e];
+      f16x4 rr[4] = {zero, zero, zero, zero};
+      if (both && mok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N) rr[g] = *reinterpret_cast<const f16x4*>(p.res + (long)m * p.ldr + nb);
+        }
+      }
+      if (!RICH) {
+        load_bias(j, bv[0]);
+        if (has_shift || has_res) load_aux1(i, j, ax[0][0]);
+      }
+      epilogue_tile_math(p, v, bv[RICH ? j : 0], ax[i & kOne][RICH ? j : 0], rr, a_pre, r_pre, a_post, r_post);
+      if (!mok) return;
+      if (wide) {
+        // lanes l and l + 32 hold the same row: one v_permlane32_swap per dword trades group g of the upper half against group
+        // g + 1 of the lower half; afterwards the lower lane owns channels 8g .. 8g+7 and the upper lane 8(g+1) .. 8(g+1)+7,
+        // a 16-byte store each (the write path is issue-bound on 8-byte pieces)
+        f16* orow = p.out + (long)m * p.ldo;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          f16x4 ha, hb;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { ha[e] = (f16)v[4 * g + e]; hb[e] = (f16)v[4 * g + 4 + e]; }
+          const uint2 ua = *reinterpret_cast<const uint2*>(&ha), ub = *reinterpret_cast<const uint2*>(&hb);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+          const int col = nbase + j * 32 + 8 * g + 8 * hi;
+          if (col < p.N) *reinterpret_cast<uint4*>(orow + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      } else if (p.out_mode == GN_OUT_ROWMAJOR) {
+        f16* orow = p.out + (long)m * p.ldo;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          f16x4 h;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) h[e] = (f16)v[4 * g + e];
+          if (nb < p.N) *reinterpret_cast<f16x4*>(orow + nb) = h;
+        }
+      } else if (p.out_mode == GN_OUT_F32) {  // f32 result (weight gradients: fp32 like the reference's master grads)
+        float* orow = reinterpret_cast<float*>(p.out) + (long)m * p.ldo;
+        if (p.accumulate) {
+          f32x4 old[4];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+            const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            old[g] = nb < p.N ? *reinterpret_cast<const f32x4*>(orow + nb) : z4;
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += old[e >> 2][e & 3];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+          if (nb < p.N) *reinterpret_cast<f32x4*>(orow + nb) = o;
+        }
+      } else {  // GN_OUT_BATCH_TRANSPOSED: out[b][n][m - b * rpb]
+        const int ml = m - bidx * p.rpb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N) {
+            f16* o = p.out + ((long)bidx * p.N + nb) * p.ldo + ml;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(long)e * p.ldo] = (f16)v[4 * g + e];
+          }
+        }
+      }
+    });
+  });
+}
+
+template <int TM, int TN, bool RICH = (TM * TN <= 4)>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi,
                                               int z) {
-  // plain f16 rows whose 8-channel groups are 16-byte aligned take the paired 16-byte stores
-  const bool wide = p.out_mode == GN_OUT_ROWMAJOR && (p.ldo & 7) == 0 && (p.N & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
+  if (p.splitk > 1) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int m = mbase + i * 32 + l31;
-    if (m >= p.M) continue;
-    if (p.splitk > 1) {
+    for (int i = 0; i < TM; ++i) {
+      const int m = mbase + i * 32 + l31;
+      if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -185,8 +358,24 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             *reinterpret_cast<f32x4*>(p.ws + ((long)z * p.M + m) * p.N + nb) = v;
           }
         }
-    } else if (p.act == GN_ACT_GEGLU) {
-      if constexpr (TN % 2 == 0) {
+    }
+  } else if (p.act == GN_ACT_GEGLU) {
+    if constexpr (TN % 2 == 0) {
+      const f16x4 zero = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+      f16x4 bh[TN / 2][4], bg[TN / 2][4];
+#pragma unroll
+      for (int j = 0; j < TN; j += 2)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nh = nbase + j * 32 + 8 * g + 4 * hi;
+          const bool ok = p.bias && nh + 32 < p.N;
+          bh[j / 2][g] = ok ? *reinterpret_cast<const f16x4*>(p.bias + nh) : zero;
+          bg[j / 2][g] = ok ? *reinterpret_cast<const f16x4*>(p.bias + nh + 32) : zero;
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int m = mbase + i * 32 + l31;
+        if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; j += 2)
 #pragma unroll
@@ -194,40 +383,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
             const int nh = nbase + j * 32 + 8 * g + 4 * hi;
             if (nh + 32 < p.N) {
               const int oc = ((nbase + j * 32) >> 1) + 8 * g + 4 * hi;
-              float h[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-              float gg[4] = {acc[j + 1][i][4 * g], acc[j + 1][i][4 * g + 1], acc[j + 1][i][4 * g + 2],
-                             acc[j + 1][i][4 * g + 3]};
-              epilogue_geglu4(p, m, nh, nh + 32, oc, h, gg);
+              f16x4 o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                o[e] = (f16)((acc[j][i][4 * g + e] + (float)bh[j / 2][g][e]) * gelu_fast(acc[j + 1][i][4 * g + e] + (float)bg[j / 2][g][e]));
+              *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + oc) = o;
             }
           }
       }
-    } else if (wide) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          const int nb8 = nbase + j * 32 + 8 * g;
-          if (nb8 < p.N) {  // wave-uniform
-            const float a[4] = {acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
-            const float b[4] = {acc[j][i][4 * g + 4], acc[j][i][4 * g + 5], acc[j][i][4 * g + 6], acc[j][i][4 * g + 7]};
-            epilogue_store8_pair(p, m, nb8, hi, a, b);
-          }
-        }
-    } else {
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
-          if (nb < p.N)
-            epilogue_store4(p, m, nb, acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]);
-        }
     }
+  } else {
+    gemm_epilogue_direct<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi);
   }
 }
 
 // LDS-DMA (`buffer_load_dwordx4 ... lds`) plumbing shared by the DMA-staged kernels
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
+// waves per SIMD a tile kernel reaches when LDS is the only limit (160 KB per CU): passed to __launch_bounds__ so that the register
+// allocator keeps the (load-batching, hence register-hungry) epilogue inside the budget of that occupancy
+constexpr int gemm_waves_per_simd(int lds_bytes, int waves_per_block) {
+  const int blocks = 160 * 1024 / lds_bytes;
+  const int w = blocks * waves_per_block / 4;
+  return w < 1 ? 1 : (w > 4 ? 4 : w);
+}
 constexpr unsigned kOOB = 0xFFFFFFF0u;  // out-of-range buffer offset: the hardware writes zeros to LDS for such lanes
 
 }  // namespace

@@ -7,8 +7,19 @@
 
 namespace {
 
+// s_waitcnt takes an immediate: one asm statement per count
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 1 && N <= 16, "DMA instructions per wave per K tile");
+#define GN_VMCNT_CASE(n) if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory");
+  GN_VMCNT_CASE(1) GN_VMCNT_CASE(2) GN_VMCNT_CASE(3) GN_VMCNT_CASE(4) GN_VMCNT_CASE(5) GN_VMCNT_CASE(6) GN_VMCNT_CASE(7) GN_VMCNT_CASE(8)
+  GN_VMCNT_CASE(9) GN_VMCNT_CASE(10) GN_VMCNT_CASE(11) GN_VMCNT_CASE(12) GN_VMCNT_CASE(13) GN_VMCNT_CASE(14) GN_VMCNT_CASE(15)
+  GN_VMCNT_CASE(16)
+#undef GN_VMCNT_CASE
+}
+
 template <int BM, int BN, int WM, int WN, bool CONV>
-__global__ __launch_bounds__(WM* WN * 64) void gemm_s3_kernel(const GemmParams pin) {
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 128, WM* WN)) void gemm_s3_kernel(const GemmParams pin) {
   const GemmParams p = batch_offset(pin);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -160,13 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_s3_kernel(const GemmParams p
   constexpr int NIN = GA + GB;  // DMA instructions per wave per tile
   dma_tile(0);
   dma_tile(1);  // past the last K tile the offsets are out of range: zero fill, no fetch -- the count stays the same on every path
-  if constexpr (NIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (NIN == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (NIN == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (NIN == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (NIN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (NIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_vmcnt<NIN>();
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
@@ -193,20 +198,15 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_s3_kernel(const GemmParams p
           acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (NIN == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (NIN == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if constexpr (NIN == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (NIN == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if constexpr (NIN == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (NIN == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_vmcnt<NIN>();
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     cur = cur == 2 ? 0 : cur + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead zero fills
 
-  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+  constexpr bool RICH = TM * TN * 16 + TN * 8 * 3 + 96 <= 512 / gemm_waves_per_simd(3 * (A_BYTES + B_BYTES), NW);
+  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -226,6 +226,10 @@ void gn_launch_gemm_s3(const void* params, int cfg, bool conv, int grid_x, int g
     case 0: launch_s3<128, 128, 2, 2>(p, conv, grid, st); break;
     case 1: launch_s3<128, 64, 2, 2>(p, conv, grid, st); break;
     case 2: launch_s3<64, 64, 2, 2>(p, conv, grid, st); break;
-    default: launch_s3<256, 64, 4, 1>(p, conv, grid, st); break;
+    case 3: launch_s3<256, 64, 4, 1>(p, conv, grid, st); break;
+    // exact-fit tiles: N = 640 / 1280 / 320 problems whose 128x64 or 128x128 grids leave 256 CUs with 1.25 .. 2.5 workgroups each
+    case 4: launch_s3<128, 160, 4, 1>(p, conv, grid, st); break;
+    case 5: launch_s3<64, 160, 2, 1>(p, conv, grid, st); break;
+    default: launch_s3<64, 320, 2, 2>(p, conv, grid, st); break;
   }
 }

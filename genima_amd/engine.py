@@ -171,7 +171,7 @@ class Engine:
     # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
     # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
     _retuned = set()  # shapes already re-raced in this process (GN_RETUNE)
-    N_TILE_CFGS = 19  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..19 3-stage ring (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip)
+    N_TILE_CFGS = 23  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..22 3-stage ring, 23 2-stage 128x160 (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip)
 
     @staticmethod
     def _tune_key(d: GemmDesc) -> str:

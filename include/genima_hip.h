@@ -75,7 +75,9 @@ typedef struct gn_gemm_desc {
   int32_t tile;           /* 0 = library heuristic; 1..6 = {256x128, 128x128, 128x64, 64x64, 256x64, 128x256} register-staged block tile,
                              7..14 = {256x256, 256x128, 128x128, 128x64, 64x64, 256x64, 128x320, 256x320} LDS-DMA block tile,
                              15 = 256x256 ping-pong (8-phase, counted vmcnt; K % 64 == 0, conv C1/C2 % 64 == 0, no GEGLU / batch),
-                             16..19 = {128x128, 128x64, 64x64, 256x64} with a 3-stage LDS-DMA ring (two K tiles in flight, counted vmcnt)
+                             16..22 = {128x128, 128x64, 64x64, 256x64, 128x160, 64x160, 64x320} with a 3-stage LDS-DMA ring (two K tiles
+                             in flight, counted vmcnt); 20..22 are the exact-fit tiles of the N = 640 / 1280 / 320 launches,
+                             23 = 128x160 two-stage LDS-DMA
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */

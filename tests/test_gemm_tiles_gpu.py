@@ -1,0 +1,87 @@
+"""-m gpu: EVERY block-tile configuration of gn_gemm (gn_gemm_desc::tile 1..23: register-staged, LDS-DMA, ping-pong, 3-stage ring,
+exact-fit) through EVERY epilogue mode -- bias, per-batch time shift, residual before / after the activation, activation, output
+scale, narrow (N % 8 != 0) rows, f32 output with accumulation, batch-transposed output -- against an fp32 torch restatement on the
+same f16-rounded inputs.  The engine's autotuner only ever runs the per-shape winner, so without this test a tile whose epilogue
+variant is wrong shows up as a NaN three subsystems later (the fused epilogue is shared: csrc/gemm_common.h).
+Reference ops: diffusers' ResnetBlock2D / Attention / FeedForward Linear + conv call sites."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import assert_close, randn_h
+
+pytestmark = pytest.mark.gpu
+
+N_TILES = 23
+
+
+@pytest.fixture()
+def tile_override(engine):
+    yield lambda t: engine.lib.gn_set_gemm_tile_override(t - 1)
+    engine.lib.gn_set_gemm_tile_override(-1)
+
+
+@pytest.fixture()
+def eng(engine):
+    old, old_auto = getattr(engine, "no_table", False), engine.autotune
+    engine.no_table, engine.autotune = True, False  # the override decides, not the tune table / the autotuner
+    yield engine
+    engine.no_table, engine.autotune = old, old_auto
+
+
+ACTS = {0: lambda v: v, 1: F.silu, 2: F.gelu, 4: F.relu}
+
+
+@pytest.mark.parametrize("tile", range(1, N_TILES + 1))
+def test_linear_epilogues_every_tile(eng, tile_override, tile):
+    tile_override(tile)
+    # ragged M (row tail inside a 32-row band), N = 5 x 64 + 8 (column tail inside a 32-column tile), K = 3 tiles
+    for (M, N, K) in ((1000, 328, 192), (300, 76, 128)):  # 76: N % 8 != 0 -> the 8-byte store path
+        x, w, b = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5), randn_h(N, seed=3, scale=0.3)
+        r = randn_h(M, N, seed=4)
+        xf, wf, bf, rf = x.float().cpu(), w.float().cpu(), b.float().cpu(), r.float().cpu()
+        base = xf @ wf.t()
+        for act in (0, 1, 2, 4):
+            y = eng.linear(x, w, b, act=act, residual=r)
+            assert_close(y, ACTS[act](base + bf) + rf, what=f"tile {tile} linear {M}x{N}x{K} act {act} +res")
+        y = eng.linear(x, w, None)
+        assert_close(y, base, what=f"tile {tile} linear {M}x{N}x{K} plain")
+
+
+@pytest.mark.parametrize("tile", range(1, N_TILES + 1))
+def test_conv_epilogues_every_tile(eng, tile_override, tile):
+    tile_override(tile)
+    B, H, W, Cin, Cout = 3, 12, 20, 64, 136
+    x, w, b = randn_h(B, H, W, Cin, seed=5), randn_h(Cout, 9 * Cin, seed=6, scale=(9 * Cin) ** -0.5), randn_h(Cout, seed=7, scale=0.3)
+    shift, res = randn_h(B, Cout, seed=8), randn_h(B, H, W, Cout, seed=9)
+    wt = w.float().cpu().view(Cout, 3, 3, Cin).permute(0, 3, 1, 2)
+    conv = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), wt, b.float().cpu(), padding=1).permute(0, 2, 3, 1)
+    sf, rf = shift.float().cpu()[:, None, None, :], res.float().cpu()
+    y = eng.conv2d(x, w, b, shift=shift)                                  # ResnetBlock2D conv1 + time embedding
+    assert_close(y, conv + sf, what=f"tile {tile} conv +shift")
+    y = eng.conv2d(x, w, b, residual=res, out_scale=0.5)                   # conv2 + skip, output_scale_factor
+    assert_close(y, conv * 0.5 + rf, what=f"tile {tile} conv scale +res")
+    y = eng.conv2d(x, w, b, residual=res, act=4, residual_before_act=True)  # ResNet basic block: relu(conv + identity)
+    assert_close(y, F.relu(conv + rf), what=f"tile {tile} conv relu(conv+res)")
+    y = eng.conv2d(x, w, b, shift=shift, residual=res, act=1)               # both vectors at once (the tile-by-tile residual path)
+    assert_close(y, F.silu(conv + sf) + rf, what=f"tile {tile} conv +shift silu +res")
+
+
+@pytest.mark.parametrize("tile", range(1, N_TILES + 1))
+def test_f32_accumulate_and_transposed_every_tile(eng, tile_override, tile):
+    from genima_amd import train_ops as T
+
+    tile_override(tile)
+    M, N, K = 200, 136, 128
+    a, w = randn_h(M, K, seed=10), randn_h(N, K, seed=11, scale=K ** -0.5)
+    ref = a.float().cpu() @ w.float().cpu().t()
+    out = torch.full((M, N), 0.25, device="cuda", dtype=torch.float32)
+    T.gemm(eng, a, w, out, M, N, K, K, K, N, f32_out=True, accumulate=True)
+    T.gemm(eng, a, w, out, M, N, K, K, K, N, f32_out=True, accumulate=True)
+    assert_close(out, 2 * ref + 0.25, what=f"tile {tile} f32 accumulate")
+    # batch-transposed output (V^T for the attention kernel): y[b, n, m_local], row stride pad_cols
+    Bn, rows, pad = 2, 100, 104
+    b = randn_h(N, seed=12, scale=0.3)
+    y = eng.linear(a.view(Bn, rows, K), w, b, transposed_out=True, rows_per_batch=rows, pad_cols=pad)
+    want = (ref + b.float().cpu()).view(Bn, rows, N).permute(0, 2, 1)
+    assert_close(y.view(Bn, N, pad)[:, :, :rows], want, what=f"tile {tile} transposed")
