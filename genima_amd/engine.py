@@ -185,22 +185,28 @@ class Engine:
             key += "|fp8"
         return key
 
-    def _autotune(self, d: GemmDesc, key: Optional[str] = None):
+    @staticmethod
+    def apply_plan(d: GemmDesc, plan: int):
+        """A tune-table value is ``tile + 100 * splitk`` (splitk 0 = the library's heuristic for that tile)."""
+        d.tile, d.splitk = int(plan) % 100, int(plan) // 100
+
+    def _autotune(self, d: GemmDesc, key: Optional[str] = None) -> int:
+        """-> the plan (``tile + 100 * splitk``) of this problem: from the table, or measured now and remembered."""
         key = key or self._tune_key(d)
         table = _tune_table()
         challengers = [int(c) for c in os.environ.get("GN_RETUNE", "").split(",") if c.strip()]  # e.g. GN_RETUNE=15: race new tiles
         if key in table and not (challengers and key not in self._retuned):                       # against each shape's incumbent
             return table[key]
-        best, best_ms = 0, float("inf")
         cands = (1, 2, 5, 6, 7, 8, 9, 12, 16, 19) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
         if key in table:
             self._retuned.add(key)
-            cands = [table[key]] + [c for c in challengers if c != table[key] and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19))]
+            cands = [table[key]] + [c for c in challengers if c != table[key] % 100 and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19))]
         if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         e0, e1 = self.event(), self.event()
-        for c in cands:
-            d.tile = c
+
+        def race(plan: int) -> float:
+            self.apply_plan(d, plan)
             nb = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
             d.workspace = self._workspace(nb).data_ptr() if nb > 0 else None
             check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm(autotune)")
@@ -211,8 +217,23 @@ class Engine:
                     check(self.lib.gn_gemm(self._ctx, C.byref(d)), "gn_gemm(autotune)")
                 self.event_record(e1)
                 ms = min(ms, self.event_elapsed_ms(e0, e1))
+            return ms
+
+        best, best_ms = 0, float("inf")
+        for c in cands:
+            ms = race(c)
             if ms < best_ms:
                 best, best_ms = c, ms
+        # K splits of the winning tile: the library's heuristic aims at ~1.5 workgroups per CU; for the long-K, few-tile launches (the
+        # 16x16 / 8x8 latent levels) the right count is whatever makes the grid a multiple of the 256 CUs.  3 % margin against noise.
+        if best < 100 and d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8:
+            tile = best
+            for sk in (1, 2, 3, 4, 6, 8):
+                if sk * 512 > d.K:
+                    break
+                ms = race(tile + 100 * sk)
+                if ms < 0.97 * best_ms:
+                    best, best_ms = tile + 100 * sk, ms
         self.lib.gn_event_destroy(e0)
         self.lib.gn_event_destroy(e1)
         table[key] = best
@@ -222,7 +243,7 @@ class Engine:
     def _gemm(self, d: GemmDesc, keep):
         if d.tile == 0 and d.splitk == 0:
             # autotuning engines measure unknown shapes; every engine uses a tile that was already measured on this architecture
-            d.tile = self._autotune(d) if self.autotune else (0 if getattr(self, "no_table", False) else _tune_table().get(self._tune_key(d), 0))
+            self.apply_plan(d, self._autotune(d) if self.autotune else (0 if getattr(self, "no_table", False) else _tune_table().get(self._tune_key(d), 0)))
         ws_bytes = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
         ws = None
         if ws_bytes > 0:

@@ -36,10 +36,10 @@ def gemm(E: Engine, a, w, out, M: int, N: int, K: int, lda: int, ldw: int, ldo: 
         d.w_bs, d.w_bs2 = w_bs
         d.out_bs, d.out_bs2 = out_bs
     if E.autotune:
-        d.tile = _tuned_tile(E, d, out)
+        E.apply_plan(d, _tuned_tile(E, d, out))
     else:
         from .engine import _tune_table
-        d.tile = _tune_table().get(E._tune_key(d), 0)
+        E.apply_plan(d, _tune_table().get(E._tune_key(d), 0))
     nb = int(E.lib.gn_gemm_workspace_bytes(C.byref(d)))
     if nb > 0:
         d.workspace = E._workspace(nb).data_ptr()

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from genima_amd.engine import Engine  # noqa: E402
 
 E = Engine("cuda:0")
-for b, hw, c in [(8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (8, 64, 1280), (8, 4096, 640), (8, 1024, 1280), (8, 16384, 512), (8, 262144, 128)]:
+for b, hw, c in [(8, 4096, 320), (8, 1024, 640), (8, 256, 1280), (8, 64, 1280), (8, 4096, 640), (8, 1024, 1280), (8, 1024, 1920), (8, 256, 2560), (1, 1024, 320), (1, 4096, 320), (8, 16384, 512), (8, 262144, 128)]:
     side = int(hw ** 0.5)
     x = torch.randn(b, side, side, c, device="cuda").half()
     g, bt = torch.ones(c, device="cuda").half(), torch.zeros(c, device="cuda").half()
