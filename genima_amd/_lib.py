@@ -35,6 +35,7 @@ class GemmDesc(C.Structure):
         ("a_bs", C.c_int64), ("a_bs2", C.c_int64), ("w_bs", C.c_int64), ("w_bs2", C.c_int64),
         ("out_bs", C.c_int64), ("out_bs2", C.c_int64), ("res_bs", C.c_int64), ("res_bs2", C.c_int64),
         ("accumulate", C.c_int32), ("fp8", C.c_int32), ("scale_a", C.c_void_p), ("scale_w", C.c_void_p),
+        ("out2", C.c_void_p), ("ldo2", C.c_int64), ("split_n", C.c_int32),
     ]
 
 

@@ -680,7 +680,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
       if (sk < 1) sk = 1;
     }
   }
-  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8) sk = 1;
+  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8 || d->out2) sk = 1;
   int kper = (int)(cdiv64(cdiv64(K, sk), BK) * BK);
   sk = (int)cdiv64(K, kper);
   pl.splitk = sk;
@@ -727,6 +727,13 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.act = d->act; p.out_mode = d->out_mode; p.res_first = d->residual_before_act;
   p.accumulate = d->accumulate;
   p.sa = nullptr; p.sw = nullptr;
+  p.out2 = (f16*)d->out2; p.ldo2 = d->ldo2; p.split_n = d->split_n;
+  if (d->out2) {
+    GN_REQUIRE(d->out_mode == GN_OUT_ROWMAJOR && !geglu && d->batch <= 1 && !d->fp8, "gn_gemm: out2 needs a plain row-major f16 problem");
+    GN_REQUIRE(d->split_n > 0 && d->split_n < d->N && d->split_n % 32 == 0, "gn_gemm: split_n (%d) must be a multiple of 32 inside (0, N)", d->split_n);
+    GN_REQUIRE(d->rows_per_batch > 0 && d->M % d->rows_per_batch == 0 && d->ldo2 >= d->rows_per_batch, "gn_gemm: out2 needs rows_per_batch | M and ldo2 >= rows_per_batch");
+    GN_REQUIRE(d->N % 8 == 0 && d->ldo % 8 == 0 && ((uintptr_t)d->out & 15) == 0, "gn_gemm: out2 needs the 16-byte row-major store path for out");
+  }
   p.nbatch = d->batch > 1 ? d->batch : 0;
   p.binner = p.nbatch ? (d->batch_inner > 0 ? d->batch_inner : 1) : 0;
   p.a_bs = d->a_bs; p.a_bs2 = d->a_bs2; p.w_bs = d->w_bs; p.w_bs2 = d->w_bs2;

@@ -33,6 +33,9 @@ struct GemmParams {
   long a_bs, a_bs2, w_bs, w_bs2, o_bs, o_bs2, r_bs, r_bs2;  // batch strides (elements; o_* in output elements)
   const float* sa;                       // fp8: per-row scales of A [M]
   const float* sw;                       // fp8: per-row scales of W [N]
+  f16* out2;                             // two-destination output: columns >= split_n go here, batch-transposed (row stride ldo2)
+  long ldo2;
+  int split_n;
 };
 
 // batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
@@ -259,7 +262,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
     }
     const int m = mbase + i * 32 + l31;
     const bool mok = m < p.M;
-    const int bidx = p.out_mode == GN_OUT_BATCH_TRANSPOSED ? m / p.rpb : 0;
+    const int bidx = (p.out_mode == GN_OUT_BATCH_TRANSPOSED || p.out2) ? m / p.rpb : 0;
     static_for<TN>::run([&](auto J) {
       constexpr int j = decltype(J)::value;
       float v[16];
@@ -279,7 +282,18 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
       }
       epilogue_tile_math(p, v, bv[RICH ? j : 0], ax[i & kOne][RICH ? j : 0], rr, a_pre, r_pre, a_post, r_post);
       if (!mok) return;
-      if (wide) {
+      if (p.out2 && nbase + j * 32 >= p.split_n) {  // wave-uniform: a 32-column tile never straddles split_n (split_n % 32 == 0)
+        const int ml = m - bidx * p.rpb;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+          if (nb < p.N) {
+            f16* o = p.out2 + ((long)bidx * (p.N - p.split_n) + (nb - p.split_n)) * p.ldo2 + ml;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[(long)e * p.ldo2] = (f16)v[4 * g + e];
+          }
+        }
+      } else if (wide) {
         // lanes l and l + 32 hold the same row: one v_permlane32_swap per dword trades group g of the upper half against group
         // g + 1 of the lower half; afterwards the lower lane owns channels 8g .. 8g+7 and the upper lane 8(g+1) .. 8(g+1)+7,
         // a 16-byte store each (the write path is issue-bound on 8-byte pieces)

@@ -183,6 +183,8 @@ class Engine:
             key += "|acc"
         if d.fp8:
             key += "|fp8"
+        if d.out2:
+            key += f"|o2{int(d.split_n)}"
         return key
 
     @staticmethod
@@ -226,7 +228,7 @@ class Engine:
                 best, best_ms = c, ms
         # K splits of the winning tile: the library's heuristic aims at ~1.5 workgroups per CU; for the long-K, few-tile launches (the
         # 16x16 / 8x8 latent levels) the right count is whatever makes the grid a multiple of the 256 CUs.  3 % margin against noise.
-        if best < 100 and d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8:
+        if best < 100 and d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8 and not d.out2:
             tile = best
             for sk in (1, 2, 3, 4, 6, 8):
                 if sk * 512 > d.K:
@@ -321,9 +323,12 @@ class Engine:
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
-               transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0) -> torch.Tensor:
+               transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0,
+               split_n: int = 0, out2: Optional[torch.Tensor] = None):
         """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
-        transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel)."""
+        transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel).
+        split_n > 0: ONE launch with two destinations (the q | k | v projections of a self-attention block): columns [0, split_n)
+        row-major -> y [.., split_n], columns [split_n, N) batch-transposed -> y2 [b, N - split_n, pad_cols]; returns (y, y2)."""
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
@@ -334,7 +339,17 @@ class Engine:
             return self.linear_fp8(xq, xs, fp8w[0], fp8w[1], bias, act=act, residual=residual, out=out, name=name)
         n_out = N // 2 if act == ACT_GEGLU else N
         d = GemmDesc()
-        if transposed_out:
+        if split_n:
+            assert not transposed_out and rows_per_batch > 0 and M % rows_per_batch == 0 and 0 < split_n < N
+            nb = M // rows_per_batch
+            ld2 = pad_cols if pad_cols else _round_up(rows_per_batch, 64)
+            if out is None:
+                out = self.buf(name, tuple(x.shape[:-1]) + (split_n,))
+            if out2 is None:
+                out2 = self.buf(None if name is None else name + ".t", (nb, N - split_n, ld2), zero=True)
+            d.out_mode, d.ldo, d.rows_per_batch = OUT_ROWMAJOR, out.stride(-2), rows_per_batch
+            d.out2, d.ldo2, d.split_n = _ptr(out2), ld2, split_n
+        elif transposed_out:
             assert rows_per_batch > 0 and M % rows_per_batch == 0
             nb = M // rows_per_batch
             ld = pad_cols if pad_cols else _round_up(rows_per_batch, 64)
@@ -350,8 +365,8 @@ class Engine:
         d.lda, d.ldw = x.stride(-2) if x.dim() > 1 else K, w.stride(0)
         d.ldr = residual.stride(-2) if residual is not None else 0
         d.act, d.splitk, d.out_scale = act, splitk, 1.0
-        self._gemm(d, (x, w, bias, residual, out))
-        return out
+        self._gemm(d, (x, w, bias, residual, out, out2))
+        return (out, out2) if split_n else out
 
     # ---- fp8 (OCP e4m3) Linear: SURVEY section 8 a15 / BASELINE configs[4] "fp8 MFMA" -------------------------------------------
     _fp8_weights = None   # {weight data_ptr: (bytes, scales, weight)} of the Linears that run on the fp8 MFMA (enable_fp8)

@@ -108,8 +108,11 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
             b = f"{p}.transformer_blocks.{k}"
             with E.scope(f"tb{k}"):
                 n = E.layernorm(h, W[b + ".norm1.weight"], W[b + ".norm1.bias"], name="ln1")
-                qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")
-                vt = E.linear(n, W[b + ".attn1.to_v.weight"], transposed_out=True, rows_per_batch=N, pad_cols=_rup(N, 64), name="vt")
+                if b + ".attn1.to_qkv.weight" in W:  # q | k | v in one two-destination launch (q, k row-major + V^T)
+                    qk, vt = E.linear(n, W[b + ".attn1.to_qkv.weight"], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
+                else:
+                    qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")
+                    vt = E.linear(n, W[b + ".attn1.to_v.weight"], transposed_out=True, rows_per_batch=N, pad_cols=_rup(N, 64), name="vt")
                 a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
                 h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
                 n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")

@@ -4,7 +4,8 @@
     the padding so padded output channels are exact zeros and padded input channels are ignored.
   * Linear  [out, in] kept as is (K contiguous).
   * GEGLU   ``ff.net.0.proj`` [8C, C] -> alternating 32-row blocks [hidden | gate] (gn_gemm GN_ACT_GEGLU contract).
-  * Self-attention ``to_q``/``to_k`` fused into one [2C, C] projection (``attn1.to_qk`` / ``self_attn.qk_proj``).
+  * Self-attention ``to_q``/``to_k`` fused into one [2C, C] projection (``attn1.to_qk`` / ``self_attn.qk_proj``), and
+    ``to_q``/``to_k``/``to_v`` into one [3C, C] projection (``attn1.to_qkv``: one two-destination launch, q | k row-major + V^T).
   * All ``time_emb_proj`` Linears of a network concatenated into one [sum Cout, temb] GEMM (``time_emb_proj_all``) whose
     output columns are sliced per ResNet block by pointer offset (gn_gemm ``ldshift``).
 Explicit and caller-owned, as SURVEY.md section 8(b) asks: nothing is repacked behind the caller's back.
@@ -134,6 +135,9 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
                 qb, kb = name[: -len("weight")] + "bias", (base + kn)[: -len("weight")] + "bias"
                 if qb in sd:
                     out[(base + fused)[: -len("weight")] + "bias"] = torch.cat([sd[qb], sd[kb]]).to(dtype).contiguous()
+                if qn == ".attn1.to_q.weight" and base + ".attn1.to_v.weight" in sd and qb not in sd:
+                    # q | k | v as ONE launch (two-destination GEMM: q, k row-major + V^T): the inference graphs' self-attention
+                    out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
     meta = {}
     if temb_w:
         out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(dtype).contiguous()

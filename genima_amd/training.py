@@ -37,7 +37,7 @@ from .engine import Engine
 from .packing import pack_state_dict
 
 F16, F32 = torch.float16, torch.float32
-_DUP_SUFFIXES = (".attn1.to_q.weight", ".attn1.to_k.weight", ".time_emb_proj.weight", ".time_emb_proj.bias")
+_DUP_SUFFIXES = (".attn1.to_q.weight", ".attn1.to_k.weight", ".attn1.to_qkv.weight", ".time_emb_proj.weight", ".time_emb_proj.bias")
 CTX_PAD = 8  # prompt-token rows are zero-padded to a multiple of this (GEMM reduction granule)
 
 
@@ -74,7 +74,7 @@ class TrainParams(FrozenParams):
         off = 0
         for name, t in packed.items():
             if name.endswith(_DUP_SUFFIXES):
-                continue  # covered by attn1.to_qk / time_emb_proj_all
+                continue  # covered by attn1.to_qk (+ to_v) / time_emb_proj_all
             self.layout[name] = (off, tuple(t.shape))
             off += _rup(t.numel(), 8)
         self.numel = off
@@ -624,7 +624,8 @@ class ControlNetTrainer:
         per-output-channel scales, activations per call with per-token scales (engine.enable_fp8).  The data-gradient GEMMs keep
         the f16 weight copies, and nothing of the trainable ControlNet changes.  Returns the number of weights switched."""
         ws = [w for n, w in self.unet.W.items()
-              if isinstance(w, torch.Tensor) and w.dim() == 2 and n.endswith(".weight") and (".attn1." in n or ".attn2." in n or ".ff.net." in n)]
+              if isinstance(w, torch.Tensor) and w.dim() == 2 and n.endswith(".weight") and (".attn1." in n or ".attn2." in n or ".ff.net." in n)
+              and not n.endswith(".to_qkv.weight")]  # the inference graphs' fused copy: the training forward runs to_qk + to_v
         self.E.enable_fp8(ws)
         return len(ws)
 

@@ -94,6 +94,13 @@ typedef struct gn_gemm_desc {
   int32_t fp8;
   const void* scale_a;    /* fp8: f32 [M] */
   const void* scale_w;    /* fp8: f32 [N], 16-byte aligned */
+  /* two-destination output: the q | k | v projections of a self-attention block as ONE launch (diffusers Attention.to_q / to_k /
+   * to_v, three cuBLAS calls in the reference: SURVEY.md K7).  Columns [0, split_n) go to `out` (row-major, ldo) as usual; columns
+   * [split_n, N) go to `out2` batch-transposed: out2[b][n - split_n][m - b * rows_per_batch], row stride ldo2 -- the V^T layout
+   * gn_attention_fwd reads.  split_n % 32 == 0; GN_OUT_ROWMAJOR, no GEGLU / batch / fp8; K is never split.  NULL = off. */
+  void* out2;
+  int64_t ldo2;
+  int32_t split_n;
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */

@@ -85,3 +85,10 @@ def test_f32_accumulate_and_transposed_every_tile(eng, tile_override, tile):
     y = eng.linear(a.view(Bn, rows, K), w, b, transposed_out=True, rows_per_batch=rows, pad_cols=pad)
     want = (ref + b.float().cpu()).view(Bn, rows, N).permute(0, 2, 1)
     assert_close(y.view(Bn, N, pad)[:, :, :rows], want, what=f"tile {tile} transposed")
+    # two destinations (q | k row-major + V^T in one launch): columns [0, 2C) and [2C, 3C)
+    Cq = 96
+    w3, b3 = randn_h(3 * Cq, K, seed=13, scale=K ** -0.5), randn_h(3 * Cq, seed=14, scale=0.3)
+    qk, vt = eng.linear(a.view(Bn, rows, K), w3, b3, split_n=2 * Cq, rows_per_batch=rows, pad_cols=pad)
+    full = a.float().cpu() @ w3.float().cpu().t() + b3.float().cpu()
+    assert_close(qk.reshape(M, 2 * Cq), full[:, : 2 * Cq], what=f"tile {tile} q|k part")
+    assert_close(vt.view(Bn, Cq, pad)[:, :, :rows], full[:, 2 * Cq:].view(Bn, rows, Cq).permute(0, 2, 1), what=f"tile {tile} V^T part")
