@@ -10,7 +10,7 @@ done
 python - <<'PY'
 import csv, glob, json, os
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/pmc_traffic"
-fams = [("gemm", ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_kernel", "gemm_fp8_kernel", "splitk_reduce")), ("attn", ("attn_fwd",)), ("layernorm", ("layernorm_kernel",)),
+fams = [("gemm", ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_s3_kernel", "gemm_kernel", "gemm_fp8_kernel", "splitk_reduce")), ("attn", ("attn_fwd",)), ("layernorm", ("layernorm_kernel",)),
         ("gn_stats", ("gn_stats_kernel",)), ("gn_apply", ("gn_apply_kernel",)), ("gn_fused", ("gn_fused_kernel",)), ("gn_finalize", ("gn_finalize_kernel",))]
 out = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
