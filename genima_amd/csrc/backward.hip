@@ -263,80 +263,108 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const f16* __restrict_
 }
 
 // ---- LayerNorm backward: wave per row; per-block f32 partials of dgamma / dbeta ----------------------------------------------
+// CH 16-byte chunks per lane (C <= 512 CH), R rows per wave and trip: the x and dy loads of all R rows are issued before the first
+// reduction (a wave that walks its rows one at a time pays two dependent memory round trips per row: 44 us at 32768 x 320), and the
+// three reductions of the R rows interleave.
 constexpr int LNB_MAXCH = 4;  // C <= 2048
+template <int CH, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ dy,
                                                             f16* __restrict__ dx, float* __restrict__ part, long M, int C, float eps,
                                                             int rows_per_block) {
   // block = 4 waves; each wave walks rows_per_block/4 rows; lanes own fixed column chunks so dgamma/dbeta accumulate in registers
-  __shared__ float red[4][2];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int CC = C >> 3;
-  float dg[LNB_MAXCH][8], db[LNB_MAXCH][8];
+  float dg[CH][8], db[CH][8], gm[CH][8];
 #pragma unroll
-  for (int i = 0; i < LNB_MAXCH; ++i)
+  for (int i = 0; i < CH; ++i) {
+    const int cx = lane + 64 * i;
+    uint4 g4 = make_uint4(0, 0, 0, 0);
+    if (cx < CC) g4 = *reinterpret_cast<const uint4*>(gamma + cx * 8);
+    const f16x8 hg = *reinterpret_cast<const f16x8*>(&g4);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; }
-  const long r0 = (long)blockIdx.x * rows_per_block;
-  for (long row = r0 + w; row < min(M, r0 + rows_per_block); row += 4) {
-    float xv[LNB_MAXCH][8], gv[LNB_MAXCH][8];
-    float s = 0.f;
+    for (int e = 0; e < 8; ++e) { dg[i][e] = 0.f; db[i][e] = 0.f; gm[i][e] = (float)hg[e]; }
+  }
+  const long r0 = (long)blockIdx.x * rows_per_block, rend = min(M, r0 + rows_per_block);
+  const float invC = 1.0f / (float)C;
+  for (long rb = r0 + (long)w * R; rb < rend; rb += 4 * R) {
+    uint4 xa[R][CH], da[R][CH];
 #pragma unroll
-    for (int i = 0; i < LNB_MAXCH; ++i) {
-      const int cx = lane + 64 * i;
-      if (cx < CC) {
-        const uint4 a = *reinterpret_cast<const uint4*>(x + row * C + cx * 8);
-        const f16x8 h = *reinterpret_cast<const f16x8*>(&a);
+    for (int r = 0; r < R; ++r)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { xv[i][e] = (float)h[e]; s += xv[i][e]; }
+      for (int i = 0; i < CH; ++i) {
+        const int cx = lane + 64 * i;
+        const bool ok = cx < CC && rb + r < rend;
+        xa[r][i] = ok ? *reinterpret_cast<const uint4*>(x + (rb + r) * C + cx * 8) : make_uint4(0, 0, 0, 0);
+        da[r][i] = ok ? *reinterpret_cast<const uint4*>(dy + (rb + r) * C + cx * 8) : make_uint4(0, 0, 0, 0);
+      }
+    float s[R], ss[R], mean[R], rstd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      s[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&xa[r][i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[r] += (float)h[e];
       }
     }
-    const float mean = wave_sum(s) / (float)C;
-    float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < LNB_MAXCH; ++i) {
-      const int cx = lane + 64 * i;
-      if (cx < CC)
+    for (int r = 0; r < R; ++r) mean[r] = wave_sum(s[r]) * invC;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = xv[i][e] - mean; ss += d * d; }
+    for (int r = 0; r < R; ++r) {
+      ss[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&xa[r][i]);
+        if (lane + 64 * i < CC)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { const float d = (float)h[e] - mean[r]; ss[r] += d * d; }
+      }
     }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)C + eps);
-    float m1 = 0.f, m2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LNB_MAXCH; ++i) {
-      const int cx = lane + 64 * i;
-      if (cx < CC) {
-        const uint4 a = *reinterpret_cast<const uint4*>(dy + row * C + cx * 8), g4 = *reinterpret_cast<const uint4*>(gamma + cx * 8);
-        const f16x8 hd = *reinterpret_cast<const f16x8*>(&a), hg = *reinterpret_cast<const f16x8*>(&g4);
+    for (int r = 0; r < R; ++r) rstd[r] = rsqrtf(wave_sum(ss[r]) * invC + eps);
+    float m1[R], m2[R];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float xh = (xv[i][e] - mean) * rstd, d = (float)hd[e];
-          xv[i][e] = xh;
-          dg[i][e] += d * xh;
-          db[i][e] += d;
-          gv[i][e] = d * (float)hg[e];
-          m1 += gv[i][e];
-          m2 += gv[i][e] * xh;
+    for (int r = 0; r < R; ++r) {
+      m1[r] = 0.f; m2[r] = 0.f;
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const f16x8 hx = *reinterpret_cast<const f16x8*>(&xa[r][i]), hd = *reinterpret_cast<const f16x8*>(&da[r][i]);
+        if (lane + 64 * i < CC)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)hx[e] - mean[r]) * rstd[r], d = (float)hd[e];
+            dg[i][e] += d * xh;
+            db[i][e] += d;
+            const float gv = d * gm[i][e];
+            m1[r] += gv;
+            m2[r] += gv * xh;
+          }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) { m1[r] = wave_sum(m1[r]) * invC; m2[r] = wave_sum(m2[r]) * invC; }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const int cx = lane + 64 * i;
+        if (cx < CC && rb + r < rend) {
+          const f16x8 hx = *reinterpret_cast<const f16x8*>(&xa[r][i]), hd = *reinterpret_cast<const f16x8*>(&da[r][i]);
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = ((float)hx[e] - mean[r]) * rstd[r];
+            o[e] = (f16)(rstd[r] * ((float)hd[e] * gm[i][e] - m1[r] - xh * m2[r]));
+          }
+          *reinterpret_cast<uint4*>(dx + (rb + r) * C + cx * 8) = *reinterpret_cast<uint4*>(&o);
         }
       }
-    }
-    m1 = wave_sum(m1) / (float)C;
-    m2 = wave_sum(m2) / (float)C;
-#pragma unroll
-    for (int i = 0; i < LNB_MAXCH; ++i) {
-      const int cx = lane + 64 * i;
-      if (cx < CC) {
-        f16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (f16)(rstd * (gv[i][e] - m1 - xv[i][e] * m2));
-        *reinterpret_cast<uint4*>(dx + row * C + cx * 8) = *reinterpret_cast<uint4*>(&o);
-      }
-    }
   }
-  (void)red;
   if (part) {  // per-wave partial rows: part[(block*4 + wave)][2][C]
     float* o = part + ((long)blockIdx.x * 4 + w) * 2 * C;
 #pragma unroll
-    for (int i = 0; i < LNB_MAXCH; ++i) {
+    for (int i = 0; i < CH; ++i) {
       const int cx = lane + 64 * i;
       if (cx < CC)
 #pragma unroll
@@ -737,8 +765,15 @@ int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const vo
   GN_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || workspace), "gn_layernorm_bwd: dgamma/dbeta come together and need a workspace");
   const int rpb = 64;
   const long blocks = (M + rpb - 1) / rpb;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const f16*)x, (const f16*)gamma, (const f16*)dy, (f16*)dx,
-                     dgamma ? (float*)workspace : nullptr, (long)M, C, eps, rpb);
+  float* part = dgamma ? (float*)workspace : nullptr;
+  const int CC = C / 8;
+#define GN_LNB(CH, R) hipLaunchKernelGGL((layernorm_bwd_kernel<CH, R>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const f16*)x, \
+                                         (const f16*)gamma, (const f16*)dy, (f16*)dx, part, (long)M, C, eps, rpb)
+  if (CC <= 64) GN_LNB(1, 4);
+  else if (CC <= 128) GN_LNB(2, 2);
+  else if (CC <= 192) GN_LNB(3, 1);
+  else GN_LNB(4, 1);
+#undef GN_LNB
   GN_LAUNCH_CHECK();
   if (dgamma) {
     // partial rows are [blocks*4][2][C]: view as R = blocks*4 rows of 2C columns -> [2C] sums

@@ -23,6 +23,7 @@ struct GNParams {
   float* stats;     // optional [B][G][2] (mean, rstd) saved for the backward pass
   int B, HW, C1, C2, C, G, cpg, chunks, rows, achunks, arows, act;
   float eps;
+  int save_scsh;    // scsh is a caller buffer that has to be filled (training), not the workspace scratch of the 3-launch path
 };
 
 // (channel-chunk, pixel-lane) thread mapping shared by the stats and apply kernels: TX = min(C/8, 256) lanes walk the
@@ -254,9 +255,17 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GNParams p)
   const float mean = ts / n;
   const float var = fmaxf(tss / n - mean * mean, 0.0f);
   const float rstd = rsqrtf(var + p.eps);
+  if (p.stats && tid == 0) {  // training: (mean, rstd) per (batch, group) for the backward pass
+    p.stats[((long)b * p.G + g) * 2] = mean;
+    p.stats[((long)b * p.G + g) * 2 + 1] = rstd;
+  }
   if (p0 < pstep) {
     const float a0 = rstd * (float)p.gamma[c], a1 = rstd * (float)p.gamma[c + 1];
     const float s0 = (float)p.beta[c] - mean * a0, s1 = (float)p.beta[c + 1] - mean * a1;
+    if (p.save_scsh && p0 == 0) {  // training: per-(b, c) scale / shift (the layout gn_finalize_kernel writes)
+      f32x4 o = {a0, s0, a1, s1};
+      *reinterpret_cast<f32x4*>(p.scsh + ((long)b * p.C + c) * 2) = o;
+    }
     f16* dst = p.y + (long)b * p.HW * p.C + c;
     for (int r = p0; r < p.HW; r += pstep) {
       const unsigned int raw = slab[r * hpg + j];
@@ -383,7 +392,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.scsh = p.partials + (long)d->B * gn_pick_chunks(d->B, d->HW) * d->groups * 2;
   p.stats = (float*)d->save_stats;
   if (d->save_scsh) p.scsh = (float*)d->save_scsh;  // training: persistent per-(b, c) scale/shift for the backward pass
-  const bool saving = d->save_stats || d->save_scsh;
+  p.save_scsh = d->save_scsh != nullptr;
   {  // single-launch path when a (batch, group) slab fits in LDS
     static int fused_ok = -1;
     static long fused_max = GNF_MAX_LDS;
@@ -398,7 +407,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
     // few (batch, group) slabs leave most CUs idle -- unless the whole tensor is so small that the call is latency-bound anyway
     // (batch 1: 32 slabs; one launch of ~6 us instead of three)
     const bool small = (long)d->B * d->HW * C * 2 <= (4l << 20);
-    if (fused_ok && !saving && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= fused_max &&
+    if (fused_ok && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= fused_max &&
         ((long)d->B * d->groups >= 64 || small)) {
       hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups, d->B), dim3(GNF_THREADS), (size_t)slab, ctx->stream, p);
       GN_LAUNCH_CHECK();
