@@ -48,8 +48,11 @@ __device__ __forceinline__ uint4 tile_load_column_chunk(uint32_t (*tile)[33], in
   for (int i = 0; i < 8; ++i) h[i] = (tile[r8 + i][w] >> sh) & 0xffffu;
   return make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
 }
+// SUMS: also write the column sums of the tile's 64 rows -- part[blockIdx.y][col] -- the first stage of a bias / time-shift gradient
+// (the weight-gradient path transposes dY anyway; reading it a second time for gn_colsum_f32 cost 1.5 ms per train step)
+template <bool SUMS>
 __global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restrict__ in, f16* __restrict__ out, int rows, int cols, long ld_in,
-                                                              long ld_out, long in_bs, long out_bs) {
+                                                              long ld_out, long in_bs, long out_bs, float* __restrict__ part) {
   __shared__ uint32_t tile[64][33];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -67,7 +70,18 @@ __global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restr
 #pragma unroll
   for (int it = 0; it < 2; ++it) {
     const int oc = hi + 32 * it, c = c0 + oc, r = r0 + lo * 8;
-    if (c < cols && r < rows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = tile_load_column_chunk(tile, lo * 8, oc);
+    const uint4 v = tile_load_column_chunk(tile, lo * 8, oc);  // rows past `rows` were stored as zeros
+    if (c < cols && r < rows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = v;
+    if (SUMS) {
+      const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
+      float a = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a += (float)h[e];
+      a += __shfl_xor(a, 1);  // the 8 threads of one output row are neighbouring lanes
+      a += __shfl_xor(a, 2);
+      a += __shfl_xor(a, 4);
+      if (lo == 0 && c < cols) part[(long)blockIdx.y * cols + c] = a;
+    }
   }
 }
 
@@ -672,11 +686,30 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
   const bool vec = cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && in_bs % 8 == 0 && out_bs % 8 == 0 && ld_out >= (rows + 7) / 8 * 8 &&
                    ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
   if (vec)
-    hipLaunchKernelGGL(transpose2d_vec_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
-                       (long)in_bs, (long)out_bs);
+    hipLaunchKernelGGL(transpose2d_vec_kernel<false>, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
+                       (long)in_bs, (long)out_bs, (float*)nullptr);
   else
     hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
                        (long)in_bs, (long)out_bs);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+/* out = in^T as gn_transpose2d (one matrix), and sums[g][cols] (+)= column sums of rows [g * rows / groups, (g + 1) * rows / groups):
+ * the bias gradient (groups = 1) or the per-sample time-shift gradient (groups = batch) from the pass that transposes dY for the
+ * weight gradient.  rows / groups must be a multiple of 64; workspace = ceil(rows / 64) * cols floats. */
+int32_t gn_transpose2d_colsum(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
+                              float* sums, int32_t groups, int32_t accumulate, void* workspace) {
+  GN_REQUIRE(ctx && in && out && sums && workspace && rows > 0 && cols > 0 && groups > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d_colsum: bad arguments");
+  GN_REQUIRE(rows % groups == 0 && (rows / groups) % 64 == 0, "gn_transpose2d_colsum: rows / groups (%d / %d) must be a multiple of 64", rows, groups);
+  GN_REQUIRE(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0,
+             "gn_transpose2d_colsum: cols / strides must be multiples of 8, buffers 16-byte aligned");
+  const dim3 grid((cols + 63) / 64, rows / 64, 1);
+  hipLaunchKernelGGL(transpose2d_vec_kernel<true>, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
+                     0l, 0l, (float*)workspace);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups * cols, 64)), dim3(256), 0, ctx->stream, (const float*)workspace, sums, groups,
+                     rows / 64 / groups, cols, accumulate);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -78,6 +78,26 @@ def transpose2d(E: Engine, x: torch.Tensor, rows: int, cols: int, *, ld_in: Opti
     return out
 
 
+def transpose2d_colsum(E: Engine, x: torch.Tensor, rows: int, cols: int, sums) -> torch.Tensor:
+    """x [rows, cols] -> x^T [cols, rows], and for every (tensor, groups) of ``sums``: tensor[groups, cols] += the column sums of each
+    of the ``groups`` row blocks -- in ONE pass over x (the bias / time-shift gradients ride on the transpose the weight gradient
+    needs).  Falls back to transpose2d + colsum when a row block is not a multiple of 64 rows."""
+    sums = [(s, g) for s, g in sums if s is not None]
+    if not sums:
+        return transpose2d(E, x, rows, cols)
+    if cols % 8 != 0 or any(rows % g != 0 or (rows // g) % 64 != 0 for _, g in sums):
+        for s, g in sums:
+            colsum(E, x, s, g, rows // g, cols, cols)
+        return transpose2d(E, x, rows, cols)
+    out = torch.empty((cols, rows), dtype=F16, device=x.device)
+    ws = E._workspace((rows // 64) * cols * 4)
+    (s0, g0), rest = sums[0], sums[1:]
+    check(E.lib.gn_transpose2d_colsum(E._ctx, _ptr(x), _ptr(out), rows, cols, cols, rows, _ptr(s0), g0, 1, _ptr(ws)), "gn_transpose2d_colsum")
+    for s, g in rest:  # further groupings of the same 64-row partial sums
+        check(E.lib.gn_reduce_rows_f32(E._ctx, _ptr(ws), _ptr(s), g, rows // 64 // g, cols, 1), "gn_reduce_rows_f32")
+    return out
+
+
 def conv_weight_dgrad(E: Engine, w: torch.Tensor, taps: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Packed conv weight [Cout, taps*Cin] -> the data-gradient conv's weight [Cin, taps*Cout]: in/out channels swapped and the
     taps rotated by 180 degrees (out[ci][taps-1-t][co] = w[co][t][ci]); one batched tile transpose, batch = taps."""

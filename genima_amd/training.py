@@ -208,7 +208,7 @@ class Graph:
             dy2 = dy.view(M, N)
             self.acc(residual, dy)
             if net.G is not None:
-                dyt = T.transpose2d(E, dy2, M, N)
+                dyt = T.transpose2d_colsum(E, dy2, M, N, [(net.G[bn], 1)] if bn else [])  # the bias gradient rides on the transpose
                 if self._xt[0] is x.t:  # the previous backward op consumed the same input (q|k and v projections of one LayerNorm)
                     xt = self._xt[1]
                 else:
@@ -216,8 +216,6 @@ class Graph:
                     self._xt = (x.t, xt)
                 Mp = dyt.shape[1]
                 T.gemm(E, dyt, xt, net.G[wn], N, K, Mp, Mp, Mp, K, f32_out=True, accumulate=True)
-                if bn:
-                    T.colsum(E, dy2, net.G[bn], 1, M, N, N)
             if x.needs:
                 self.acc(x, E.linear(dy2, net.wt(wn)).view(x.t.shape))
         return self._push(out, bw)
@@ -251,11 +249,8 @@ class Graph:
             if net.G is not None:
                 assert x2 is None and not upsample2x, "weight gradients of concat / upsample convs are not needed by the ControlNet"
                 assert M % 8 == 0, "conv wgrad needs B*Ho*Wo to be a multiple of 8"
-                if sh_var is not None:
-                    T.colsum(E, dy2, net.dshift[prefix], B, Ho * Wo, Cout, Cout)
-                if bn:
-                    T.colsum(E, dy2, net.G[bn], 1, M, Cout, Cout)
-                dyt = T.transpose2d(E, dy2, M, Cout)
+                dyt = T.transpose2d_colsum(E, dy2, M, Cout, [(net.dshift[prefix] if sh_var is not None else None, B),
+                                                             (net.G[bn] if bn else None, 1)])  # time-shift and bias gradients
                 cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)
                 Kw = ksize * ksize * C1
                 T.gemm(E, dyt, cols, net.G[wn], Cout, Kw, M, M, M, Kw, f32_out=True, accumulate=True)

@@ -278,3 +278,20 @@ def test_mse_adamw_clip(engine):
     out16 = torch.empty(n, dtype=torch.float16, device="cuda")
     T.cast_f32_f16(engine, wd, out16)
     assert torch.equal(out16.cpu(), wd.cpu().half())
+
+
+@pytest.mark.parametrize("rows,cols,groups", [(4096, 320, 8), (1024, 136, 1), (640, 64, 5), (1000, 72, 1)])
+def test_transpose_with_column_sums(engine, rows, cols, groups):
+    """gn_transpose2d_colsum: x^T and the bias (1 group) / per-sample time-shift (batch groups) gradients from one pass over dY
+    (autograd's `.sum(0)` of the Linear / conv bias backward); (1000, 72): a row block that is not 64-row tiled takes the two-launch path."""
+    g = torch.Generator().manual_seed(31)
+    x = (torch.randn(rows, cols, generator=g) * 0.7).half().cuda()
+    s1 = torch.full((1, cols), 0.5, device="cuda")
+    sg = torch.full((groups, cols), -0.25, device="cuda")
+    xt = T.transpose2d_colsum(engine, x, rows, cols, [(sg, groups), (None, 3), (s1, 1)])
+    xf = x.float().cpu()
+    assert torch.equal(xt[:, :rows].cpu(), x.t().cpu())
+    assert_close(sg, xf.view(groups, rows // groups, cols).sum(1) - 0.25, rel=1e-5, what="grouped column sums")
+    assert_close(s1, xf.sum(0, keepdim=True) + 0.5, rel=1e-5, what="column sums")
+    xt2 = T.transpose2d_colsum(engine, x, rows, cols, [])
+    assert torch.equal(xt2, xt)
