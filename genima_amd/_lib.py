@@ -108,7 +108,7 @@ SIGNATURES = {
     "gn_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_transpose2d": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
     "gn_im2col_t": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
-    "gn_transpose2d_colsum": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _P, _I32, _I32, _P]),
+    "gn_transpose2d_colsum": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _P, _I32, _P, _I32, _P]),
     "gn_colsum_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "gn_colsum_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I64, _P, _I32]),
     "gn_reduce_rows_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),

@@ -52,34 +52,47 @@ __device__ __forceinline__ uint4 tile_load_column_chunk(uint32_t (*tile)[33], in
 // (the weight-gradient path transposes dY anyway; reading it a second time for gn_colsum_f32 cost 1.5 ms per train step)
 template <bool SUMS>
 __global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restrict__ in, f16* __restrict__ out, int rows, int cols, long ld_in,
-                                                              long ld_out, long in_bs, long out_bs, float* __restrict__ part) {
+                                                              long ld_out, long in_bs, long out_bs, float* __restrict__ part, int row_tiles) {
+  // row_tiles (SUMS only): consecutive 64-row tiles one block walks, so that the partial-sum matrix stays short (<= 128 rows: the
+  // second-stage reduction reads all of it)
   __shared__ uint32_t tile[64][33];
   const int b = blockIdx.z;
-  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int c0 = blockIdx.x * 64;
   const int t = threadIdx.x, lo = t & 7, hi = t >> 3;
   in += (long)b * in_bs;
   out += (long)b * out_bs;
+  float colacc[2] = {0.f, 0.f};
+  for (int rt = 0; rt < row_tiles; ++rt) {
+    const int r0 = (blockIdx.y * row_tiles + rt) * 64;
+    if (rt > 0) __syncthreads();
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int r = r0 + hi + 32 * it, c = c0 + lo * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < rows && c < cols) v = *reinterpret_cast<const uint4*>(in + (long)r * ld_in + c);
-    tile_store_chunk(tile, hi + 32 * it, lo, v);
+    for (int it = 0; it < 2; ++it) {
+      const int r = r0 + hi + 32 * it, c = c0 + lo * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < rows && c < cols) v = *reinterpret_cast<const uint4*>(in + (long)r * ld_in + c);
+      tile_store_chunk(tile, hi + 32 * it, lo, v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int oc = hi + 32 * it, c = c0 + oc, r = r0 + lo * 8;
+      const uint4 v = tile_load_column_chunk(tile, lo * 8, oc);  // rows past `rows` were stored as zeros
+      if (c < cols && r < rows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = v;
+      if (SUMS) {
+        const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) colacc[it] += (float)h[e];
+      }
+    }
   }
-  __syncthreads();
+  if (SUMS) {
 #pragma unroll
-  for (int it = 0; it < 2; ++it) {
-    const int oc = hi + 32 * it, c = c0 + oc, r = r0 + lo * 8;
-    const uint4 v = tile_load_column_chunk(tile, lo * 8, oc);  // rows past `rows` were stored as zeros
-    if (c < cols && r < rows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = v;
-    if (SUMS) {
-      const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
-      float a = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) a += (float)h[e];
+    for (int it = 0; it < 2; ++it) {
+      float a = colacc[it];
       a += __shfl_xor(a, 1);  // the 8 threads of one output row are neighbouring lanes
       a += __shfl_xor(a, 2);
       a += __shfl_xor(a, 4);
+      const int c = c0 + hi + 32 * it;
       if (lo == 0 && c < cols) part[(long)blockIdx.y * cols + c] = a;
     }
   }
@@ -687,7 +700,7 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
                    ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
   if (vec)
     hipLaunchKernelGGL(transpose2d_vec_kernel<false>, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
-                       (long)in_bs, (long)out_bs, (float*)nullptr);
+                       (long)in_bs, (long)out_bs, (float*)nullptr, 1);
   else
     hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
                        (long)in_bs, (long)out_bs);
@@ -695,22 +708,33 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
   return GN_OK;
 }
 
-/* out = in^T as gn_transpose2d (one matrix), and sums[g][cols] (+)= column sums of rows [g * rows / groups, (g + 1) * rows / groups):
- * the bias gradient (groups = 1) or the per-sample time-shift gradient (groups = batch) from the pass that transposes dY for the
- * weight gradient.  rows / groups must be a multiple of 64; workspace = ceil(rows / 64) * cols floats. */
+/* out = in^T as gn_transpose2d (one matrix), and sums[g][cols] += column sums of rows [g * rows / groups, (g + 1) * rows / groups):
+ * the bias gradient (groups = 1) and / or the per-sample time-shift gradient (groups = batch) from the pass that transposes dY for
+ * the weight gradient.  sums2 / groups2: an optional second grouping of the same partial sums.  rows / groups must be multiples of
+ * 64; workspace = ceil(rows / 64) * cols floats. */
 int32_t gn_transpose2d_colsum(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
-                              float* sums, int32_t groups, int32_t accumulate, void* workspace) {
+                              float* sums, int32_t groups, float* sums2, int32_t groups2, void* workspace) {
   GN_REQUIRE(ctx && in && out && sums && workspace && rows > 0 && cols > 0 && groups > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d_colsum: bad arguments");
-  GN_REQUIRE(rows % groups == 0 && (rows / groups) % 64 == 0, "gn_transpose2d_colsum: rows / groups (%d / %d) must be a multiple of 64", rows, groups);
+  if (!sums2) groups2 = groups;
+  GN_REQUIRE(groups2 > 0 && rows % groups == 0 && (rows / groups) % 64 == 0 && rows % groups2 == 0 && (rows / groups2) % 64 == 0,
+             "gn_transpose2d_colsum: rows / groups (%d / %d, %d) must be multiples of 64", rows, groups, groups2);
   GN_REQUIRE(cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0,
              "gn_transpose2d_colsum: cols / strides must be multiples of 8, buffers 16-byte aligned");
-  const dim3 grid((cols + 63) / 64, rows / 64, 1);
+  int rt = 1;  // 64-row tiles per block: keep the partial matrix at <= 128 rows where the row blocks allow
+  const int t1 = rows / groups / 64, t2 = rows / groups2 / 64;
+  while (t1 % (rt * 2) == 0 && t2 % (rt * 2) == 0 && (long)rows / 64 / rt > 128) rt *= 2;
+  const dim3 grid((cols + 63) / 64, rows / 64 / rt, 1);
   hipLaunchKernelGGL(transpose2d_vec_kernel<true>, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
-                     0l, 0l, (float*)workspace);
+                     0l, 0l, (float*)workspace, rt);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups * cols, 64)), dim3(256), 0, ctx->stream, (const float*)workspace, sums, groups,
-                     rows / 64 / groups, cols, accumulate);
+                     t1 / rt, cols, 1);
   GN_LAUNCH_CHECK();
+  if (sums2) {
+    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups2 * cols, 64)), dim3(256), 0, ctx->stream, (const float*)workspace, sums2, groups2,
+                       t2 / rt, cols, 1);
+    GN_LAUNCH_CHECK();
+  }
   return GN_OK;
 }
 

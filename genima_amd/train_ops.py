@@ -91,10 +91,9 @@ def transpose2d_colsum(E: Engine, x: torch.Tensor, rows: int, cols: int, sums) -
         return transpose2d(E, x, rows, cols)
     out = torch.empty((cols, rows), dtype=F16, device=x.device)
     ws = E._workspace((rows // 64) * cols * 4)
-    (s0, g0), rest = sums[0], sums[1:]
-    check(E.lib.gn_transpose2d_colsum(E._ctx, _ptr(x), _ptr(out), rows, cols, cols, rows, _ptr(s0), g0, 1, _ptr(ws)), "gn_transpose2d_colsum")
-    for s, g in rest:  # further groupings of the same 64-row partial sums
-        check(E.lib.gn_reduce_rows_f32(E._ctx, _ptr(ws), _ptr(s), g, rows // 64 // g, cols, 1), "gn_reduce_rows_f32")
+    assert len(sums) <= 2
+    (s0, g0), (s1, g1) = sums[0], (sums[1] if len(sums) > 1 else (None, 0))
+    check(E.lib.gn_transpose2d_colsum(E._ctx, _ptr(x), _ptr(out), rows, cols, cols, rows, _ptr(s0), g0, _ptr(s1), g1, _ptr(ws)), "gn_transpose2d_colsum")
     return out
 
 

@@ -225,11 +225,12 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
 /* out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c] (0 in the padding); M = B*Ho*Wo contiguous */
 int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize,
                     int32_t stride, int32_t pad);
-/* gn_transpose2d of one matrix that also yields sums[g][cols] (+)= the column sums of row block g (groups = 1: bias gradient;
- * groups = batch: per-sample time-shift gradient) -- the weight-gradient path transposes dY anyway.  (rows / groups) % 64 == 0;
- * workspace: ceil(rows / 64) * cols floats.  Replaces the `.sum(0)` of autograd's Linear / conv bias backward. */
+/* gn_transpose2d of one matrix that also yields sums[g][cols] += the column sums of row block g (groups = 1: bias gradient;
+ * groups = batch: per-sample time-shift gradient; sums2 / groups2: an optional second grouping from the same pass) -- the
+ * weight-gradient path transposes dY anyway.  (rows / groups) % 64 == 0; workspace: ceil(rows / 64) * cols floats.  Replaces the
+ * `.sum(0)` of autograd's Linear / conv bias backward. */
 int32_t gn_transpose2d_colsum(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
-                              float* sums, int32_t groups, int32_t accumulate, void* workspace);
+                              float* sums, int32_t groups, float* sums2, int32_t groups2, void* workspace);
 int64_t gn_colsum_workspace_bytes(int32_t nb, int32_t rows_per_batch, int32_t cols);
 /* out[b][c] (+)= sum_r x[b*rows_per_batch + r][c]  (bias gradients nb = 1; time-shift gradients nb = batch) */
 int32_t gn_colsum_f32(gn_ctx* ctx, const void* x, float* out, int32_t nb, int32_t rows_per_batch, int32_t cols, int64_t ld,
