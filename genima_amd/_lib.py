@@ -117,9 +117,9 @@ SIGNATURES = {
     "gn_geglu_bwd": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32]),
     "gn_softmax_bwd": (_I32, [_P, _P, _P, _I64, _I32, _I64, _F]),
     "gn_layernorm_bwd_workspace_bytes": (_I64, [_I64, _I32]),
-    "gn_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F]),
+    "gn_layernorm_bwd": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _F, _P]),
     "gn_groupnorm_bwd_workspace_bytes": (_I64, [_I32, _I32, _I32]),
-    "gn_groupnorm_bwd": (_I32, [_P, C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "gn_groupnorm_bwd": (_I32, [_P, C.POINTER(GroupNormDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "gn_zero_upsample2x": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_sumpool2x2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_mse_loss": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F]),

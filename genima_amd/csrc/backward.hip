@@ -296,9 +296,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const f16* __restrict_
 constexpr int LNB_MAXCH = 4;  // C <= 2048
 template <int CH, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma, const f16* __restrict__ dy,
-                                                            f16* __restrict__ dx, float* __restrict__ part, long M, int C, float eps,
-                                                            int rows_per_block) {
+                                                            f16* dx, float* __restrict__ part, long M, int C, float eps,
+                                                            int rows_per_block, const f16* dx_add) {
   // block = 4 waves; each wave walks rows_per_block/4 rows; lanes own fixed column chunks so dgamma/dbeta accumulate in registers
+  // dx_add (optional, may alias dx): the gradient x already holds, added before the store
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int CC = C >> 3;
   float dg[CH][8], db[CH][8], gm[CH][8];
@@ -384,6 +385,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restric
             const float xh = ((float)hx[e] - mean[r]) * rstd[r];
             o[e] = (f16)(rstd[r] * ((float)hd[e] * gm[i][e] - m1[r] - xh * m2[r]));
           }
+          if (dx_add) {
+            const uint4 ar = *reinterpret_cast<const uint4*>(dx_add + (rb + r) * C + cx * 8);
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(&ar);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f16)((float)o[e] + (float)ah[e]);
+          }
           *reinterpret_cast<uint4*>(dx + (rb + r) * C + cx * 8) = *reinterpret_cast<uint4*>(&o);
         }
       }
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const f16* __restric
 struct GNBParams {
   const f16* x; const f16* x2; const f16* dy; const f16* gamma; const f16* beta;
   f16* dx; f16* dx2;
+  const f16* dx_add; const f16* dx2_add;  // optional: gradients already held by x / x2, added before the store (may alias dx / dx2)
   float* part;    // [B][chunks][2][C] per-channel partial sums of dyh and dyh*x
   float* coef;    // [B][C][3]: dx = a1*dyh + a2*x + a3
   float* sums;    // [B][2][C]: per-channel totals over the whole slab (S1 | S2)
@@ -544,8 +552,8 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const GNBParams p, const
   if (idx >= (long)p.HW * CC) return;
   const int r = (int)(idx / CC), c = (int)(idx - (long)r * CC) * 8;
   const long pix = (long)b * p.HW + r;
-  const f16* src; f16* dst; int cs, co;
-  if (c < p.C1) { src = p.x; dst = p.dx; cs = p.C1; co = c; } else { src = p.x2; dst = p.dx2; cs = p.C2; co = c - p.C1; }
+  const f16* src; f16* dst; const f16* add; int cs, co;
+  if (c < p.C1) { src = p.x; dst = p.dx; add = p.dx_add; cs = p.C1; co = c; } else { src = p.x2; dst = p.dx2; add = p.dx2_add; cs = p.C2; co = c - p.C1; }
   if (!dst) return;
   const uint4 xr = *reinterpret_cast<const uint4*>(src + pix * cs + co);
   const uint4 dr = *reinterpret_cast<const uint4*>(p.dy + pix * p.C + c);
@@ -558,6 +566,12 @@ __global__ __launch_bounds__(256) void gnb_apply_kernel(const GNBParams p, const
     const float xv = (float)xh[e];
     const float d = gnb_dyh((float)dh[e], xv, ss[2 * e], ss[2 * e + 1], p.act);
     o[e] = (f16)(k[3 * e] * d + k[3 * e + 1] * xv + k[3 * e + 2]);
+  }
+  if (add) {  // the f16 sum the separate add launch would have produced: f16(f16(dx) + g)
+    const uint4 ar = *reinterpret_cast<const uint4*>(add + pix * cs + co);
+    const f16x8 ah = *reinterpret_cast<const f16x8*>(&ar);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)o[e] + (float)ah[e]);
   }
   *reinterpret_cast<uint4*>(dst + pix * cs + co) = *reinterpret_cast<uint4*>(&o);
 }
@@ -817,7 +831,7 @@ int64_t gn_layernorm_bwd_workspace_bytes(int64_t M, int32_t C) {
   return blocks * 4 * 2 * C * 4;
 }
 int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const void* dy, void* dx, float* dgamma, float* dbeta, void* workspace,
-                         int64_t M, int32_t C, float eps) {
+                         int64_t M, int32_t C, float eps, const void* dx_add) {
   GN_REQUIRE(ctx && x && gamma && dy && dx && M > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LNB_MAXCH, "gn_layernorm_bwd: C must be a multiple of 8, <= %d", 64 * 8 * LNB_MAXCH);
   GN_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || workspace), "gn_layernorm_bwd: dgamma/dbeta come together and need a workspace");
   const int rpb = 64;
@@ -825,7 +839,7 @@ int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const vo
   float* part = dgamma ? (float*)workspace : nullptr;
   const int CC = C / 8;
 #define GN_LNB(CH, R) hipLaunchKernelGGL((layernorm_bwd_kernel<CH, R>), dim3((unsigned)blocks), dim3(256), 0, ctx->stream, (const f16*)x, \
-                                         (const f16*)gamma, (const f16*)dy, (f16*)dx, part, (long)M, C, eps, rpb)
+                                         (const f16*)gamma, (const f16*)dy, (f16*)dx, part, (long)M, C, eps, rpb, (const f16*)dx_add)
   if (CC <= 64) GN_LNB(1, 4);
   else if (CC <= 128) GN_LNB(2, 2);
   else if (CC <= 192) GN_LNB(3, 1);
@@ -847,11 +861,12 @@ int64_t gn_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
 }
 /* fwd_ws: the forward's workspace (gn_groupnorm_workspace_bytes) still holding scsh[B][C][2]; stats: [B][G][2] (mean, rstd) */
 int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy, void* dx, void* dx2, const float* scsh, const float* stats,
-                         float* dgamma, float* dbeta, void* workspace) {
+                         float* dgamma, float* dbeta, void* workspace, const void* dx_add, const void* dx2_add) {
   GN_REQUIRE(ctx && d && d->x && dy && scsh && stats && workspace && (dx || dx2), "gn_groupnorm_bwd: null pointer");
   GNBParams p;
   p.x = (const f16*)d->x; p.x2 = (const f16*)d->x2; p.dy = (const f16*)dy; p.gamma = (const f16*)d->gamma; p.beta = (const f16*)d->beta;
   p.dx = (f16*)dx; p.dx2 = (f16*)dx2; p.dgamma = dgamma; p.dbeta = dbeta;
+  p.dx_add = (const f16*)dx_add; p.dx2_add = (const f16*)dx2_add;
   p.B = d->B; p.HW = d->HW; p.C1 = d->C1; p.C2 = d->C2; p.C = d->C1 + d->C2; p.G = d->groups; p.cpg = p.C / p.G; p.act = d->act; p.eps = d->eps;
   GN_REQUIRE(p.C <= 4096 && p.C % 8 == 0 && p.C1 % 8 == 0, "gn_groupnorm_bwd: C <= 4096, C and C1 multiples of 8");
   int chunks = p.HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;

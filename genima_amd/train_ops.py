@@ -181,13 +181,14 @@ def attention_bwd(E: Engine, q, q_off: int, k, k_off: int, v, o, d_o, lse, heads
 
 
 def layernorm_bwd(E: Engine, x, gamma, dy, dgamma: Optional[torch.Tensor] = None, dbeta: Optional[torch.Tensor] = None,
-                  eps: float = 1e-5) -> torch.Tensor:
-    """dgamma / dbeta: f32 [C] views inside the flat gradient buffer (accumulated), or None."""
+                  eps: float = 1e-5, add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dgamma / dbeta: f32 [C] views inside the flat gradient buffer (accumulated), or None.  add: the gradient x already holds from
+    another branch (same shape): the result is their f16 sum, without a separate add launch."""
     Cc = x.shape[-1]
     M = x.numel() // Cc
     dx = torch.empty_like(x)
     ws = E._workspace(int(E.lib.gn_layernorm_bwd_workspace_bytes(M, Cc))) if dgamma is not None else None
-    check(E.lib.gn_layernorm_bwd(E._ctx, _ptr(x), _ptr(gamma), _ptr(dy), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), M, Cc, eps), "gn_layernorm_bwd")
+    check(E.lib.gn_layernorm_bwd(E._ctx, _ptr(x), _ptr(gamma), _ptr(dy), _ptr(dx), _ptr(dgamma), _ptr(dbeta), _ptr(ws), M, Cc, eps, _ptr(add)), "gn_layernorm_bwd")
     return dx
 
 
@@ -215,15 +216,15 @@ def groupnorm_fwd_train(E: Engine, x, gamma, beta, groups: int, eps: float, act:
 
 
 def groupnorm_bwd(E: Engine, s: GNSaved, dy, need_dx: bool = True, need_dx2: bool = True, dgamma: Optional[torch.Tensor] = None,
-                  dbeta: Optional[torch.Tensor] = None):
-    """-> (dx, dx2).  dgamma / dbeta: f32 [C] views (accumulated), or None."""
+                  dbeta: Optional[torch.Tensor] = None, add: Optional[torch.Tensor] = None, add2: Optional[torch.Tensor] = None):
+    """-> (dx, dx2).  dgamma / dbeta: f32 [C] views (accumulated), or None.  add / add2: gradients x / x2 already hold (summed in)."""
     d = s.desc
     dx = torch.empty_like(s.x) if need_dx else None
     dx2 = torch.empty_like(s.x2) if (s.x2 is not None and need_dx2) else None
     Cc = d.C1 + d.C2
     ws = E._workspace(int(E.lib.gn_groupnorm_bwd_workspace_bytes(d.B, d.HW, Cc)))
-    check(E.lib.gn_groupnorm_bwd(E._ctx, C.byref(d), _ptr(dy), _ptr(dx), _ptr(dx2), _ptr(s.scsh), _ptr(s.stats), _ptr(dgamma), _ptr(dbeta), _ptr(ws)),
-          "gn_groupnorm_bwd")
+    check(E.lib.gn_groupnorm_bwd(E._ctx, C.byref(d), _ptr(dy), _ptr(dx), _ptr(dx2), _ptr(s.scsh), _ptr(s.stats), _ptr(dgamma), _ptr(dbeta), _ptr(ws),
+                                 _ptr(add if need_dx else None), _ptr(add2 if dx2 is not None else None)), "gn_groupnorm_bwd")
     return dx, dx2
 
 

@@ -337,11 +337,16 @@ class Graph:
 
         def bw(dy):
             tr = net.G is not None
+            # gradients x / x2 already hold (the residual branch) are summed inside the apply kernel, not by an add launch
+            cur = x.cell[0] if x.needs else None
+            cur2 = x2.cell[0] if (x2 is not None and x2.needs) else None
+            assert (cur is None or cur.is_contiguous()) and (cur2 is None or cur2.is_contiguous())
             dx, dx2 = T.groupnorm_bwd(E, saved, dy, need_dx=True, need_dx2=x2 is not None and x2.needs,
-                                      dgamma=net.G[wn] if tr else None, dbeta=net.G[bn] if tr else None)
-            self.acc(x, dx)
-            if x2 is not None:
-                self.acc(x2, dx2)
+                                      dgamma=net.G[wn] if tr else None, dbeta=net.G[bn] if tr else None, add=cur, add2=cur2)
+            if x.needs:
+                x.cell[0] = dx
+            if x2 is not None and x2.needs:
+                x2.cell[0] = dx2
         return self._push(out, bw)
 
     def layernorm(self, net: FrozenParams, x: Var, wn: str, bn: str, eps: float = 1e-5) -> Var:
@@ -351,7 +356,12 @@ class Graph:
 
         def bw(dy):
             tr = net.G is not None
-            self.acc(x, T.layernorm_bwd(E, x.t, W[wn], dy, net.G[wn] if tr else None, net.G[bn] if tr else None, eps))
+            if x.needs:
+                cur = x.cell[0]
+                assert cur is None or cur.is_contiguous()
+                x.cell[0] = T.layernorm_bwd(E, x.t, W[wn], dy, net.G[wn] if tr else None, net.G[bn] if tr else None, eps, add=cur)
+            elif tr:
+                T.layernorm_bwd(E, x.t, W[wn], dy, net.G[wn], net.G[bn], eps)
         return self._push(out, bw)
 
     # ---- attention: flash forward, materialised batched-GEMM backward (P recomputed from q, k)

@@ -245,12 +245,13 @@ int32_t gn_geglu_bwd(gn_ctx* ctx, const void* dy, const void* hg, void* dhg, int
 int32_t gn_softmax_bwd(gn_ctx* ctx, const void* p, void* dp, int64_t rows, int32_t cols, int64_t ld, float scale);
 int64_t gn_layernorm_bwd_workspace_bytes(int64_t M, int32_t C);
 /* dx from (x, gamma, dy); dgamma/dbeta (f32, dbeta == dgamma + C, accumulated) optional */
+/* dx_add (optional, may alias dx): the gradient x already holds from another branch; dx = f16(f16(dx) + dx_add) */
 int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const void* dy, void* dx, float* dgamma, float* dbeta,
-                         void* workspace, int64_t M, int32_t C, float eps);
+                         void* workspace, int64_t M, int32_t C, float eps, const void* dx_add);
 int64_t gn_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C);
 /* backward of gn_groupnorm_fwd(d) run with save_stats/save_scsh; dx / dx2 follow d->x / d->x2 (either may be NULL) */
 int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy, void* dx, void* dx2, const float* scsh,
-                         const float* stats, float* dgamma, float* dbeta, void* workspace);
+                         const float* stats, float* dgamma, float* dbeta, void* workspace, const void* dx_add, const void* dx2_add);
 int32_t gn_zero_upsample2x(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C); /* stride-2 dgrad */
 int32_t gn_sumpool2x2(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C);       /* upsample dgrad */
 int32_t gn_mse_loss(gn_ctx* ctx, const void* pred, const void* target, void* dpred, float* loss_out, void* workspace,

@@ -209,6 +209,10 @@ def test_layernorm_backward(engine):
     assert_close(dx, x.grad, what="layernorm dx")
     assert_close(dgb[:C], gm.grad, what="layernorm dgamma")
     assert_close(dgb[C:], bt.grad, what="layernorm dbeta")
+    # gradient accumulation fused into the kernel: exactly the f16 sum a separate add launch gives
+    held = h(q16(torch.randn(M, C, generator=g(5))))
+    dx_acc = T.layernorm_bwd(engine, h(x.detach()), h(gm.detach()), h(dy), add=held)
+    assert torch.equal(dx_acc, (dx.float() + held.float()).half())
 
 
 @pytest.mark.parametrize("act,concat", [(1, False), (0, False), (1, True)])
@@ -234,6 +238,12 @@ def test_groupnorm_backward(engine, act, concat):
         assert_close(dx2, nhwc(x2.grad), rel=2e-3, what="groupnorm dx2")
     assert_close(dgb[:C], gm.grad, rel=2e-3, what="groupnorm dgamma")
     assert_close(dgb[C:], bt.grad, rel=2e-3, what="groupnorm dbeta")
+    held1 = h(q16(torch.randn(dx1.shape, generator=g(6))))
+    held2 = h(q16(torch.randn(dx2.shape, generator=g(7)))) if concat else None
+    a1, a2 = T.groupnorm_bwd(engine, saved, h(nhwc(dy)), add=held1, add2=held2)
+    assert torch.equal(a1, (dx1.float() + held1.float()).half())
+    if concat:
+        assert torch.equal(a2, (dx2.float() + held2.float()).half())
 
 
 # ---------------------------------------------------------------------------------------------------- loss + optimizer
