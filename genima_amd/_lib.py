@@ -125,7 +125,7 @@ SIGNATURES = {
     "gn_mse_loss": (_I32, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F]),
     "gn_sumsq_f32": (_I32, [_P, _P, _I64, _P, _P]),
     "gn_clip_coef": (_I32, [_P, _P, _P, _F, _F]),
-    "gn_adamw_flat": (_I32, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _P, _F]),
+    "gn_adamw_flat": (_I32, [_P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _F, _I32, _P, _F, _P, _I32]),
     "gn_color_jitter_workspace_bytes": (_I64, [_I32]),
     "gn_color_jitter": (_I32, [_P, _P, _P, _I32, _I64, _I32, _P, _P, _P]),
     "gn_reflect_pad_crop": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),

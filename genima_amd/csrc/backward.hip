@@ -649,22 +649,29 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
   __syncthreads();
   if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n, float lr,
-                             float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ gscale_dev, float gscale) {
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                             float b1, float b2, float eps, float wd, float bc1, float bc2, const float* __restrict__ gscale_dev, float gscale,
+                             f16* __restrict__ half_out, int zero_grad) {
   // torch.optim.AdamW (diffusion/train_controlnet_genima.py:1178-1185): decoupled weight decay, bias-corrected moments.
   // gscale_dev (optional, device scalar): the global-norm clip coefficient computed on the device (no host sync).
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  // half_out (optional): the f16 working copy of the parameters, refreshed here instead of by a cast pass over the fp32 master;
+  // zero_grad: the gradient is cleared in the pass that consumed it (optimizer.zero_grad(), also when the step is skipped)
   if (i >= n) return;
+  const float graw = g[i];
+  if (zero_grad) g[i] = 0.0f;
   if (gscale_dev && gscale_dev[2] != 0.0f) return;  // non-finite gradients: skip the step (torch.cuda.amp.GradScaler.step)
   const float gs = gscale * (gscale_dev ? gscale_dev[0] : 1.0f);
-  const float gi = g[i] * gs;
+  const float gi = graw * gs;
   float pi = p[i] * (1.0f - lr * wd);
   const float mi = b1 * m[i] + (1.0f - b1) * gi;
   const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
   m[i] = mi;
   v[i] = vi;
   const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
-  p[i] = pi - (lr / bc1) * (mi / denom);
+  const float pn = pi - (lr / bc1) * (mi / denom);
+  p[i] = pn;
+  if (half_out) half_out[i] = (f16)pn;
 }
 __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float* __restrict__ out, float max_norm, float inv_scale) {
   // out[0] = min(1, max_norm / (norm + 1e-6)), out[1] = norm of the unscaled gradients (torch.nn.utils.clip_grad_norm_ after
@@ -935,12 +942,12 @@ int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_nor
 }
 
 /* fused AdamW over flat f32 buffers; step >= 1; grad is multiplied by grad_scale * (clip_dev ? clip_dev[0] : 1) */
-int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, int32_t step, const float* clip_dev, float grad_scale) {
+int32_t gn_adamw_flat(gn_ctx* ctx, float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t step, const float* clip_dev, float grad_scale, void* half_out, int32_t zero_grad) {
   GN_REQUIRE(ctx && param && grad && m && v && n > 0 && step >= 1, "gn_adamw_flat: bad arguments");
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(nblk(n)), dim3(256), 0, ctx->stream, param, grad, m, v, (long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2,
-                     clip_dev, grad_scale);
+                     clip_dev, grad_scale, (f16*)half_out, zero_grad);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

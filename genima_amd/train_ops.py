@@ -266,8 +266,11 @@ def clip_coef(E: Engine, sumsq_t: torch.Tensor, clip: torch.Tensor, max_norm: fl
     return clip
 
 
-def adamw(E: Engine, param, grad, m, v, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
-    check(E.lib.gn_adamw_flat(E._ctx, _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps, wd, step, _ptr(clip), grad_scale), "gn_adamw_flat")
+def adamw(E: Engine, param, grad, m, v, lr, beta1, beta2, eps, wd, step: int, clip: Optional[torch.Tensor] = None, grad_scale: float = 1.0,
+          half_out: Optional[torch.Tensor] = None, zero_grad: bool = False):
+    """half_out: f16 working copy refreshed in the same pass (no cast pass over the master); zero_grad: the gradient is cleared in the same pass."""
+    check(E.lib.gn_adamw_flat(E._ctx, _ptr(param), _ptr(grad), _ptr(m), _ptr(v), param.numel(), lr, beta1, beta2, eps, wd, step, _ptr(clip), grad_scale,
+                              _ptr(half_out), int(zero_grad)), "gn_adamw_flat")
 
 
 def latent_sample(E: Engine, moments: torch.Tensor, eps: torch.Tensor, C_lat: int, scale: float, ld_out: int = 8) -> torch.Tensor:

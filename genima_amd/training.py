@@ -674,10 +674,10 @@ class ControlNetTrainer:
         T.sumsq(E, cn.grad, self._ss)
         T.clip_coef(E, self._ss, self._clip, self.max_grad_norm, inv)
         self.opt_step += 1
+        # one pass: AdamW on the fp32 master, the f16 working copy refreshed from the new values, the gradient cleared
         T.adamw(E, cn.master, cn.grad, cn.exp_avg, cn.exp_avg_sq, self.current_lr(), self.betas[0], self.betas[1], self.eps, self.wd,
-                self.opt_step, self._clip, inv)
-        cn.sync_half()
-        cn.zero_grad()
+                self.opt_step, self._clip, inv, half_out=cn.half, zero_grad=True)
+        cn._wt.clear()  # derived (transposed / rotated) weight copies are stale
 
     def current_lr(self) -> float:
         return self.lr * (float(self.lr_lambda(self.sched_step)) if self.lr_lambda is not None else 1.0)

@@ -261,8 +261,11 @@ int32_t gn_sumsq_f32(gn_ctx* ctx, const float* x, int64_t n, float* out, void* w
  * norm = sqrt(sumsq[0]) * inv_scale; clip[0] = min(1, max_norm / (norm + 1e-6)); clip[1] = norm; clip[2] = 1 when non-finite
  * (gn_adamw_flat given this clip buffer then leaves the parameters untouched, as GradScaler.step does) */
 int32_t gn_clip_coef(gn_ctx* ctx, const float* sumsq, float* clip, float max_norm, float inv_scale);
-int32_t gn_adamw_flat(gn_ctx* ctx, float* param, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
-                      float beta2, float eps, float weight_decay, int32_t step, const float* clip_dev, float grad_scale);
+/* half_out (optional): f16 [n] working copy of the parameters, refreshed in the same pass; zero_grad: grad is cleared in the same pass
+ * (optimizer.zero_grad(), also when the step is skipped) */
+int32_t gn_adamw_flat(gn_ctx* ctx, float* param, float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int32_t step, const float* clip_dev, float grad_scale,
+                      void* half_out, int32_t zero_grad);
 /* VAE posterior sample of the train step (diffusion/train_controlnet_genima.py:1329-1332): moments [p, ld_moments] = (mean | logvar),
  * out[p, 0:C] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale, out[p, C:ld_out] = 0 */
 int32_t gn_latent_sample(gn_ctx* ctx, const void* moments, const void* eps, void* out, int64_t pixels, int32_t C,
