@@ -66,6 +66,15 @@ class GroupNormDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
+        ("R", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("ld_dy", C.c_int64), ("ld_x", C.c_int64), ("ld_dw", C.c_int64),
+        ("conv", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("tile", C.c_int32), ("splitk", C.c_int32),
+    ]
+
+
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/genima_hip.h declares (tests/test_abi.py checks the two agree)
@@ -108,6 +117,8 @@ SIGNATURES = {
     "gn_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_transpose2d": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
     "gn_im2col_t": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
+    "gn_wgrad_workspace_bytes": (_I64, [C.POINTER(WgradDesc)]),
+    "gn_wgrad": (_I32, [_P, C.POINTER(WgradDesc)]),
     "gn_transpose2d_colsum": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _P, _I32, _P, _I32, _P]),
     "gn_colsum_workspace_bytes": (_I64, [_I32, _I32, _I32]),
     "gn_colsum_f32": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I64, _P, _I32]),

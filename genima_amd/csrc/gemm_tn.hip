@@ -1,0 +1,271 @@
+// Weight-gradient GEMM on operands in their NATURAL layout (no transposed copies, no im2col^T):
+//   dW[n, k] += sum_r dY[r, n] * X[r, k]            (Linear; conv: X[r, k] = x[pixel(r) + tap(k), channel(k)], zero outside the image)
+// Both operands are "reduction-major" -- the summed index r (a pixel / token) is the slow one -- which is the layout the forward pass
+// leaves them in.  The previous path transposed dY and X (or materialised im2col^T) so that the forward kernel's K-contiguous
+// loaders could read them: 435 transpose + 28 im2col^T launches and ~4.4 ms per train step.  Here the LDS image of a K tile is simply
+// 64 rows of dY (BM channels each) and 64 rows of X (BN channels each), filled by LDS-DMA, and the MFMA operands -- 8 consecutive r
+// for one channel -- come out of LDS through gfx950's transpose read: ds_read_b64_tr_b16 hands lane c of a 16-lane group column c
+// of a 4-row x 16-column block whose rows the group's lanes address themselves (tools/probes/ds_read_tr_probe.hip pins the
+// semantics), so two reads give a lane its v_mfma_f32_32x32x16_f16 fragment.
+// Bank conflicts: a wave's transpose read touches 8 rows x two 32-byte column pairs; the rows of the image are swizzled at 32-byte
+// pair granularity (applied on the SOURCE side of the lane-linear LDS-DMA) so that the 16 (row, pair) pieces spread over all banks.
+// Reference op: the weight gradient autograd computes for nn.Linear / nn.Conv2d inside accelerator.backward(loss)
+// (diffusion/train_controlnet_genima.py:1391).
+#include "gemm_common.h"
+
+namespace {
+
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) h4* lds_h4_ptr;
+struct H8 { h4 lo, hi; };  // two transpose reads = one MFMA operand (8 consecutive reduction rows of one channel)
+
+struct TnParams {
+  GemmParams g;   // a = dY, w = X; M = dW rows (dY columns), N = dW columns, K = R (reduction rows); out = dW (f32, accumulate)
+  int B, H, W, C, KH, KW, stride, pad, Ho, Wo;  // conv geometry (X = NHWC activations)
+};
+
+// chunk swizzle of a row of CPR 16-byte chunks: XOR on the 32-byte pair index so that rows r..r+3 and r+8..r+11 (one transpose read
+// of a wave) land on different banks
+template <int CPR>
+__device__ __forceinline__ int tn_swz(int row) {
+  // (only row bits 0, 1 and 3 may enter: a fragment's second read is 4 rows further, the next k16 step 16 rows further, and both
+  //  must keep the swizzle so that one base address + immediates walks the tile)
+  if constexpr (CPR >= 16) return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-byte rows: every row starts at bank 0
+  else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;              // 128-byte rows: odd rows already sit on the other bank half
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) void gemm_tn_kernel(const TnParams tp) {
+  const GemmParams& p = tp.g;
+  constexpr int NW = 4, WM = 2, WN = 2;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int CPA = BM / 8, CPB = BN / 8;            // 16-byte chunks per LDS row
+  constexpr int RPA = 64 / CPA, RPB = 64 / CPB;        // rows one DMA instruction (64 lanes x 16 B) fills
+  constexpr int GA = 64 / RPA / NW, GB = 64 / RPB / NW;  // DMA instructions per wave per K tile
+  constexpr int A_BYTES = 64 * BM * 2, B_BYTES = 64 * BN * 2;
+  static_assert(TM >= 1 && TN >= 1 && GA >= 1 && GB >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int tile_n = blockIdx.x % p.tiles_n, tile_m = blockIdx.x / p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;   // dW row / column origin of this workgroup
+  const int z = blockIdx.y;
+  const long rbeg = (long)z * p.kper;
+  const long rend = min((long)p.K, rbeg + p.kper);
+  const int nk = (int)((rend - rbeg + 63) / 64);
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- loader state.  A piece i of this wave: LDS rows (wave + NW * i) * RPA + lane / CPA, physical chunk lane % CPA
+  const int arow = lane / CPA, apc = lane % CPA;
+  const int brow = lane / CPB, bpc = lane % CPB;
+  // conv: the column tile lies inside one tap (C % BN == 0)
+  int tap_dy = 0, tap_dx = 0, c0 = n0;
+  if constexpr (CONV) {
+    const int tap = n0 / tp.C;
+    c0 = n0 - tap * tp.C;
+    tap_dy = tap / tp.KW;
+    tap_dx = tap - tap_dy * tp.KW;
+  }
+  // conv: (b, oy, ox) of the row each B piece loads, advanced by 64 rows per K tile without divisions
+  int pb[GB], py[GB], px[GB];
+  const int q64 = CONV ? 64 / tp.Wo : 0, r64 = CONV ? 64 % tp.Wo : 0;
+  if constexpr (CONV) {
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const long r = rbeg + (wave + NW * i) * RPB + brow;
+      const int hw = tp.Ho * tp.Wo;
+      const int b = (int)(r / hw), rem = (int)(r - (long)b * hw);
+      pb[i] = b; py[i] = rem / tp.Wo; px[i] = rem - py[i] * tp.Wo;
+    }
+  }
+
+  auto dma_tile = [&](int buf, long r0) {
+    unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+    unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int lrow = (wave + NW * i) * RPA + arow;
+      const long r = r0 + lrow;
+      const int col = m0 + ((apc ^ tn_swz<CPA>(lrow)) << 3);
+      const unsigned voff = (r < rend && col < p.M) ? (unsigned)((r * p.lda + col) * 2) : kOOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int lrow = (wave + NW * i) * RPB + brow;
+      const long r = r0 + lrow;
+      const int lc = (bpc ^ tn_swz<CPB>(lrow)) << 3;
+      unsigned voff = kOOB;
+      if constexpr (CONV) {
+        const int iy = py[i] * tp.stride - tp.pad + tap_dy, ix = px[i] * tp.stride - tp.pad + tap_dx;
+        if (r < rend && n0 + lc < p.N && (unsigned)iy < (unsigned)tp.H && (unsigned)ix < (unsigned)tp.W)
+          voff = (unsigned)(((((long)pb[i] * tp.H + iy) * tp.W + ix) * tp.C + c0 + lc) * 2);
+        // next K tile: 64 rows further
+        px[i] += r64; py[i] += q64;
+        if (px[i] >= tp.Wo) { px[i] -= tp.Wo; ++py[i]; }
+        while (py[i] >= tp.Ho) { py[i] -= tp.Ho; ++pb[i]; }
+      } else {
+        if (r < rend && n0 + lc < p.N) voff = (unsigned)((r * p.ldw + n0 + lc) * 2);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment addresses: lane (i = lane & 15, g = (lane >> 4) & 1, hb = lane >> 5) of the transpose read supplies the 8 bytes at
+  // row 8 hb + i / 4 (+ 4 for the second read, + 16 per k16 step), columns 16 g + 4 (i % 4) of a 32-column tile
+  const int ti = lane & 15, tg = (lane >> 4) & 1;
+  const int frow = 8 * hi + (ti >> 2);
+  auto frag_off = [&](int cpr_swz, int col, int rowb) {  // byte offset inside a tile image
+    const int chunk = (col >> 3) ^ cpr_swz;
+    return frow * rowb + (chunk << 4) + ((col & 7) << 1);
+  };
+  int aoff[TM], boff[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) aoff[i] = frag_off(tn_swz<CPA>(frow), wm * WTM + i * 32 + 16 * tg + 4 * (ti & 3), BM * 2);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) boff[j] = frag_off(tn_swz<CPB>(frow), wn * WTN + j * 32 + 16 * tg + 4 * (ti & 3), BN * 2);
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
+
+  dma_tile(0, rbeg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) dma_tile(cur ^ 1, rbeg + (long)(kt + 1) * 64);
+    const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+    const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f16x8 fa[TM], fw[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const unsigned char* q = As + aoff[i] + kk * 16 * (BM * 2);
+        const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)q);
+        const h4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(q + 4 * (BM * 2)));
+        fa[i] = __builtin_bit_cast(f16x8, H8{lo, hi4});
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const unsigned char* q = Bs + boff[j] + kk * 16 * (BN * 2);
+        const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)q);
+        const h4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(q + 4 * (BN * 2)));
+        fw[j] = __builtin_bit_cast(f16x8, H8{lo, hi4});
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  GemmParams pe = p;
+  gemm_epilogue<TM, TN>(pe, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+}
+
+// split-K: dW += sum of the f32 partial slabs (fixed order)
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long M, int N, long ldo, int splitk) {
+  const long n4 = N >> 2;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * n4) return;
+  const long m = idx / n4;
+  const int nb = (int)(idx - m * n4) * 4;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int zz = 0; zz < splitk; ++zz) s += *reinterpret_cast<const f32x4*>(ws + ((long)zz * M + m) * N + nb);
+  float* o = out + m * ldo + nb;
+  *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + s;
+}
+
+struct TnPlan { int bm, bn, splitk; long kper; };
+TnPlan tn_plan(const gn_wgrad_desc* d) {
+  TnPlan pl;
+  const bool small = d->tile == 2 || (d->tile == 0 && (d->N < 128 || d->K < 128 || (d->conv && d->C % 128 != 0)));
+  pl.bm = pl.bn = small ? 64 : 128;
+  const long blocks = ((d->N + pl.bm - 1) / pl.bm) * ((d->K + pl.bn - 1) / pl.bn);
+  int sk = d->splitk;
+  if (sk <= 0) {  // a handful of output tiles under a reduction over every pixel of the batch: the row split supplies the parallelism
+    sk = (int)((1024 + blocks - 1) / blocks);
+    const long maxsk = d->R / 512;
+    if (sk > maxsk) sk = (int)maxsk;
+    if (sk > 256) sk = 256;
+    if (sk < 1) sk = 1;
+  }
+  long kper = ((d->R + sk - 1) / sk + 63) / 64 * 64;
+  pl.splitk = (int)((d->R + kper - 1) / kper);
+  pl.kper = kper;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" int64_t gn_wgrad_workspace_bytes(const gn_wgrad_desc* d) {
+  if (!d) return 0;
+  const TnPlan pl = tn_plan(d);
+  return pl.splitk > 1 ? (int64_t)pl.splitk * d->N * d->K * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
+  GN_REQUIRE(ctx && d && d->dy && d->x && d->dw, "gn_wgrad: null pointer");
+  GN_REQUIRE(d->R > 0 && d->N > 0 && d->K > 0 && d->N % 8 == 0 && d->K % 8 == 0 && d->ld_dy % 8 == 0 && d->ld_dy >= d->N && d->ld_dw % 4 == 0 &&
+             d->ld_dw >= d->K, "gn_wgrad: N, K, ld_dy must be multiples of 8 and the strides cover the rows");
+  GN_REQUIRE(((uintptr_t)d->dy & 15) == 0 && ((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->dw & 15) == 0, "gn_wgrad: 16-byte alignment");
+  TnParams tp;
+  GemmParams& p = tp.g;
+  p = GemmParams();
+  p.a = (const f16*)d->dy; p.w = (const f16*)d->x; p.out = (f16*)d->dw; p.ws = (float*)d->workspace;
+  p.M = (int)d->N; p.N = (int)d->K; p.K = (int)d->R;
+  p.lda = d->ld_dy; p.ldo = d->ld_dw;
+  p.out_mode = GN_OUT_F32; p.accumulate = 1; p.act = GN_ACT_NONE; p.out_scale = 1.0f; p.rpb = (int)d->N;
+  GN_REQUIRE((uint64_t)d->R * d->ld_dy * 2 < 0xFFFFFF00ull, "gn_wgrad: dY too large for 32-bit buffer offsets");
+  p.a_bytes = (unsigned)((uint64_t)d->R * d->ld_dy * 2);
+  if (d->conv) {
+    GN_REQUIRE(d->C > 0 && d->C % 64 == 0 && d->K == (int64_t)d->KH * d->KW * d->C && d->R == (int64_t)d->B * d->Ho * d->Wo && d->stride >= 1,
+               "gn_wgrad(conv): C %% 64 == 0, K = KH*KW*C, R = B*Ho*Wo");
+    const uint64_t xb = (uint64_t)d->B * d->H * d->W * d->C * 2;
+    GN_REQUIRE(xb < 0xFFFFFF00ull, "gn_wgrad(conv): x too large for 32-bit buffer offsets");
+    p.w_bytes = (unsigned)xb;
+    tp.B = d->B; tp.H = d->H; tp.W = d->W; tp.C = d->C; tp.KH = d->KH; tp.KW = d->KW; tp.stride = d->stride; tp.pad = d->pad; tp.Ho = d->Ho; tp.Wo = d->Wo;
+  } else {
+    GN_REQUIRE(d->ld_x % 8 == 0 && d->ld_x >= d->K && (uint64_t)d->R * d->ld_x * 2 < 0xFFFFFF00ull, "gn_wgrad: ld_x must be a multiple of 8, >= K, x within 4 GB");
+    p.ldw = d->ld_x;
+    p.w_bytes = (unsigned)((uint64_t)d->R * d->ld_x * 2);
+    tp.B = tp.H = tp.W = tp.C = tp.KH = tp.KW = tp.stride = tp.pad = tp.Ho = tp.Wo = 0;
+  }
+  const TnPlan pl = tn_plan(d);
+  if (d->conv) GN_REQUIRE(d->C % pl.bn == 0, "gn_wgrad(conv): C (%d) must be a multiple of the column tile (%d)", d->C, pl.bn);
+  p.splitk = pl.splitk; p.kper = (int)pl.kper;
+  if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_wgrad: split over rows (%d) needs a workspace of gn_wgrad_workspace_bytes()", pl.splitk);
+  p.tiles_m = (int)((d->N + pl.bm - 1) / pl.bm); p.tiles_n = (int)((d->K + pl.bn - 1) / pl.bn);
+  const dim3 grid(p.tiles_m * p.tiles_n, pl.splitk, 1);
+  if (pl.bm == 128) {
+    if (d->conv) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, true>), grid, dim3(256), 0, ctx->stream, tp);
+    else hipLaunchKernelGGL((gemm_tn_kernel<128, 128, false>), grid, dim3(256), 0, ctx->stream, tp);
+  } else {
+    if (d->conv) hipLaunchKernelGGL((gemm_tn_kernel<64, 64, true>), grid, dim3(256), 0, ctx->stream, tp);
+    else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, false>), grid, dim3(256), 0, ctx->stream, tp);
+  }
+  GN_LAUNCH_CHECK();
+  if (pl.splitk > 1) {
+    const long total = (long)d->N * (d->K >> 2);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d->workspace, d->dw, (long)d->N,
+                       (int)d->K, (long)d->ld_dw, pl.splitk);
+    GN_LAUNCH_CHECK();
+  }
+  return GN_OK;
+}

@@ -9,7 +9,7 @@ from typing import Optional
 
 import torch
 
-from ._lib import OUT_F32, OUT_ROWMAJOR, AttnBwdDesc, GemmDesc, GroupNormDesc, check
+from ._lib import OUT_F32, OUT_ROWMAJOR, AttnBwdDesc, GemmDesc, GroupNormDesc, WgradDesc, check
 from .engine import Engine, _ptr
 
 F16, F32 = torch.float16, torch.float32
@@ -76,6 +76,83 @@ def transpose2d(E: Engine, x: torch.Tensor, rows: int, cols: int, *, ld_in: Opti
         out = (torch.zeros if ld_out != rows else torch.empty)(shape, dtype=F16, device=E.device)
     check(E.lib.gn_transpose2d(E._ctx, x.data_ptr() + 2 * in_off, _ptr(out), rows, cols, ld_in, ld_out, batch, in_bs, cols * ld_out), "gn_transpose2d")
     return out
+
+
+def wgrad(E: Engine, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, ksize: int = 0, stride: int = 1, pad: int = 0, tile: int = 0):
+    """dw [N, K] f32 += dy^T . X with both operands in their forward layout (csrc/gemm_tn.hip: no transposed copies).
+    Linear (ksize == 0): dy [R, N], x [R, K].  Conv: dy [B, Ho, Wo, N] (or [R, N]), x NHWC [B, H, W, C], K = ksize^2 * C."""
+    d = WgradDesc()
+    N = dy.shape[-1]
+    R = dy.numel() // N
+    d.dy, d.x, d.dw = _ptr(dy), _ptr(x), _ptr(dw)
+    d.R, d.N, d.ld_dy, d.ld_dw, d.tile = R, N, N, dw.stride(0), tile
+    if ksize:
+        B, H, W, Cc = x.shape
+        Ho, Wo = (H + 2 * pad - ksize) // stride + 1, (W + 2 * pad - ksize) // stride + 1
+        assert R == B * Ho * Wo, (R, B, Ho, Wo)
+        d.conv, d.B, d.H, d.W, d.C, d.KH, d.KW, d.stride, d.pad, d.Ho, d.Wo = 1, B, H, W, Cc, ksize, ksize, stride, pad, Ho, Wo
+        d.K = ksize * ksize * Cc
+    else:
+        d.K = x.shape[-1]
+        d.ld_x = d.K
+        assert x.numel() // d.K == R
+    if tile == 0:
+        from .engine import _tune_table
+        key = f"wg|{int(d.conv)}|{R}|{N}|{int(d.K)}|{int(d.C)}|{int(d.KH)}|{int(d.stride)}"
+        plan = _tune_table().get(key)
+        if plan is None and E.autotune:
+            plan = _tune_wgrad(E, d, dw, key)
+        if plan:
+            d.tile, d.splitk = plan % 100, plan // 100
+    _run_wgrad(E, d)
+    return dw
+
+
+def _run_wgrad(E: Engine, d: WgradDesc):
+    nb = int(E.lib.gn_wgrad_workspace_bytes(C.byref(d)))
+    d.workspace = E._workspace(nb).data_ptr() if nb > 0 else None
+    check(E.lib.gn_wgrad(E._ctx, C.byref(d)), "gn_wgrad")
+
+
+def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str) -> int:
+    """Race the two tiles and a few row splits of gn_wgrad on this shape (into a scratch copy of dw) and remember the winner in the
+    GEMM tune table (value = tile + 100 * row split, split 0 = the library's heuristic)."""
+    from . import engine as _eng
+    real = d.dw
+    scratch = torch.empty_like(dw)
+    d.dw = scratch.data_ptr()
+    best, best_ms = 0, float("inf")
+    e0, e1 = E.event(), E.event()
+    try:
+        for tile in (1, 2):
+            if tile == 1 and d.conv and d.C % 128 != 0:
+                continue
+            for sk in (0, 64, 32, 16, 8):
+                if sk and sk * 512 > d.R:
+                    continue
+                d.tile, d.splitk = tile, sk
+                _run_wgrad(E, d)
+                ms = float("inf")
+                for _ in range(2):
+                    E.event_record(e0)
+                    for _ in range(3):
+                        _run_wgrad(E, d)
+                    E.event_record(e1)
+                    ms = min(ms, E.event_elapsed_ms(e0, e1))
+                if ms < best_ms:
+                    best, best_ms = tile + 100 * sk, ms
+    finally:
+        d.dw = real
+        E.lib.gn_event_destroy(e0)
+        E.lib.gn_event_destroy(e1)
+    _eng._tune_table()[key] = best
+    _eng._tune_dirty[0] = True
+    return best
+
+
+def wgrad_ok(N: int, K: int, conv_C: int = 0) -> bool:
+    """Shapes gn_wgrad takes (the others keep the transposed-copy GEMM path)."""
+    return N % 8 == 0 and K % 8 == 0 and (conv_C == 0 or conv_C % 64 == 0)
 
 
 def transpose2d_colsum(E: Engine, x: torch.Tensor, rows: int, cols: int, sums) -> torch.Tensor:

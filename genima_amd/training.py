@@ -216,14 +216,19 @@ class Graph:
             dy2 = dy.view(M, N)
             self.acc(residual, dy)
             if net.G is not None:
-                dyt = T.transpose2d_colsum(E, dy2, M, N, [(net.G[bn], 1)] if bn else [])  # the bias gradient rides on the transpose
-                if self._xt[0] is x.t:  # the previous backward op consumed the same input (q|k and v projections of one LayerNorm)
-                    xt = self._xt[1]
+                if T.wgrad_ok(N, K) and M % 8 == 0:  # dW += dY^T X straight from the row-major operands (csrc/gemm_tn.hip)
+                    T.wgrad(E, dy2, x.t.view(M, K), net.G[wn])
+                    if bn:
+                        T.colsum(E, dy2, net.G[bn], 1, M, N, N)
                 else:
-                    xt = T.transpose2d(E, x.t.view(M, K), M, K)
-                    self._xt = (x.t, xt)
-                Mp = dyt.shape[1]
-                T.gemm(E, dyt, xt, net.G[wn], N, K, Mp, Mp, Mp, K, f32_out=True, accumulate=True)
+                    dyt = T.transpose2d_colsum(E, dy2, M, N, [(net.G[bn], 1)] if bn else [])  # the bias gradient rides on the transpose
+                    if self._xt[0] is x.t:  # the previous backward op consumed the same input (q|k and v projections of one LayerNorm)
+                        xt = self._xt[1]
+                    else:
+                        xt = T.transpose2d(E, x.t.view(M, K), M, K)
+                        self._xt = (x.t, xt)
+                    Mp = dyt.shape[1]
+                    T.gemm(E, dyt, xt, net.G[wn], N, K, Mp, Mp, Mp, K, f32_out=True, accumulate=True)
             if x.needs:
                 self.acc_gemm(x, lambda cur: E.linear(dy2, net.wt(wn), residual=None if cur is None else cur.view(M, K)).view(x.t.shape))
         return self._push(out, bw)
@@ -257,11 +262,17 @@ class Graph:
             if net.G is not None:
                 assert x2 is None and not upsample2x, "weight gradients of concat / upsample convs are not needed by the ControlNet"
                 assert M % 8 == 0, "conv wgrad needs B*Ho*Wo to be a multiple of 8"
-                dyt = T.transpose2d_colsum(E, dy2, M, Cout, [(net.dshift[prefix] if sh_var is not None else None, B),
-                                                             (net.G[bn] if bn else None, 1)])  # time-shift and bias gradients
-                cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)
+                sums = [(net.dshift[prefix] if sh_var is not None else None, B), (net.G[bn] if bn else None, 1)]  # time-shift and bias gradients
                 Kw = ksize * ksize * C1
-                T.gemm(E, dyt, cols, net.G[wn], Cout, Kw, M, M, M, Kw, f32_out=True, accumulate=True)
+                if T.wgrad_ok(Cout, Kw, C1) and x.t.dim() == 4:  # straight from NHWC x and dY: no im2col^T, no transposes
+                    T.wgrad(E, dy2, x.t, net.G[wn], ksize=ksize, stride=stride, pad=ksize // 2)
+                    for sm, grp in sums:
+                        if sm is not None:
+                            T.colsum(E, dy2, sm, grp, M // grp, Cout, Cout)
+                else:
+                    dyt = T.transpose2d_colsum(E, dy2, M, Cout, sums)
+                    cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)
+                    T.gemm(E, dyt, cols, net.G[wn], Cout, Kw, M, M, M, Kw, f32_out=True, accumulate=True)
             if needs_in:
                 parts = ((x, 0, C1),) + (((x2, C1, C1 + C2),) if x2 is not None else ())
                 if ksize == 1:

@@ -225,6 +225,25 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
 /* out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c] (0 in the padding); M = B*Ho*Wo contiguous */
 int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize,
                     int32_t stride, int32_t pad);
+/* ---- weight gradient on operands in their forward layout (no transposed copies, no im2col^T) ---------------------------------------
+ * dw[n, k] += sum_r dy[r, n] * X[r, k];  dense: X = x [R, ld_x];  conv: X[r, tap * C + c] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c]
+ * for r = (b, oy, ox), zero outside the image (x NHWC [B, H, W, C], C % 64 == 0).  What autograd computes for nn.Linear / nn.Conv2d weights
+ * inside accelerator.backward(loss) (diffusion/train_controlnet_genima.py:1391).  f32 result accumulated into dw; the reduction over the
+ * R rows is split across workgroups deterministically (workspace: gn_wgrad_workspace_bytes). */
+typedef struct gn_wgrad_desc {
+  const void* dy;        /* f16 [R, ld_dy] */
+  const void* x;         /* f16 [R, ld_x] or NHWC [B, H, W, C] */
+  float* dw;             /* f32 [N, ld_dw], accumulated */
+  void* workspace;
+  int64_t R, N, K;       /* K = columns of dw (conv: KH*KW*C) */
+  int64_t ld_dy, ld_x, ld_dw;
+  int32_t conv, B, H, W, C, KH, KW, stride, pad, Ho, Wo;
+  int32_t tile;          /* 0 = heuristic, 1 = 128x128, 2 = 64x64 */
+  int32_t splitk;        /* 0 = heuristic */
+} gn_wgrad_desc;
+int64_t gn_wgrad_workspace_bytes(const gn_wgrad_desc* d);
+int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d);
+
 /* gn_transpose2d of one matrix that also yields sums[g][cols] += the column sums of row block g (groups = 1: bias gradient;
  * groups = batch: per-sample time-shift gradient; sums2 / groups2: an optional second grouping from the same pass) -- the
  * weight-gradient path transposes dY anyway.  (rows / groups) % 64 == 0; workspace: ceil(rows / 64) * cols floats.  Replaces the

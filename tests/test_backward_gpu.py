@@ -305,3 +305,39 @@ def test_transpose_with_column_sums(engine, rows, cols, groups):
     assert_close(s1, xf.sum(0, keepdim=True) + 0.5, rel=1e-5, what="column sums")
     xt2 = T.transpose2d_colsum(engine, x, rows, cols, [])
     assert torch.equal(xt2, xt)
+
+
+@pytest.mark.parametrize("R,N,K,tile", [(4096, 320, 320, 0), (1000, 136, 72, 0), (8192, 1280, 320, 1), (777 * 8, 64, 640, 2), (32768, 320, 1280, 0)])
+def test_wgrad_linear_natural_layout(engine, R, N, K, tile):
+    """gn_wgrad (csrc/gemm_tn.hip): dW += dY^T X from row-major dY [R, N] and X [R, K] -- LDS transpose reads instead of transposed copies
+    -- against an fp64 torch product of the same f16 inputs; accumulation into existing f32 values; ragged R / N / K tails."""
+    gg = torch.Generator().manual_seed(R + N)
+    dy = (torch.randn(R, N, generator=gg) * 0.5).half().cuda()
+    x = (torch.randn(R, K, generator=gg) * 0.5).half().cuda()
+    dw = torch.full((N, K), 0.125, device="cuda")
+    T.wgrad(engine, dy, x, dw, tile=tile)
+    ref = (dy.double().t() @ x.double()).float().cpu() + 0.125
+    assert_close(dw, ref, rel=2e-4, what=f"wgrad {R}x{N}x{K}")
+    first = dw.clone()
+    T.wgrad(engine, dy, x, dw, tile=tile)
+    assert_close(dw, 2 * ref - 0.125, rel=2e-4, what="wgrad accumulate")
+    dw2 = torch.full((N, K), 0.125, device="cuda")
+    T.wgrad(engine, dy, x, dw2, tile=tile)
+    assert torch.equal(dw2, first), "deterministic"
+
+
+@pytest.mark.parametrize("B,H,C,N,ks,stride", [(2, 16, 64, 72, 3, 1), (2, 32, 128, 128, 3, 1), (3, 16, 320, 320, 3, 2), (2, 12, 64, 64, 1, 1),
+                                               (8, 32, 640, 640, 3, 1)])
+def test_wgrad_conv_natural_layout(engine, B, H, C, N, ks, stride):
+    """Conv weight gradient straight from NHWC x and dY (no im2col^T): against autograd's conv2d weight gradient (fp32 on the f16 inputs),
+    in the packed [Cout, tap * C + c] layout of the forward weights."""
+    gg = torch.Generator().manual_seed(B * H + C)
+    x = q16(torch.randn(B, C, H, H, generator=gg) * 0.5)
+    w = torch.zeros(N, C, ks, ks, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=stride, padding=ks // 2)
+    dy = q16(torch.randn(y.shape, generator=gg) * 0.5)
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(N, ks * ks * C)  # [Cout, (dy, dx, c)]
+    dw = torch.zeros(N, ks * ks * C, device="cuda")
+    T.wgrad(engine, h(nhwc(dy)), h(nhwc(x)), dw, ksize=ks, stride=stride, pad=ks // 2)
+    assert_close(dw, ref, rel=5e-4, what=f"conv wgrad {C}->{N} k{ks} s{stride}")
