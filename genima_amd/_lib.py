@@ -72,6 +72,7 @@ class WgradDesc(C.Structure):
         ("R", C.c_int64), ("N", C.c_int64), ("K", C.c_int64), ("ld_dy", C.c_int64), ("ld_x", C.c_int64), ("ld_dw", C.c_int64),
         ("conv", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
         ("stride", C.c_int32), ("pad", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("tile", C.c_int32), ("splitk", C.c_int32),
+        ("dbias", C.c_void_p), ("dshift", C.c_void_p), ("shift_groups", C.c_int32),
     ]
 
 

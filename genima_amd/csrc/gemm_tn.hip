@@ -22,6 +22,7 @@ struct H8 { h4 lo, hi; };  // two transpose reads = one MFMA operand (8 consecut
 struct TnParams {
   GemmParams g;   // a = dY, w = X; M = dW rows (dY columns), N = dW columns, K = R (reduction rows); out = dW (f32, accumulate)
   int B, H, W, C, KH, KW, stride, pad, Ho, Wo;  // conv geometry (X = NHWC activations)
+  float* sums_ws;  // optional [splitk][M]: column sums of dY over each row slice (bias / time-shift gradients ride on the A operand)
 };
 
 // chunk swizzle of a row of CPR 16-byte chunks: XOR on the 32-byte pair index so that rows r..r+3 and r+8..r+11 (one transpose read
@@ -63,13 +64,19 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
   // ---- loader state.  A piece i of this wave: LDS rows (wave + NW * i) * RPA + lane / CPA, physical chunk lane % CPA
   const int arow = lane / CPA, apc = lane % CPA;
   const int brow = lane / CPB, bpc = lane % CPB;
-  // conv: the column tile lies inside one tap (C % BN == 0)
-  int tap_dy = 0, tap_dx = 0, c0 = n0;
+  // conv: every 16-byte piece (8 channels) lies inside one tap (C % 8 == 0); a piece's LDS row -- hence its swizzled column, tap and
+  // channel -- is the same for every K tile
+  int tdy[GB], tdx[GB], tcc[GB];
   if constexpr (CONV) {
-    const int tap = n0 / tp.C;
-    c0 = n0 - tap * tp.C;
-    tap_dy = tap / tp.KW;
-    tap_dx = tap - tap_dy * tp.KW;
+#pragma unroll
+    for (int i = 0; i < GB; ++i) {
+      const int lrow = (wave + NW * i) * RPB + brow;
+      const int col = n0 + ((bpc ^ tn_swz<CPB>(lrow)) << 3);
+      const int tap = col / tp.C;
+      tcc[i] = col - tap * tp.C;
+      tdy[i] = tap / tp.KW;
+      tdx[i] = tap - tdy[i] * tp.KW;
+    }
   }
   // conv: (b, oy, ox) of the row each B piece loads, advanced by 64 rows per K tile without divisions
   int pb[GB], py[GB], px[GB];
@@ -102,9 +109,9 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
       const int lc = (bpc ^ tn_swz<CPB>(lrow)) << 3;
       unsigned voff = kOOB;
       if constexpr (CONV) {
-        const int iy = py[i] * tp.stride - tp.pad + tap_dy, ix = px[i] * tp.stride - tp.pad + tap_dx;
+        const int iy = py[i] * tp.stride - tp.pad + tdy[i], ix = px[i] * tp.stride - tp.pad + tdx[i];
         if (r < rend && n0 + lc < p.N && (unsigned)iy < (unsigned)tp.H && (unsigned)ix < (unsigned)tp.W)
-          voff = (unsigned)(((((long)pb[i] * tp.H + iy) * tp.W + ix) * tp.C + c0 + lc) * 2);
+          voff = (unsigned)(((((long)pb[i] * tp.H + iy) * tp.W + ix) * tp.C + tcc[i]) * 2);
         // next K tile: 64 rows further
         px[i] += r64; py[i] += q64;
         if (px[i] >= tp.Wo) { px[i] -= tp.Wo; ++py[i]; }
@@ -138,6 +145,11 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
+  const bool do_sums = tp.sums_ws != nullptr && tile_n == 0 && wn == 0;
+  float csum[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) csum[i] = 0.0f;
+
   dma_tile(0, rbeg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -157,6 +169,12 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
         const h4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(q + 4 * (BM * 2)));
         fa[i] = __builtin_bit_cast(f16x8, H8{lo, hi4});
       }
+      if (do_sums) {  // wave-uniform: the first column tile's wn = 0 waves also sum the dY fragments they hold anyway
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csum[i] += (float)fa[i][e];
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const unsigned char* q = Bs + boff[j] + kk * 16 * (BN * 2);
@@ -175,6 +193,14 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
     cur ^= 1;
   }
 
+  if (do_sums) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const float v = csum[i] + __shfl_xor(csum[i], 32);  // lanes l and l + 32 hold the two 8-row halves of a k16 step
+      const int m = m0 + wm * WTM + i * 32 + l31;
+      if (hi == 0 && m < p.M) tp.sums_ws[(long)z * p.M + m] = v;
+    }
+  }
   GemmParams pe = p;
   gemm_epilogue<TM, TN>(pe, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
 }
@@ -192,10 +218,20 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
   *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + s;
 }
 
+// out[g][n] += sum of the slices of row group g (fixed order): dbias (one group) and the per-sample time-shift gradient
+__global__ __launch_bounds__(256) void tn_sums_kernel(const float* __restrict__ ws, float* __restrict__ out, int N, int groups, int slices_per_group) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)groups * N) return;
+  const int g = (int)(idx / N), n = (int)(idx - (long)g * N);
+  float s = 0.f;
+  for (int zz = 0; zz < slices_per_group; ++zz) s += ws[((long)g * slices_per_group + zz) * N + n];
+  out[idx] += s;
+}
+
 struct TnPlan { int bm, bn, splitk; long kper; };
 TnPlan tn_plan(const gn_wgrad_desc* d) {
   TnPlan pl;
-  const bool small = d->tile == 2 || (d->tile == 0 && (d->N < 128 || d->K < 128 || (d->conv && d->C % 128 != 0)));
+  const bool small = d->tile == 2 || (d->tile == 0 && (d->N < 128 || d->K < 128));
   pl.bm = pl.bn = small ? 64 : 128;
   const long blocks = ((d->N + pl.bm - 1) / pl.bm) * ((d->K + pl.bn - 1) / pl.bn);
   int sk = d->splitk;
@@ -207,6 +243,12 @@ TnPlan tn_plan(const gn_wgrad_desc* d) {
     if (sk < 1) sk = 1;
   }
   long kper = ((d->R + sk - 1) / sk + 63) / 64 * 64;
+  if (d->dshift && d->shift_groups > 0) {  // per-sample sums: a row slice must not straddle two samples
+    const long hw = d->R / d->shift_groups;
+    long spg = (hw + kper - 1) / kper;  // slices per sample
+    while (spg < hw / 64 && (hw % spg != 0 || (hw / spg) % 64 != 0)) ++spg;
+    kper = hw / spg;
+  }
   pl.splitk = (int)((d->R + kper - 1) / kper);
   pl.kper = kper;
   return pl;
@@ -217,7 +259,9 @@ TnPlan tn_plan(const gn_wgrad_desc* d) {
 extern "C" int64_t gn_wgrad_workspace_bytes(const gn_wgrad_desc* d) {
   if (!d) return 0;
   const TnPlan pl = tn_plan(d);
-  return pl.splitk > 1 ? (int64_t)pl.splitk * d->N * d->K * (int64_t)sizeof(float) : 0;
+  const int64_t slabs = pl.splitk > 1 ? (int64_t)pl.splitk * d->N * d->K : 0;
+  const int64_t sums = (d->dbias || d->dshift) ? (int64_t)pl.splitk * d->N : 0;
+  return (slabs + sums) * (int64_t)sizeof(float);
 }
 
 extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
@@ -235,8 +279,8 @@ extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
   GN_REQUIRE((uint64_t)d->R * d->ld_dy * 2 < 0xFFFFFF00ull, "gn_wgrad: dY too large for 32-bit buffer offsets");
   p.a_bytes = (unsigned)((uint64_t)d->R * d->ld_dy * 2);
   if (d->conv) {
-    GN_REQUIRE(d->C > 0 && d->C % 64 == 0 && d->K == (int64_t)d->KH * d->KW * d->C && d->R == (int64_t)d->B * d->Ho * d->Wo && d->stride >= 1,
-               "gn_wgrad(conv): C %% 64 == 0, K = KH*KW*C, R = B*Ho*Wo");
+    GN_REQUIRE(d->C > 0 && d->C % 8 == 0 && d->K == (int64_t)d->KH * d->KW * d->C && d->R == (int64_t)d->B * d->Ho * d->Wo && d->stride >= 1,
+               "gn_wgrad(conv): C %% 8 == 0, K = KH*KW*C, R = B*Ho*Wo");
     const uint64_t xb = (uint64_t)d->B * d->H * d->W * d->C * 2;
     GN_REQUIRE(xb < 0xFFFFFF00ull, "gn_wgrad(conv): x too large for 32-bit buffer offsets");
     p.w_bytes = (unsigned)xb;
@@ -248,9 +292,15 @@ extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
     tp.B = tp.H = tp.W = tp.C = tp.KH = tp.KW = tp.stride = tp.pad = tp.Ho = tp.Wo = 0;
   }
   const TnPlan pl = tn_plan(d);
-  if (d->conv) GN_REQUIRE(d->C % pl.bn == 0, "gn_wgrad(conv): C (%d) must be a multiple of the column tile (%d)", d->C, pl.bn);
   p.splitk = pl.splitk; p.kper = (int)pl.kper;
-  if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_wgrad: split over rows (%d) needs a workspace of gn_wgrad_workspace_bytes()", pl.splitk);
+  const bool want_sums = d->dbias || d->dshift;
+  if (pl.splitk > 1 || want_sums) GN_REQUIRE(d->workspace, "gn_wgrad: split over rows (%d) / column sums need a workspace of gn_wgrad_workspace_bytes()", pl.splitk);
+  if (d->dshift) {
+    GN_REQUIRE(d->shift_groups > 0 && d->R % d->shift_groups == 0 && (d->R / d->shift_groups) % 64 == 0,
+               "gn_wgrad: dshift needs R / shift_groups (%ld / %d) to be a multiple of 64", (long)d->R, d->shift_groups);
+    GN_REQUIRE((d->R / d->shift_groups) % pl.kper == 0, "gn_wgrad: row slices (%ld) do not tile a sample", pl.kper);
+  }
+  tp.sums_ws = want_sums ? (float*)d->workspace + (pl.splitk > 1 ? (int64_t)pl.splitk * d->N * d->K : 0) : nullptr;
   p.tiles_m = (int)((d->N + pl.bm - 1) / pl.bm); p.tiles_n = (int)((d->K + pl.bn - 1) / pl.bn);
   const dim3 grid(p.tiles_m * p.tiles_n, pl.splitk, 1);
   if (pl.bm == 128) {
@@ -265,6 +315,16 @@ extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
     const long total = (long)d->N * (d->K >> 2);
     hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d->workspace, d->dw, (long)d->N,
                        (int)d->K, (long)d->ld_dw, pl.splitk);
+    GN_LAUNCH_CHECK();
+  }
+  if (d->dbias) {
+    hipLaunchKernelGGL(tn_sums_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)tp.sums_ws, d->dbias, (int)d->N, 1, pl.splitk);
+    GN_LAUNCH_CHECK();
+  }
+  if (d->dshift) {
+    const int G = d->shift_groups;
+    hipLaunchKernelGGL(tn_sums_kernel, dim3((unsigned)(((long)G * d->N + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)tp.sums_ws, d->dshift, (int)d->N, G,
+                       pl.splitk / G);
     GN_LAUNCH_CHECK();
   }
   return GN_OK;

@@ -78,9 +78,12 @@ def transpose2d(E: Engine, x: torch.Tensor, rows: int, cols: int, *, ld_in: Opti
     return out
 
 
-def wgrad(E: Engine, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, ksize: int = 0, stride: int = 1, pad: int = 0, tile: int = 0):
+def wgrad(E: Engine, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, ksize: int = 0, stride: int = 1, pad: int = 0, tile: int = 0,
+          dbias: Optional[torch.Tensor] = None, dshift: Optional[torch.Tensor] = None, shift_groups: int = 0):
     """dw [N, K] f32 += dy^T . X with both operands in their forward layout (csrc/gemm_tn.hip: no transposed copies).
-    Linear (ksize == 0): dy [R, N], x [R, K].  Conv: dy [B, Ho, Wo, N] (or [R, N]), x NHWC [B, H, W, C], K = ksize^2 * C."""
+    Linear (ksize == 0): dy [R, N], x [R, K].  Conv: dy [B, Ho, Wo, N] (or [R, N]), x NHWC [B, H, W, C], K = ksize^2 * C.
+    dbias [N] / dshift [shift_groups, N] (f32, accumulated): the column sums of dy over all rows / per block of R / shift_groups rows,
+    taken from the fragments the kernel loads anyway (R / shift_groups must be a multiple of 64)."""
     d = WgradDesc()
     N = dy.shape[-1]
     R = dy.numel() // N
@@ -96,6 +99,7 @@ def wgrad(E: Engine, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, ksi
         d.K = x.shape[-1]
         d.ld_x = d.K
         assert x.numel() // d.K == R
+    d.dbias, d.dshift, d.shift_groups = _ptr(dbias), _ptr(dshift), shift_groups if dshift is not None else 0
     if tile == 0:
         from .engine import _tune_table
         key = f"wg|{int(d.conv)}|{R}|{N}|{int(d.K)}|{int(d.C)}|{int(d.KH)}|{int(d.stride)}"
@@ -118,15 +122,13 @@ def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str) -> int:
     """Race the two tiles and a few row splits of gn_wgrad on this shape (into a scratch copy of dw) and remember the winner in the
     GEMM tune table (value = tile + 100 * row split, split 0 = the library's heuristic)."""
     from . import engine as _eng
-    real = d.dw
+    real, real_sums = d.dw, (d.dbias, d.dshift)
     scratch = torch.empty_like(dw)
-    d.dw = scratch.data_ptr()
+    d.dw, d.dbias, d.dshift = scratch.data_ptr(), None, None
     best, best_ms = 0, float("inf")
     e0, e1 = E.event(), E.event()
     try:
         for tile in (1, 2):
-            if tile == 1 and d.conv and d.C % 128 != 0:
-                continue
             for sk in (0, 64, 32, 16, 8):
                 if sk and sk * 512 > d.R:
                     continue
@@ -142,7 +144,7 @@ def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str) -> int:
                 if ms < best_ms:
                     best, best_ms = tile + 100 * sk, ms
     finally:
-        d.dw = real
+        d.dw, (d.dbias, d.dshift) = real, real_sums
         E.lib.gn_event_destroy(e0)
         E.lib.gn_event_destroy(e1)
     _eng._tune_table()[key] = best
@@ -152,7 +154,7 @@ def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str) -> int:
 
 def wgrad_ok(N: int, K: int, conv_C: int = 0) -> bool:
     """Shapes gn_wgrad takes (the others keep the transposed-copy GEMM path)."""
-    return N % 8 == 0 and K % 8 == 0 and (conv_C == 0 or conv_C % 64 == 0)
+    return N % 8 == 0 and K % 8 == 0 and conv_C % 8 == 0
 
 
 def transpose2d_colsum(E: Engine, x: torch.Tensor, rows: int, cols: int, sums) -> torch.Tensor:

@@ -217,9 +217,7 @@ class Graph:
             self.acc(residual, dy)
             if net.G is not None:
                 if T.wgrad_ok(N, K) and M % 8 == 0:  # dW += dY^T X straight from the row-major operands (csrc/gemm_tn.hip)
-                    T.wgrad(E, dy2, x.t.view(M, K), net.G[wn])
-                    if bn:
-                        T.colsum(E, dy2, net.G[bn], 1, M, N, N)
+                    T.wgrad(E, dy2, x.t.view(M, K), net.G[wn], dbias=net.G[bn] if bn else None)  # the bias gradient rides on the dY fragments
                 else:
                     dyt = T.transpose2d_colsum(E, dy2, M, N, [(net.G[bn], 1)] if bn else [])  # the bias gradient rides on the transpose
                     if self._xt[0] is x.t:  # the previous backward op consumed the same input (q|k and v projections of one LayerNorm)
@@ -265,10 +263,11 @@ class Graph:
                 sums = [(net.dshift[prefix] if sh_var is not None else None, B), (net.G[bn] if bn else None, 1)]  # time-shift and bias gradients
                 Kw = ksize * ksize * C1
                 if T.wgrad_ok(Cout, Kw, C1) and x.t.dim() == 4:  # straight from NHWC x and dY: no im2col^T, no transposes
-                    T.wgrad(E, dy2, x.t, net.G[wn], ksize=ksize, stride=stride, pad=ksize // 2)
-                    for sm, grp in sums:
-                        if sm is not None:
-                            T.colsum(E, dy2, sm, grp, M // grp, Cout, Cout)
+                    in_kernel = (Ho * Wo) % 64 == 0  # per-sample sums need row slices that tile a sample
+                    T.wgrad(E, dy2, x.t, net.G[wn], ksize=ksize, stride=stride, pad=ksize // 2, dbias=sums[1][0],
+                            dshift=sums[0][0] if in_kernel else None, shift_groups=B)
+                    if sums[0][0] is not None and not in_kernel:
+                        T.colsum(E, dy2, sums[0][0], B, Ho * Wo, Cout, Cout)
                 else:
                     dyt = T.transpose2d_colsum(E, dy2, M, Cout, sums)
                     cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)

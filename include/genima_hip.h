@@ -227,7 +227,7 @@ int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H,
                     int32_t stride, int32_t pad);
 /* ---- weight gradient on operands in their forward layout (no transposed copies, no im2col^T) ---------------------------------------
  * dw[n, k] += sum_r dy[r, n] * X[r, k];  dense: X = x [R, ld_x];  conv: X[r, tap * C + c] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c]
- * for r = (b, oy, ox), zero outside the image (x NHWC [B, H, W, C], C % 64 == 0).  What autograd computes for nn.Linear / nn.Conv2d weights
+ * for r = (b, oy, ox), zero outside the image (x NHWC [B, H, W, C], C % 8 == 0).  What autograd computes for nn.Linear / nn.Conv2d weights
  * inside accelerator.backward(loss) (diffusion/train_controlnet_genima.py:1391).  f32 result accumulated into dw; the reduction over the
  * R rows is split across workgroups deterministically (workspace: gn_wgrad_workspace_bytes). */
 typedef struct gn_wgrad_desc {
@@ -240,6 +240,9 @@ typedef struct gn_wgrad_desc {
   int32_t conv, B, H, W, C, KH, KW, stride, pad, Ho, Wo;
   int32_t tile;          /* 0 = heuristic, 1 = 128x128, 2 = 64x64 */
   int32_t splitk;        /* 0 = heuristic */
+  float* dbias;          /* optional f32 [N] += column sums of dy (the bias gradient), from the fragments the kernel loads anyway */
+  float* dshift;         /* optional f32 [shift_groups, N] += column sums per block of R / shift_groups rows (per-sample time-shift gradient) */
+  int32_t shift_groups;  /* R / shift_groups must be a multiple of 64 */
 } gn_wgrad_desc;
 int64_t gn_wgrad_workspace_bytes(const gn_wgrad_desc* d);
 int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d);

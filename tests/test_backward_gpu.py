@@ -322,12 +322,20 @@ def test_wgrad_linear_natural_layout(engine, R, N, K, tile):
     T.wgrad(engine, dy, x, dw, tile=tile)
     assert_close(dw, 2 * ref - 0.125, rel=2e-4, what="wgrad accumulate")
     dw2 = torch.full((N, K), 0.125, device="cuda")
-    T.wgrad(engine, dy, x, dw2, tile=tile)
-    assert torch.equal(dw2, first), "deterministic"
+    db = torch.full((N,), 2.0, device="cuda")
+    groups = 8 if R % (8 * 64) == 0 else 0
+    ds = torch.full((groups, N), -1.0, device="cuda") if groups else None
+    T.wgrad(engine, dy, x, dw2, tile=tile, dbias=db, dshift=ds, shift_groups=groups)
+    if not groups:
+        assert torch.equal(dw2, first), "deterministic"  # (per-sample sums re-slice the rows: same values, another summation order)
+    assert_close(dw2, ref, rel=2e-4, what="wgrad with column sums")
+    assert_close(db, dy.double().sum(0).float().cpu() + 2.0, rel=1e-4, what="bias gradient from the dY fragments")
+    if groups:
+        assert_close(ds, dy.double().view(groups, R // groups, N).sum(1).float().cpu() - 1.0, rel=1e-4, what="per-sample shift gradient")
 
 
 @pytest.mark.parametrize("B,H,C,N,ks,stride", [(2, 16, 64, 72, 3, 1), (2, 32, 128, 128, 3, 1), (3, 16, 320, 320, 3, 2), (2, 12, 64, 64, 1, 1),
-                                               (8, 32, 640, 640, 3, 1)])
+                                               (8, 32, 640, 640, 3, 1), (2, 64, 16, 32, 3, 2), (2, 32, 96, 256, 3, 2), (1, 48, 8, 16, 3, 1)])
 def test_wgrad_conv_natural_layout(engine, B, H, C, N, ks, stride):
     """Conv weight gradient straight from NHWC x and dY (no im2col^T): against autograd's conv2d weight gradient (fp32 on the f16 inputs),
     in the packed [Cout, tap * C + c] layout of the forward weights."""
