@@ -447,10 +447,7 @@ __global__ __launch_bounds__(256) void gnb_partial_kernel(const GNBParams p, con
         a[e] = scsh[((long)b * p.C + c8 + e) * 2];
         s[e] = scsh[((long)b * p.C + c8 + e) * 2 + 1];
       }
-      for (int r = r0 + ty; r < r1; r += TY) {
-        const long pix = (long)b * p.HW + r;
-        const uint4 xr = *reinterpret_cast<const uint4*>(src + pix * cs + co);
-        const uint4 dr = *reinterpret_cast<const uint4*>(p.dy + pix * p.C + c8);
+      auto body = [&](const uint4& xr, const uint4& dr) {
         const f16x8 xh = *reinterpret_cast<const f16x8*>(&xr), dh = *reinterpret_cast<const f16x8*>(&dr);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -459,6 +456,22 @@ __global__ __launch_bounds__(256) void gnb_partial_kernel(const GNBParams p, con
           s1[e] += d;
           s2[e] += d * xv;
         }
+      };
+      int r = r0 + ty;
+      for (; r + 3 * TY < r1; r += 4 * TY) {  // 8 loads in flight per thread: a row at a time is latency-bound
+        uint4 xr[4], dr[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long pix = (long)b * p.HW + r + u * TY;
+          xr[u] = *reinterpret_cast<const uint4*>(src + pix * cs + co);
+          dr[u] = *reinterpret_cast<const uint4*>(p.dy + pix * p.C + c8);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) body(xr[u], dr[u]);
+      }
+      for (; r < r1; r += TY) {
+        const long pix = (long)b * p.HW + r;
+        body(*reinterpret_cast<const uint4*>(src + pix * cs + co), *reinterpret_cast<const uint4*>(p.dy + pix * p.C + c8));
       }
     }
 #pragma unroll
@@ -863,7 +876,7 @@ int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const vo
 }
 
 int64_t gn_groupnorm_bwd_workspace_bytes(int32_t B, int32_t HW, int32_t C) {
-  int chunks = HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  int chunks = HW / 16; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
   return ((int64_t)B * chunks * 2 * C + (int64_t)B * C * 3 + (int64_t)B * C * 2) * 4;
 }
 /* fwd_ws: the forward's workspace (gn_groupnorm_workspace_bytes) still holding scsh[B][C][2]; stats: [B][G][2] (mean, rstd) */
@@ -876,7 +889,7 @@ int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy
   p.dx_add = (const f16*)dx_add; p.dx2_add = (const f16*)dx2_add;
   p.B = d->B; p.HW = d->HW; p.C1 = d->C1; p.C2 = d->C2; p.C = d->C1 + d->C2; p.G = d->groups; p.cpg = p.C / p.G; p.act = d->act; p.eps = d->eps;
   GN_REQUIRE(p.C <= 4096 && p.C % 8 == 0 && p.C1 % 8 == 0, "gn_groupnorm_bwd: C <= 4096, C and C1 multiples of 8");
-  int chunks = p.HW / 64; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;
+  int chunks = p.HW / 16; if (chunks < 1) chunks = 1; if (chunks > 64) chunks = 64;  // small maps: 16-row slabs keep > 100 workgroups
   p.rows = (p.HW + chunks - 1) / chunks;
   p.chunks = (p.HW + p.rows - 1) / p.rows;
   p.part = (float*)workspace;
