@@ -16,6 +16,7 @@ python bench.py --workload single_b1 --dump-ops $O/ops_b1.csv --no-cpu-baseline 
 python tools/bench_attn.py 2>/dev/null > $O/attn.txt
 python tools/probes/gemm_ksweep.py 2>/dev/null | grep "^M=" > $O/gemm_ksweep.txt
 python tools/probes/gn_bench.py 2>/dev/null | grep groupnorm > $O/gn_bench.txt
+python tools/probes/wgrad_bench.py 2>/dev/null | grep "^linear\|^conv" > $O/wgrad_bench.txt
 find $O -name "*stats.csv" | head; rm -f $O/inf/*kernel_trace.csv $O/train/*kernel_trace.csv $O/inf/*/*kernel_trace.csv $O/train/*/*kernel_trace.csv
 bash tools/probes/pmc_traffic.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_traffic/traffic.json $O/pmc_traffic.json
 tail -c 400 $O/bench_full.json | head -c 300; echo; cut -c1-160 $O/train_bench.json; cut -c1-160 $O/train_sdxl.json; cut -c1-160 $O/train_sdxl_fp8.json; tail -3 $O/pmc.log
