@@ -495,47 +495,48 @@ __global__ __launch_bounds__(256) void gnb_finalize_kernel(const GNBParams p, co
   // stats[b][g] = (mean, rstd) from the forward.  Per channel: S1 = sum dyh, S2 = sum dyh*x.
   // per group: c2 = mean(dyh*gamma), c1 = mean(dyh*gamma*xhat);  dx = r*gamma*dyh - r*c2 - r*xhat*c1
   //          = (r*gamma) dyh + (-r^2 c1) x + (r^2 c1 mu - r c2)
-  __shared__ float S1[4096], S2[4096], T1[256], T2[256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  for (int c = tid; c < p.C; c += 256) {
-    // fixed-order sum over the row chunks, two interleaved accumulators per quantity to keep the loads in flight
-    float a1 = 0.f, a2 = 0.f, b1 = 0.f, b2 = 0.f;
+  // One workgroup per (group, sample) -- a workgroup per sample walked C x chunks partials with 8 workgroups on the chip (24 us);
+  // thread (channel ci of the group, chunk lane cl) sums chunks cl, cl + L, ... and the lanes fold in a fixed order.
+  __shared__ float P1[256], P2[256], S1[256], S2[256], T[2];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int L = 256 / p.cpg;  // chunk lanes (cpg <= 256)
+  const int ci = tid % p.cpg, cl = tid / p.cpg;
+  const int c = g * p.cpg + ci;
+  float a1 = 0.f, a2 = 0.f;
+  if (cl < L) {
     const float* o = p.part + ((long)b * p.chunks * 2) * p.C + c;
-    int ch = 0;
-    for (; ch + 2 <= p.chunks; ch += 2) {
-      a1 += o[(long)(2 * ch) * p.C];
-      a2 += o[(long)(2 * ch + 1) * p.C];
-      b1 += o[(long)(2 * ch + 2) * p.C];
-      b2 += o[(long)(2 * ch + 3) * p.C];
-    }
-    if (ch < p.chunks) {
+    for (int ch = cl; ch < p.chunks; ch += L) {
       a1 += o[(long)(2 * ch) * p.C];
       a2 += o[(long)(2 * ch + 1) * p.C];
     }
-    const float s1 = a1 + b1, s2 = a2 + b2;
-    S1[c] = s1;
-    S2[c] = s2;
+  }
+  P1[tid] = a1;
+  P2[tid] = a2;
+  __syncthreads();
+  if (tid < p.cpg) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = 0; q < L; ++q) { s1 += P1[q * p.cpg + tid]; s2 += P2[q * p.cpg + tid]; }
+    S1[tid] = s1;
+    S2[tid] = s2;
     p.sums[((long)b * 2) * p.C + c] = s1;       // kept for gnb_param_kernel
     p.sums[((long)b * 2 + 1) * p.C + c] = s2;
   }
   __syncthreads();
-  for (int g = tid; g < p.G; g += 256) {
-    const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
+  const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
+  if (tid == 0) {
     float t1 = 0.f, t2 = 0.f;  // sum over the group's channels of gamma*(S2 - mu*S1)*r and gamma*S1
-    for (int cc = g * p.cpg; cc < (g + 1) * p.cpg; ++cc) {
-      const float gm = (float)p.gamma[cc];
-      t2 += gm * S1[cc];
-      t1 += gm * (S2[cc] - mu * S1[cc]) * r;
+    for (int q = 0; q < p.cpg; ++q) {
+      const float gm = (float)p.gamma[g * p.cpg + q];
+      t2 += gm * S1[q];
+      t1 += gm * (S2[q] - mu * S1[q]) * r;
     }
-    T1[g] = t1;
-    T2[g] = t2;
+    T[0] = t1;
+    T[1] = t2;
   }
   __syncthreads();
-  for (int c = tid; c < p.C; c += 256) {
-    const int g = c / p.cpg;
-    const float mu = stats[((long)b * p.G + g) * 2], r = stats[((long)b * p.G + g) * 2 + 1];
+  if (tid < p.cpg) {
     const float n = (float)p.HW * (float)p.cpg;
-    const float c1 = T1[g] / n, c2 = T2[g] / n;
+    const float c1 = T[0] / n, c2 = T[1] / n;
     float* o = p.coef + ((long)b * p.C + c) * 3;
     o[0] = r * (float)p.gamma[c];
     o[1] = -r * r * c1;
@@ -897,7 +898,8 @@ int32_t gn_groupnorm_bwd(gn_ctx* ctx, const gn_groupnorm_desc* d, const void* dy
   p.sums = p.coef + (long)p.B * p.C * 3;
   hipLaunchKernelGGL(gnb_partial_kernel, dim3(p.chunks, p.B), dim3(256), 0, ctx->stream, p, scsh);
   GN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gnb_finalize_kernel, dim3(p.B), dim3(256), 0, ctx->stream, p, stats);
+  GN_REQUIRE(p.cpg <= 256, "gn_groupnorm_bwd: at most 256 channels per group");
+  hipLaunchKernelGGL(gnb_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p, stats);
   GN_LAUNCH_CHECK();
   if (dgamma) {
     hipLaunchKernelGGL(gnb_param_kernel, dim3(nblk(p.C)), dim3(256), 0, ctx->stream, p, stats);
