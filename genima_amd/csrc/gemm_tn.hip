@@ -205,26 +205,36 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
   gemm_epilogue<TM, TN>(pe, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
 }
 
-// split-K: dW += sum of the f32 partial slabs (fixed order)
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, long M, int N, long ldo, int splitk) {
-  const long n4 = N >> 2;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * n4) return;
-  const long m = idx / n4;
-  const int nb = (int)(idx - m * n4) * 4;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int zz = 0; zz < splitk; ++zz) s += *reinterpret_cast<const f32x4*>(ws + ((long)zz * M + m) * N + nb);
-  float* o = out + m * ldo + nb;
-  *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + s;
-}
-
-// out[g][n] += sum of the slices of row group g (fixed order): dbias (one group) and the per-sample time-shift gradient
-__global__ __launch_bounds__(256) void tn_sums_kernel(const float* __restrict__ ws, float* __restrict__ out, int N, int groups, int slices_per_group) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)groups * N) return;
-  const int g = (int)(idx / N), n = (int)(idx - (long)g * N);
+// One finishing launch: dW += sum of the f32 partial slabs (fixed order), and the column-sum slices folded into dbias (one group) /
+// the per-sample time-shift gradient (shift_groups groups).  Blocks [0, nb_dw) reduce slabs, the next nb_bias the bias, the rest dshift.
+struct TnFinish {
+  const float* ws; float* dw; long M; int N; long ldo; int splitk;   // slabs (null: nothing to reduce)
+  const float* sums; float* dbias; float* dshift; int Ns, groups, spg; // column sums [splitk][Ns]
+  int nb_dw, nb_bias;
+};
+__global__ __launch_bounds__(256) void tn_finish_kernel(const TnFinish f) {
+  int blk = blockIdx.x;
+  if (blk < f.nb_dw) {
+    const long n4 = f.N >> 2;
+    const long idx = (long)blk * 256 + threadIdx.x;
+    if (idx >= f.M * n4) return;
+    const long m = idx / n4;
+    const int nb = (int)(idx - m * n4) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int zz = 0; zz < f.splitk; ++zz) s += *reinterpret_cast<const f32x4*>(f.ws + ((long)zz * f.M + m) * f.N + nb);
+    float* o = f.dw + m * f.ldo + nb;
+    *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(o) + s;
+    return;
+  }
+  blk -= f.nb_dw;
+  float* out = f.dbias;
+  int groups = 1, spg = f.splitk;
+  if (blk >= f.nb_bias) { blk -= f.nb_bias; out = f.dshift; groups = f.groups; spg = f.spg; }
+  const long idx = (long)blk * 256 + threadIdx.x;
+  if (idx >= (long)groups * f.Ns) return;
+  const int g = (int)(idx / f.Ns), n = (int)(idx - (long)g * f.Ns);
   float s = 0.f;
-  for (int zz = 0; zz < slices_per_group; ++zz) s += ws[((long)g * slices_per_group + zz) * N + n];
+  for (int zz = 0; zz < spg; ++zz) s += f.sums[((long)g * spg + zz) * f.Ns + n];
   out[idx] += s;
 }
 
@@ -311,20 +321,15 @@ extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
     else hipLaunchKernelGGL((gemm_tn_kernel<64, 64, false>), grid, dim3(256), 0, ctx->stream, tp);
   }
   GN_LAUNCH_CHECK();
-  if (pl.splitk > 1) {
-    const long total = (long)d->N * (d->K >> 2);
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)d->workspace, d->dw, (long)d->N,
-                       (int)d->K, (long)d->ld_dw, pl.splitk);
-    GN_LAUNCH_CHECK();
-  }
-  if (d->dbias) {
-    hipLaunchKernelGGL(tn_sums_kernel, dim3((unsigned)((d->N + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)tp.sums_ws, d->dbias, (int)d->N, 1, pl.splitk);
-    GN_LAUNCH_CHECK();
-  }
-  if (d->dshift) {
-    const int G = d->shift_groups;
-    hipLaunchKernelGGL(tn_sums_kernel, dim3((unsigned)(((long)G * d->N + 255) / 256)), dim3(256), 0, ctx->stream, (const float*)tp.sums_ws, d->dshift, (int)d->N, G,
-                       pl.splitk / G);
+  TnFinish f;
+  f.ws = (const float*)d->workspace; f.dw = d->dw; f.M = (long)d->N; f.N = (int)d->K; f.ldo = (long)d->ld_dw; f.splitk = pl.splitk;
+  f.sums = tp.sums_ws; f.dbias = d->dbias; f.dshift = d->dshift; f.Ns = (int)d->N; f.groups = d->dshift ? d->shift_groups : 1;
+  f.spg = d->dshift ? pl.splitk / d->shift_groups : pl.splitk;
+  f.nb_dw = pl.splitk > 1 ? (int)(((long)d->N * (d->K >> 2) + 255) / 256) : 0;
+  f.nb_bias = d->dbias ? (int)((d->N + 255) / 256) : 0;
+  const int nb_shift = d->dshift ? (int)(((long)d->shift_groups * d->N + 255) / 256) : 0;
+  if (f.nb_dw + f.nb_bias + nb_shift > 0) {
+    hipLaunchKernelGGL(tn_finish_kernel, dim3((unsigned)(f.nb_dw + f.nb_bias + nb_shift)), dim3(256), 0, ctx->stream, f);
     GN_LAUNCH_CHECK();
   }
   return GN_OK;
