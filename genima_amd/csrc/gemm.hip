@@ -363,6 +363,14 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
+  // registers: accumulators + every bias vector + two bands of shift / residual vectors + working set, against this occupancy's budget
+  constexpr int kBudget = 512 / gemm_waves_per_simd(2 * (A_BYTES + B_BYTES), NW);
+  constexpr bool RICH = epi_rich_fits(TM, TN, kBudget);
+  constexpr bool PRE = RICH && epi_prefetch_fits(TM, TN, kBudget);
+  EpiPre<TM, TN> pre;
+  bool use_pre = false;
+  if constexpr (PRE) use_pre = epilogue_prefetch<TM, TN>(p, pre, m0 + wm * WTM, n0 + wn * WTN, l31, hi);  // lands under the K loop
+
   dma_tile(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -393,9 +401,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     cur ^= 1;
   }
 
-  // registers: accumulators + every bias vector + two bands of shift / residual vectors + working set, against this occupancy's budget
-  constexpr bool RICH = TM * TN * 16 + TN * 8 * 3 + 96 <= 512 / gemm_waves_per_simd(2 * (A_BYTES + B_BYTES), NW);
-  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
 }
 
 // ======================================================================================================================

@@ -204,12 +204,41 @@ __device__ __forceinline__ void epilogue_tile_math(const GemmParams& p, float (&
   }
 }
 
+// Residual values of a whole wave tile, requested BEFORE the K loop: the epilogue's residual read is then a register move instead of a
+// memory round trip at the end of the workgroup (with every residual / bias load removed the tiled b8 call is 5 ms shorter: most of
+// that is latency the K loop can hide).  Costs TM x TN x 8 registers for the length of the loop; kernels opt in where they fit.
+template <int TM, int TN>
+struct EpiPre { f16x4 r[TM][TN][4]; };
+
+template <int TM, int TN>
+__device__ __forceinline__ bool epilogue_prefetch(const GemmParams& p, EpiPre<TM, TN>& pre, int mbase, int nbase, int l31, int hi) {
+  if (!(p.res && !p.shift && p.splitk <= 1 && p.out_mode == GN_OUT_ROWMAJOR && p.act != GN_ACT_GEGLU)) return false;  // wave-uniform
+  const f16x4 zero = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mbase + i * 32 + l31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nb = nbase + j * 32 + 8 * g + 4 * hi;
+        pre.r[i][j][g] = (m < p.M && nb < p.N) ? *reinterpret_cast<const f16x4*>(p.res + (long)m * p.ldr + nb) : zero;
+      }
+  }
+  return true;
+}
+// registers: accumulators + prefetched residuals + loop / epilogue working set against the occupancy's budget
+constexpr bool epi_prefetch_fits(int tm, int tn, int budget) { return tm * tn <= 8 && tm * tn * 16 + tn * 8 + tm * tn * 8 + 80 <= budget; }
+// the batched (RICH) epilogue: accumulators + every bias vector + one or two bands of shift / residual vectors + working set
+constexpr bool epi_rich_fits(int tm, int tn, int budget) { return tm * tn * 16 + tn * 8 * (1 + (tm < 2 ? tm : 2)) + 96 <= budget; }
+
 // RICH (registers to spare: small wave tiles, or one wave per SIMD): every bias vector up front and the shift / residual vectors of
 // the NEXT 32-row band requested before the current band's stores.  Otherwise the vectors are fetched tile by tile.
 template <int TM, int TN, bool RICH>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31,
-                                                     int hi) {
+                                                     int hi, const EpiPre<TM, TN>& pre, bool use_pre) {
   constexpr bool PIPE = RICH && TM * TN <= 8;
+  const bool pre_ok = RICH && use_pre;  // the residual of every band is already in registers (epilogue_prefetch)
   const bool has_shift = p.shift != nullptr, has_res = p.res != nullptr;
   const bool both = has_shift && has_res;  // rare: the residual is then read tile by tile
   const bool aux_is_res = has_res && !has_shift;
@@ -252,11 +281,18 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
       }
   };
   const bool wide = p.out_mode == GN_OUT_ROWMAJOR && (p.ldo & 7) == 0 && (p.N & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
-  if (PIPE && (has_shift || has_res)) load_aux(0, ax[0]);
+  if (PIPE && (has_shift || has_res) && !pre_ok) load_aux(0, ax[0]);
   static_for<TM>::run([&](auto I) {
     constexpr int i = decltype(I)::value;
     constexpr int kOne = PIPE ? 1 : 0;
-    if (has_shift || has_res) {
+    if (pre_ok) {
+      if constexpr (RICH) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) ax[i & kOne][j][g] = pre.r[i][j][g];
+      }
+    } else if (has_shift || has_res) {
       if (PIPE) { if (i + 1 < TM) load_aux(i + 1, ax[(i + 1) & kOne]); }
       else if (RICH) load_aux(i, ax[0]);
     }
@@ -356,7 +392,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
 
 template <int TM, int TN, bool RICH = (TM * TN <= 4)>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi,
-                                              int z) {
+                                              int z, const EpiPre<TM, TN>& pre, bool use_pre) {
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -407,8 +443,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       }
     }
   } else {
-    gemm_epilogue_direct<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi);
+    gemm_epilogue_direct<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, pre, use_pre);
   }
+}
+
+template <int TM, int TN, bool RICH = (TM * TN <= 4)>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi, int z) {
+  EpiPre<TM, TN> none;  // never read
+  gemm_epilogue<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, z, none, false);
 }
 
 // LDS-DMA (`buffer_load_dwordx4 ... lds`) plumbing shared by the DMA-staged kernels

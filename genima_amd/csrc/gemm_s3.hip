@@ -169,6 +169,12 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   // pieces and leaves tile t+2's in flight across the barrier -- and the barrier is the raw s_barrier (a __syncthreads() behind an
   // outstanding LDS-DMA drains vmcnt(0)).  WAR: slot (t+2) % 3 was last read in iteration t-1, before the barrier that ended it.
   constexpr int NIN = GA + GB;  // DMA instructions per wave per tile
+  constexpr int kBudget = 512 / gemm_waves_per_simd(3 * (A_BYTES + B_BYTES), NW);
+  constexpr bool RICH = epi_rich_fits(TM, TN, kBudget);
+  constexpr bool PRE = RICH && epi_prefetch_fits(TM, TN, kBudget);
+  EpiPre<TM, TN> pre;
+  bool use_pre = false;
+  if constexpr (PRE) use_pre = epilogue_prefetch<TM, TN>(p, pre, m0 + wm * WTM, n0 + wn * WTN, l31, hi);  // older than every DMA: retired by the first counted wait
   dma_tile(0);
   dma_tile(1);  // past the last K tile the offsets are out of range: zero fill, no fetch -- the count stays the same on every path
   wait_vmcnt<NIN>();
@@ -205,8 +211,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead zero fills
 
-  constexpr bool RICH = TM * TN * 16 + TN * 8 * 3 + 96 <= 512 / gemm_waves_per_simd(3 * (A_BYTES + B_BYTES), NW);
-  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
 }
 
 template <int BM, int BN, int WM, int WN>
