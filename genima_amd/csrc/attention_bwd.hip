@@ -9,8 +9,9 @@
 // Both follow the forward kernel's transposed formulation (attention.hip): the owner side sits in the MFMA B operand / the lane
 // (= accumulator column), the streamed side is the A operand read from XOR-swizzled LDS tiles whose rows are stored with index bits
 // 2 and 3 swapped, so the 8 accumulators a lane holds per 16-row step are 8 consecutive streamed rows and convert straight into the
-// next MFMA's B operand.  The second product of each kernel needs the streamed operand transposed ([d][row]); those copies
-// (Q^T, K^T, dO^T) are made by gn_transpose2d beforehand (3 x 2 bytes per element, against >= 7 matrix products per score).
+// next MFMA's B operand.  The second product of each kernel needs the streamed operand transposed ([d][row]): it is read out of
+// the SAME row-major LDS tile with ds_read_b64_tr_b16 (tr_frag below) -- round 1 streamed separate Q^T / K^T / dO^T copies made by
+// gn_transpose2d (96 transposes per step, twice the streamed bytes and LDS).
 #include "common.h"
 
 namespace {
@@ -95,8 +96,38 @@ __device__ __forceinline__ void attn_bwd_block(int nblk, int heads, int& blk, in
   blk = slot - bh * nblk;
 }
 
+// ---- the streamed operand TRANSPOSED, straight out of its row-major LDS tile (no Q^T / K^T / dO^T copies in HBM, no second tile
+// per operand in LDS): gfx950's ds_read_b64_tr_b16 hands lane c of a 16-lane group column c of a 4-row x 16-column block whose rows
+// the group's lanes address themselves.  Wanted: the MFMA A fragment of X^T -- d = 32 dt + (lane & 31), streamed rows
+// 32 u + 16 g + 8 hi + (0..7).  Logical row 16 g + 8 hi + 4 half + j sits at physical row 16 g + 8 half + 4 hi + j (rows are stored
+// with index bits 2 and 3 swapped), and the tile's chunk swizzle (row >> 1) & 7 = (half, hi, j >> 1) does not depend on u or g: one
+// byte offset per (dt, half) and lane, immediates for u and g.
+typedef __fp16 bwd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) bwd_h4* bwd_lds_h4_ptr;
+struct BwdH8 { bwd_h4 lo, hi; };
+struct TrOffsets { int off[2][2]; };  // [dt][half]
+__device__ __forceinline__ TrOffsets make_tr_offsets(int lane) {
+  TrOffsets t;
+  const int ti = lane & 15, g2 = (lane >> 4) & 1, hb = lane >> 5;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int prow = 8 * half + 4 * hb + (ti >> 2);
+      const int col = dt * 32 + 16 * g2 + 4 * (ti & 3);
+      t.off[dt][half] = prow * 128 + ((((col >> 3) ^ ((prow >> 1) & 7))) << 4) + ((col & 7) << 1);
+    }
+  return t;
+}
+__device__ __forceinline__ f16x8 tr_frag(const unsigned char* tile, const TrOffsets& t, int dt, int u, int g) {
+  const unsigned char* q = tile + (32 * u + 16 * g) * 128;
+  const bwd_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((bwd_lds_h4_ptr)(q + t.off[dt][0]));
+  const bwd_h4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((bwd_lds_h4_ptr)(q + t.off[dt][1]));
+  return __builtin_bit_cast(f16x8, BwdH8{lo, hi});
+}
+
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 3 * TILE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   int blk, h, b;
@@ -106,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 
   const f16* kp = p.k + (long)b * p.k_bs + h * D;
   const f16* vp = p.v + (long)b * p.v_bs + h * D;
-  const f16* ktp = p.kt + (long)b * p.kt_bs + (long)h * D * p.kt_rs;
+  const TrOffsets tro = make_tr_offsets(lane);
 
   f16x8 qf[4], gf[4];
 #pragma unroll
@@ -129,19 +160,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 
   const int ntiles = (p.Nk + TS - 1) / TS;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  // K / V rows past Nk_rows and the tail of the K^T slab lie beyond the descriptors and read as zeros; key columns of K^T between
-  // Nk_rows and the end of a row hold the next row's (finite) data and meet dS = 0 there
+  // K / V rows past Nk_rows lie beyond the descriptors and read as zeros
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)((((long)p.Nk_rows - 1) * p.k_rs + D) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)((((long)p.Nk_rows - 1) * p.v_rs + D) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)ktp, 0, (int)((long)D * p.kt_rs * 2), 0x00020000);
   TileStream sk = make_stream(wv, lane, p.k_rs, true, (long)TS * p.k_rs * 2);
   TileStream sv = make_stream(wv, lane, p.v_rs, true, (long)TS * p.v_rs * 2);
-  TileStream st = make_stream(wv, lane, p.kt_rs, false, TS * 2);
   auto dma_tile = [&](int buf) {  // the next tile in sequence
-    unsigned char* Ks = smem + buf * 3 * TILE;
+    unsigned char* Ks = smem + buf * 2 * TILE;
     dma_stream(sk, rs_k, Ks, wv);
     dma_stream(sv, rs_v, Ks + TILE, wv);
-    dma_stream(st, rs_t, Ks + 2 * TILE, wv);
   };
   if (ntiles > 0) dma_tile(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -151,9 +178,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
   for (int t = 0; t < ntiles; ++t) {
     const bool more = t + 1 < ntiles;
     if (more) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
-    const unsigned char* Ks = smem + cur * 3 * TILE;
+    const unsigned char* Ks = smem + cur * 2 * TILE;
     const unsigned char* Vs = Ks + TILE;
-    const unsigned char* Ts = Ks + 2 * TILE;
     const int j0 = t * TS;
     const bool need_mask = j0 + TS > p.Nk;
 
@@ -183,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const f16x8 tf = *reinterpret_cast<const f16x8*>(Ts + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
+          const f16x8 tf = tr_frag(Ks, tro, dt, u, g);  // K^T[d][key] out of the row-major K tile
           acc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(tf, dsf[u][g], acc[dt], 0, 0, 0);
         }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 }
 
 // ---- dK, dV ----------------------------------------------------------------------------------------------------------------
-constexpr int KV_BUF = 4 * TILE + 2 * 64 * 4;  // Q, dO, Q^T, dO^T tiles + lse + delta of the query tile
+constexpr int KV_BUF = 2 * TILE + 2 * 64 * 4;  // Q, dO tiles + lse + delta of the query tile
 
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BUF];
@@ -219,8 +245,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
   const f16* qp = p.q + (long)b * p.q_bs + h * D;
   const f16* gp = p.d_o + (long)b * p.do_bs + h * D;
-  const f16* qtp = p.qt + (long)b * p.qt_bs + (long)h * D * p.qt_rs;
-  const f16* gtp = p.dot + (long)b * p.dot_bs + (long)h * D * p.dot_rs;
+  const TrOffsets tro = make_tr_offsets(lane);
   const float* lsep = p.lse + ((long)b * p.heads + h) * p.Nq;
   const float* delp = p.delta + ((long)b * p.heads + h) * p.Nq;
 
@@ -241,24 +266,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
   const int ntiles = (p.Nq + TS - 1) / TS;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  // Q / dO rows past Nq and the tails of the transposed slabs read as zeros; query columns of Q^T / dO^T past Nq inside a row hold the
-  // next row's (finite) data and meet P = dS = 0 there (their lse is +inf)
+  // Q / dO rows past Nq read as zeros (and their lse is +inf: P = dS = 0 there)
   const __amdgpu_buffer_rsrc_t rs_q = __builtin_amdgcn_make_buffer_rsrc((void*)qp, 0, (int)((((long)p.Nq - 1) * p.q_rs + D) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)gp, 0, (int)((((long)p.Nq - 1) * p.do_rs + D) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_qt = __builtin_amdgcn_make_buffer_rsrc((void*)qtp, 0, (int)((long)D * p.qt_rs * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_gt = __builtin_amdgcn_make_buffer_rsrc((void*)gtp, 0, (int)((long)D * p.dot_rs * 2), 0x00020000);
   TileStream sq = make_stream(wv, lane, p.q_rs, true, (long)TS * p.q_rs * 2);
   TileStream sg = make_stream(wv, lane, p.do_rs, true, (long)TS * p.do_rs * 2);
-  TileStream sqt = make_stream(wv, lane, p.qt_rs, false, TS * 2);
-  TileStream sgt = make_stream(wv, lane, p.dot_rs, false, TS * 2);
   int jn = 0;  // first query row of the next tile to stage
   float rl = 0.f, rd = 0.f;
   auto dma_tile = [&](int buf) {  // the next tile in sequence; the 2 x 64 row statistics ride along through one register each
     unsigned char* Qs = smem + buf * KV_BUF;
     dma_stream(sq, rs_q, Qs, wv);
     dma_stream(sg, rs_g, Qs + TILE, wv);
-    dma_stream(sqt, rs_qt, Qs + 2 * TILE, wv);
-    dma_stream(sgt, rs_gt, Qs + 3 * TILE, wv);
     if (tid < 64) {
       const bool live = jn + tid < p.Nq;
       rl = live ? lsep[jn + tid] : INFINITY;  // dead query rows: P = exp2(.. - inf) = 0
@@ -269,8 +287,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
   auto store_stats = [&](int buf) {
     if (tid < 64) {
       unsigned char* Qs = smem + buf * KV_BUF;
-      reinterpret_cast<float*>(Qs + 4 * TILE)[tid] = rl;
-      reinterpret_cast<float*>(Qs + 4 * TILE + 256)[tid] = rd;
+      reinterpret_cast<float*>(Qs + 2 * TILE)[tid] = rl;
+      reinterpret_cast<float*>(Qs + 2 * TILE + 256)[tid] = rd;
     }
   };
   if (ntiles > 0) {
@@ -286,9 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
     if (more) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
     const unsigned char* Qs = smem + cur * KV_BUF;
     const unsigned char* Gs = Qs + TILE;
-    const unsigned char* QTs = Qs + 2 * TILE;
-    const unsigned char* GTs = Qs + 3 * TILE;
-    const float* Ls = reinterpret_cast<const float*>(Qs + 4 * TILE);
+    const float* Ls = reinterpret_cast<const float*>(Qs + 2 * TILE);
     const float* Ds = Ls + 64;
 
     f32x16 s[2], dp[2];
@@ -326,8 +342,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-          const f16x8 gt = *reinterpret_cast<const f16x8*>(GTs + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
-          const f16x8 qt = *reinterpret_cast<const f16x8*>(QTs + lds_swz<128>(dt * 32 + l31, u * 4 + g * 2 + hi));
+          const f16x8 gt = tr_frag(Gs, tro, dt, u, g);  // dO^T[d][query] and Q^T[d][query] out of the row-major tiles
+          const f16x8 qt = tr_frag(Qs, tro, dt, u, g);
           accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gt, pf[u][g], accV[dt], 0, 0, 0);
           accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qt, dsf[u][g], accK[dt], 0, 0, 0);
         }
@@ -360,19 +376,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p
 
 extern "C" int32_t gn_attention_bwd(gn_ctx* ctx, const gn_attn_bwd_desc* d) {
   GN_REQUIRE(ctx && d, "gn_attention_bwd: null ctx/desc");
-  GN_REQUIRE(d->q && d->k && d->v && d->o && d->d_o && d->qt && d->kt && d->dot && d->lse && d->delta && d->dq && d->dk && d->dv,
-             "gn_attention_bwd: null pointer");
+  GN_REQUIRE(d->q && d->k && d->v && d->o && d->d_o && d->lse && d->delta && d->dq && d->dk && d->dv, "gn_attention_bwd: null pointer");
   GN_REQUIRE(d->D == 64, "gn_attention_bwd: head dim %d unsupported (64)", d->D);
   GN_REQUIRE(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0 && d->Nq % 8 == 0 && d->Nk_rows % 8 == 0 && d->Nk_rows >= d->Nk,
              "gn_attention_bwd: Nq (%d) and Nk_rows (%d) must be multiples of 8, Nk_rows >= Nk (%d)", d->Nq, d->Nk_rows, d->Nk);
-  const int64_t bs[] = {d->q_bs, d->k_bs, d->v_bs, d->o_bs, d->do_bs, d->qt_bs, d->kt_bs, d->dot_bs};
-  const int32_t rs[] = {d->q_rs, d->k_rs, d->v_rs, d->o_rs, d->do_rs, d->qt_rs, d->kt_rs, d->dot_rs};
-  for (int i = 0; i < 8; ++i) GN_REQUIRE(bs[i] % 8 == 0 && rs[i] % 8 == 0, "gn_attention_bwd: input strides must be multiples of 8");
+  const int64_t bs[] = {d->q_bs, d->k_bs, d->v_bs, d->o_bs, d->do_bs};
+  const int32_t rs[] = {d->q_rs, d->k_rs, d->v_rs, d->o_rs, d->do_rs};
+  for (int i = 0; i < 5; ++i) GN_REQUIRE(bs[i] % 8 == 0 && rs[i] % 8 == 0, "gn_attention_bwd: input strides must be multiples of 8");
   GN_REQUIRE(d->dq_rs % 4 == 0 && d->dk_rs % 4 == 0 && d->dv_rs % 4 == 0 && d->dq_bs % 4 == 0 && d->dk_bs % 4 == 0 && d->dv_bs % 4 == 0,
              "gn_attention_bwd: output strides must be multiples of 4");
-  GN_REQUIRE(d->qt_rs >= d->Nq && d->dot_rs >= d->Nq && d->kt_rs >= d->Nk_rows, "gn_attention_bwd: transposed copies too narrow");
-  const void* in[] = {d->q, d->k, d->v, d->o, d->d_o, d->qt, d->kt, d->dot};
-  for (int i = 0; i < 8; ++i) GN_REQUIRE(((uintptr_t)in[i] & 15) == 0, "gn_attention_bwd: inputs must be 16-byte aligned");
+  const void* in[] = {d->q, d->k, d->v, d->o, d->d_o};
+  for (int i = 0; i < 5; ++i) GN_REQUIRE(((uintptr_t)in[i] & 15) == 0, "gn_attention_bwd: inputs must be 16-byte aligned");
   GN_REQUIRE(((uintptr_t)d->dq & 7) == 0 && ((uintptr_t)d->dk & 7) == 0 && ((uintptr_t)d->dv & 7) == 0, "gn_attention_bwd: outputs must be 8-byte aligned");
   GN_REQUIRE(d->scale > 0.0f, "gn_attention_bwd: scale must be positive");
   AttnBwdParams p;

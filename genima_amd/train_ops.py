@@ -241,18 +241,13 @@ def attention_bwd(E: Engine, q, q_off: int, k, k_off: int, v, o, d_o, lse, heads
     Nkr, ldk = k.shape[1], k.shape[2]
     Cc = v.shape[-1]
     D = Cc // heads
-    qt = transpose2d(E, q, N, Cc, ld_in=ldq, batch=B, in_bs=N * ldq, in_off=q_off).view(B, Cc, -1)
-    kt = transpose2d(E, k, Nkr, Cc, ld_in=ldk, batch=B, in_bs=Nkr * ldk, in_off=k_off).view(B, Cc, -1)
-    dot = transpose2d(E, d_o, N, Cc, batch=B, in_bs=N * Cc).view(B, Cc, -1)
     delta = torch.empty((B, heads, N), dtype=F32, device=E.device)
     d = AttnBwdDesc()
     d.q, d.k, d.v, d.o, d.d_o = q.data_ptr() + 2 * q_off, k.data_ptr() + 2 * k_off, _ptr(v), _ptr(o), _ptr(d_o)
-    d.qt, d.kt, d.dot, d.lse, d.delta = _ptr(qt), _ptr(kt), _ptr(dot), _ptr(lse), _ptr(delta)
+    d.lse, d.delta = _ptr(lse), _ptr(delta)  # (qt / kt / dot stay NULL: the kernels transpose out of their LDS tiles)
     d.dq, d.dk, d.dv = dq.data_ptr() + 2 * q_off, dk.data_ptr() + 2 * k_off, _ptr(dv)
     d.q_bs, d.k_bs, d.v_bs, d.o_bs, d.do_bs = q.stride(0), k.stride(0), v.stride(0), o.stride(0), d_o.stride(0)
     d.q_rs, d.k_rs, d.v_rs, d.o_rs, d.do_rs = q.stride(1), k.stride(1), v.stride(1), o.stride(1), d_o.stride(1)
-    d.qt_bs, d.kt_bs, d.dot_bs = qt.stride(0), kt.stride(0), dot.stride(0)
-    d.qt_rs, d.kt_rs, d.dot_rs = qt.stride(1), kt.stride(1), dot.stride(1)
     d.dq_bs, d.dk_bs, d.dv_bs = dq.stride(0), dk.stride(0), dv.stride(0)
     d.dq_rs, d.dk_rs, d.dv_rs = dq.stride(1), dk.stride(1), dv.stride(1)
     d.B, d.heads, d.Nq, d.Nk, d.Nk_rows, d.D, d.scale = B, heads, N, nk_valid, Nkr, D, float(D) ** -0.5

@@ -131,8 +131,9 @@ int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d);
 /* Flash-attention backward (D = 64; xformers memory-efficient attention backward under accelerator.backward,
  * diffusion/train_controlnet_genima.py:1125-1126, :1402).  P is recomputed per tile from q, k and the forward's lse; two
  * deterministic kernels (dQ over key tiles; dK, dV over query tiles), no atomics.  q / k / v / o / d_o and the gradients are
- * row-major [B][rows][ld] with head h at column h*D of the given base pointer; qt / kt / dot are gn_transpose2d copies
- * [B][heads*D][rows_pad] of Q, K and dO.  Rows Nk .. Nk_rows-1 of k / v must be zero padding (their dk / dv rows are left
+ * row-major [B][rows][ld] with head h at column h*D of the given base pointer; qt / kt / dot (transposed copies of Q, K, dO that
+ * round 1's kernels streamed) are IGNORED and may be NULL: the kernels read the transposed operand out of the row-major LDS tile
+ * with ds_read_b64_tr_b16.  Rows Nk .. Nk_rows-1 of k / v must be zero padding (their dk / dv rows are left
  * untouched); Nq and Nk_rows are multiples of 8.  delta: f32 [B][heads][Nq] scratch (sum_d dO*O, written here). */
 typedef struct gn_attn_bwd_desc {
   const void* q; const void* k; const void* v; const void* o; const void* d_o;
