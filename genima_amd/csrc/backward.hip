@@ -847,15 +847,22 @@ int32_t gn_softmax_bwd(gn_ctx* ctx, const void* p, void* dp, int64_t rows, int32
   return GN_OK;
 }
 
+// rows per workgroup: 64 on long inputs, fewer on short ones so that >= 256 workgroups exist (M = 2048 gave 32 workgroups: 46 us)
+static int lnb_rows_per_block(int64_t M) {
+  int rpb = 64;
+  while (rpb > 8 && (M + rpb - 1) / rpb < 256) rpb >>= 1;
+  return rpb;
+}
 int64_t gn_layernorm_bwd_workspace_bytes(int64_t M, int32_t C) {
-  const int64_t blocks = (M + 63) / 64;
+  const int rpb = lnb_rows_per_block(M);
+  const int64_t blocks = (M + rpb - 1) / rpb;
   return blocks * 4 * 2 * C * 4;
 }
 int32_t gn_layernorm_bwd(gn_ctx* ctx, const void* x, const void* gamma, const void* dy, void* dx, float* dgamma, float* dbeta, void* workspace,
                          int64_t M, int32_t C, float eps, const void* dx_add) {
   GN_REQUIRE(ctx && x && gamma && dy && dx && M > 0 && C > 0 && C % 8 == 0 && C <= 64 * 8 * LNB_MAXCH, "gn_layernorm_bwd: C must be a multiple of 8, <= %d", 64 * 8 * LNB_MAXCH);
   GN_REQUIRE((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || workspace), "gn_layernorm_bwd: dgamma/dbeta come together and need a workspace");
-  const int rpb = 64;
+  const int rpb = lnb_rows_per_block(M);
   const long blocks = (M + rpb - 1) / rpb;
   float* part = dgamma ? (float*)workspace : nullptr;
   const int CC = C / 8;
