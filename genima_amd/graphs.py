@@ -323,9 +323,13 @@ def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor, hidden: Optional[List[t
             p = f"text_model.encoder.layers.{i}"
             with E.scope(f"l{i}"):
                 n = E.layernorm(x, W[p + ".layer_norm1.weight"], W[p + ".layer_norm1.bias"], eps, name="ln1")
-                qk = E.linear(n, W[p + ".self_attn.qk_proj.weight"], W[p + ".self_attn.qk_proj.bias"], name="qk")
-                vt = E.linear(n, W[p + ".self_attn.v_proj.weight"], W[p + ".self_attn.v_proj.bias"], transposed_out=True,
-                              rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
+                if p + ".self_attn.qkv_proj.weight" in W:  # q | k | v in one two-destination launch
+                    qk, vt = E.linear(n, W[p + ".self_attn.qkv_proj.weight"], W[p + ".self_attn.qkv_proj.bias"], split_n=2 * D,
+                                      rows_per_batch=L, pad_cols=_rup(L, 64), name="qk")
+                else:
+                    qk = E.linear(n, W[p + ".self_attn.qk_proj.weight"], W[p + ".self_attn.qk_proj.bias"], name="qk")
+                    vt = E.linear(n, W[p + ".self_attn.v_proj.weight"], W[p + ".self_attn.v_proj.bias"], transposed_out=True,
+                                  rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
                 a = E.attention(qk[:, :, :D], qk[:, :, D:], vt, heads, causal=True, name="sa")
                 x = E.linear(a, W[p + ".self_attn.out_proj.weight"], W[p + ".self_attn.out_proj.bias"], residual=x, name="o")
                 n = E.layernorm(x, W[p + ".layer_norm2.weight"], W[p + ".layer_norm2.bias"], eps, name="ln2")

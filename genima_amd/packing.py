@@ -135,6 +135,12 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
                 qb, kb = name[: -len("weight")] + "bias", (base + kn)[: -len("weight")] + "bias"
                 if qb in sd:
                     out[(base + fused)[: -len("weight")] + "bias"] = torch.cat([sd[qb], sd[kb]]).to(dtype).contiguous()
+                if qn == ".self_attn.q_proj.weight" and base + ".self_attn.v_proj.weight" in sd:
+                    # CLIP towers: q | k | v (+ their biases) as one two-destination launch too
+                    vw = base + ".self_attn.v_proj.weight"
+                    out[base + ".self_attn.qkv_proj.weight"] = torch.cat([sd[name], sd[base + kn], sd[vw]], dim=0).to(dtype).contiguous()
+                    if qb in sd:
+                        out[base + ".self_attn.qkv_proj.bias"] = torch.cat([sd[qb], sd[kb], sd[vw[: -len("weight")] + "bias"]]).to(dtype).contiguous()
                 if qn == ".attn1.to_q.weight" and base + ".attn1.to_v.weight" in sd and qb not in sd:
                     # q | k | v as ONE launch (two-destination GEMM: q, k row-major + V^T): the inference graphs' self-attention
                     out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
