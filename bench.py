@@ -238,10 +238,13 @@ def main():
     dev = torch.device("cuda", local)
 
     from genima_amd import configs
-    from genima_amd.pipeline import StableDiffusionControlNetPipeline
+    from genima_amd.pipeline import StableDiffusionControlNetPipeline, StableDiffusionXLControlNetPipeline
 
     B, H, W, desc = WORKLOADS[args.workload]
-    pipe = StableDiffusionControlNetPipeline.from_synthetic(configs.family(args.family), seed=0, gen_device=dev)
+    fam_cfg = configs.family(args.family)
+    # the SDXL families (BASELINE.json configs[4]'s agent: controller/agent/sdxl_controlnet_agent.py) have two text towers
+    pipe_cls = StableDiffusionXLControlNetPipeline if "text_2" in fam_cfg else StableDiffusionControlNetPipeline
+    pipe = pipe_cls.from_synthetic(fam_cfg, seed=0, gen_device=dev)
     pipe.to(dev)
     for m in (pipe.vae, pipe.text_encoder, pipe.unet, pipe.controlnet):
         m._sd = None  # fp32 masters are not needed for inference; keep only the packed f16 copy resident
@@ -312,12 +315,13 @@ def main():
         torch.cuda.synchronize(dev)
         act_ms = (time.perf_counter() - t2) / 5 * 1000.0
 
+    label = {"sd-turbo": "SD-Turbo"}.get(args.family, args.family)  # other families (sdxl-turbo: configs[4]'s agent) name themselves
     out = {
-        "metric": "joint-target images/sec (SD-Turbo + ControlNet, 4-view tiled 512x512, 5 steps, incl. CLIP text + VAE decode)"
-        if H == 512 else "images/sec (SD-Turbo + ControlNet 256x256 single view, 5 steps, incl. CLIP text + VAE decode)",
+        "metric": f"joint-target images/sec ({label} + ControlNet, 4-view tiled 512x512, 5 steps, incl. CLIP text + VAE decode)"
+        if H == 512 else f"images/sec ({label} + ControlNet 256x256 single view, 5 steps, incl. CLIP text + VAE decode)",
         "value": value, "unit": "images/sec", "n_gpus": world, "steps": calls, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / calls, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (f32 accumulate)", "data": "synthetic (seeded random-init SD-Turbo-architecture weights, counter-PRNG images)",
+        "dtype": "f16 (f32 accumulate)", "data": f"synthetic (seeded random-init {label}-architecture weights, counter-PRNG images)",
         "config": {"workload": desc, "family": args.family, "per_gpu_batch": B, "global_batch": B * world,
                    "image": f"{H}x{W}", "denoise_steps": args.denoise_steps, "parallelism": f"replicas x{world} (episodes sharded, no collective)",
                    "hip_graph": bool(args.graph), "act_controller_forward": act_agent is not None,
