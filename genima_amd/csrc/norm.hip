@@ -97,45 +97,43 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
 }
 
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const GNParams p) {
-  // all 256 threads share the partial reduction: thread (g, part) sums chunks part, part + P, ... (independent loads), the
-  // P part sums are then combined in a fixed order -> deterministic, and the dependent-load chain is chunks / P long.
+  // one workgroup per (group, sample): thread t sums chunks t, t + 256, ... (f64), the 256 partial sums are combined in a fixed
+  // order -> deterministic; then the group's channels get their folded scale / shift.  (A workgroup per SAMPLE walked all G x chunks
+  // partials with B workgroups on the chip: ~7 us of latency per launch.)
   __shared__ double dsum[256], dsq[256];
-  __shared__ float mean_s[256], rstd_s[256];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int P = 256 / p.G;
-  const int g = tid % p.G, part = tid / p.G;
+  __shared__ float ms[2];
+  const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
   double s = 0.0, ss = 0.0;
-  if (part < P) {
-    for (int ch = part; ch < p.chunks; ch += P) {
-      const float2 in = *reinterpret_cast<const float2*>(p.partials + (((long)b * p.chunks + ch) * p.G + g) * 2);
-      s += (double)in.x;
-      ss += (double)in.y;
-    }
+  for (int ch = tid; ch < p.chunks; ch += 256) {
+    const float2 in = *reinterpret_cast<const float2*>(p.partials + (((long)b * p.chunks + ch) * p.G + g) * 2);
+    s += (double)in.x;
+    ss += (double)in.y;
   }
   dsum[tid] = s;
   dsq[tid] = ss;
   __syncthreads();
-  if (tid < p.G) {
+  if (tid == 0) {
     double ts = 0.0, tss = 0.0;
-    for (int q = 0; q < P; ++q) { ts += dsum[q * p.G + tid]; tss += dsq[q * p.G + tid]; }
+    const int n_t = p.chunks < 256 ? p.chunks : 256;
+    for (int q = 0; q < n_t; ++q) { ts += dsum[q]; tss += dsq[q]; }
     const double n = (double)p.HW * (double)p.cpg;
     const double mean = ts / n;
     double var = tss / n - mean * mean;
     if (var < 0.0) var = 0.0;
-    mean_s[tid] = (float)mean;
-    rstd_s[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+    ms[0] = (float)mean;
+    ms[1] = (float)(1.0 / sqrt(var + (double)p.eps));
     if (p.stats) {  // training: keep (mean, rstd) per (batch, group) for the backward pass
-      p.stats[((long)b * p.G + tid) * 2] = mean_s[tid];
-      p.stats[((long)b * p.G + tid) * 2 + 1] = rstd_s[tid];
+      p.stats[((long)b * p.G + g) * 2] = ms[0];
+      p.stats[((long)b * p.G + g) * 2 + 1] = ms[1];
     }
   }
   __syncthreads();
-  for (int c = tid; c < p.C; c += 256) {
-    const int gg = c / p.cpg;
-    const float a = rstd_s[gg] * (float)p.gamma[c];
+  for (int ci = tid; ci < p.cpg; ci += 256) {
+    const int c = g * p.cpg + ci;
+    const float a = ms[1] * (float)p.gamma[c];
     float* o = p.scsh + ((long)b * p.C + c) * 2;
     o[0] = a;
-    o[1] = (float)p.beta[c] - mean_s[gg] * a;
+    o[1] = (float)p.beta[c] - ms[0] * a;
   }
 }
 
@@ -425,7 +423,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   }
   hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
   GN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, ctx->stream, p);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, dim3(p.achunks, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
