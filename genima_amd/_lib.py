@@ -45,7 +45,7 @@ class AttnDesc(C.Structure):
         ("q_bs", C.c_int64), ("k_bs", C.c_int64), ("vt_bs", C.c_int64), ("o_bs", C.c_int64),
         ("q_rs", C.c_int32), ("k_rs", C.c_int32), ("vt_rs", C.c_int32), ("o_rs", C.c_int32),
         ("B", C.c_int32), ("heads", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
-        ("causal", C.c_int32), ("scale", C.c_float), ("lse", C.c_void_p),
+        ("causal", C.c_int32), ("scale", C.c_float), ("lse", C.c_void_p), ("v_rowmajor", C.c_int32),
     ]
 
 

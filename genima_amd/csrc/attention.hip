@@ -34,8 +34,16 @@
 
 namespace {
 
-template <int D, int NW, int TQ>
+// VROW (D = 64 only): `vt` points at V in row-major form [B][Nk][vt_rs] (head h at column h * D) -- the layout a plain q | k | v
+// projection leaves it in.  Its LDS tile is then filled like the K tile and the P.V A-operand (8 consecutive keys of one d) comes out
+// through ds_read_b64_tr_b16, as in attention_bwd.hip.
+typedef __fp16 attn_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+typedef __attribute__((address_space(3))) attn_h4* attn_lds_h4_ptr;
+struct AttnH8 { attn_h4 lo, hi; };
+
+template <int D, int NW, int TQ, bool VROW = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+  static_assert(!VROW || D == 64, "row-major V: the LDS-DMA (D = 64) path only");
   constexpr int NT = NW * 64;
   constexpr int QB = NW * TQ * 32;   // query rows per block
   constexpr int ROWB = D * 2;        // K tile row bytes
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 
   const f16* qp = p.q + (long)b * p.q_bs + (long)h * D;
   const f16* kp = p.k + (long)b * p.k_bs + (long)h * D;
-  const f16* vp = p.vt + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
+  const f16* vp = VROW ? p.vt + (long)b * p.vt_bs + (long)h * D : p.vt + (long)b * p.vt_bs + (long)h * D * p.vt_rs;
 
   // Q fragments (B operand): lane holds Q[qrow][16*ks + 8*hi .. +8]
   f16x8 qf[TQ][KS];
@@ -118,11 +126,24 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
       const int chunk = (lane & 7) ^ ((row >> 1) & 7);
       const int key = (row & 32) | swap23(row & 31);
       koff[i] = (unsigned)(((long)key * p.k_rs + chunk * 8) * 2);
-      voff[i] = (unsigned)(((long)row * p.vt_rs + chunk * 8) * 2);
+      voff[i] = VROW ? (unsigned)(((long)key * p.vt_rs + chunk * 8) * 2) : (unsigned)(((long)row * p.vt_rs + chunk * 8) * 2);
     }
   }
+  // transpose-read offsets of the row-major V tile: [dt][half] (attention_bwd.hip make_tr_offsets)
+  int troff[2][2];
+  if constexpr (VROW) {
+    const int ti = lane & 15, g2 = (lane >> 4) & 1, hb = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int prow = 8 * half + 4 * hb + (ti >> 2);
+        const int col = dt * 32 + 16 * g2 + 4 * (ti & 3);
+        troff[dt][half] = prow * 128 + ((((col >> 3) ^ ((prow >> 1) & 7))) << 4) + ((col & 7) << 1);
+      }
+  }
   const long kbytes = ((long)(p.Nk - 1) * p.k_rs + D) * 2;
-  const long vbytes = ((long)(D - 1) * p.vt_rs + (long)((p.Nk + KT - 1) / KT) * KT) * 2;
+  const long vbytes = VROW ? ((long)(p.Nk - 1) * p.vt_rs + D) * 2 : ((long)(D - 1) * p.vt_rs + (long)((p.Nk + KT - 1) / KT) * KT) * 2;
   const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)kbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)vbytes, 0x00020000);
   auto dma_tile = [&](int buf) {  // issues the NEXT tile in sequence (offsets advance by one tile per call)
@@ -134,7 +155,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (attn_lds_ptr_t)(Ks + (wv + NW * i) * 1024), 16, koff[i], 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_v, (attn_lds_ptr_t)(Vs + (wv + NW * i) * 1024), 16, voff[i], 0, 0, 0);
         koff[i] += (unsigned)(KT * p.k_rs * 2);
-        voff[i] += (unsigned)(KT * 2);
+        voff[i] += VROW ? (unsigned)(KT * p.vt_rs * 2) : (unsigned)(KT * 2);
       }
     }
   };
@@ -211,7 +232,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const unsigned char* Vs = Ks + K_BYTES;
     const int j0 = t * KT;
     const bool need_mask = (j0 + KT > p.Nk) || (p.causal && j0 + KT - 1 > q0);  // block-uniform
-    if (DMA && j0 + KT > p.Nk) {
+    if (DMA && !VROW && j0 + KT > p.Nk) {  // (row-major V: rows past Nk lie beyond the descriptor and arrive as zeros)
       // last tile of a ragged key count (block-uniform, rare): the DMA brought V^T's pad columns in as they are, and they are not
       // trusted (P is exactly 0 there, but 0 * NaN is NaN): clear the dead keys of the tile in LDS before anyone reads it
       unsigned char* Vw = smem + cur * (K_BYTES + V_BYTES) + K_BYTES;
@@ -331,7 +352,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int sstep = 0; sstep < 2; ++sstep) {
-          const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(dt * 32 + l31, u * 4 + sstep * 2 + hi));
+          f16x8 vf;
+          if constexpr (VROW) {
+            const unsigned char* q = Vs + (32 * u + 16 * sstep) * 128;
+            const attn_h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((attn_lds_h4_ptr)(q + troff[dt][0]));
+            const attn_h4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((attn_lds_h4_ptr)(q + troff[dt][1]));
+            vf = __builtin_bit_cast(f16x8, AttnH8{lo, hi4});
+          } else {
+            vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(dt * 32 + l31, u * 4 + sstep * 2 + hi));
+          }
 #pragma unroll
           for (int tq = 0; tq < TQ; ++tq)
             oacc[tq][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[tq][u][sstep], oacc[tq][dt], 0, 0, 0);
@@ -364,11 +393,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
   }
 }
 
-template <int D, int NW, int TQ>
+template <int D, int NW, int TQ, bool VROW = false>
 void launch_attn(const AttnParams& p, int B, hipStream_t st) {
   constexpr int QB = NW * TQ * 32;
   dim3 grid(((p.Nq + QB - 1) / QB) * p.heads * B);
-  hipLaunchKernelGGL((attn_fwd_kernel<D, NW, TQ>), grid, dim3(NW * 64), 0, st, p);
+  hipLaunchKernelGGL((attn_fwd_kernel<D, NW, TQ, VROW>), grid, dim3(NW * 64), 0, st, p);
 }
 
 int attn_variant_override() {
@@ -388,7 +417,8 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   GN_REQUIRE(d->D == 64 || d->D == 32, "gn_attention_fwd: head dim %d unsupported (32 or 64)", d->D);
   GN_REQUIRE(d->B > 0 && d->heads > 0 && d->Nq > 0 && d->Nk > 0, "gn_attention_fwd: empty problem");
   GN_REQUIRE(d->q_rs % 8 == 0 && d->k_rs % 8 == 0 && d->vt_rs % 8 == 0 && d->o_rs % 4 == 0, "gn_attention_fwd: row strides must be multiples of 8 (o: 4)");
-  GN_REQUIRE(d->vt_rs >= ((d->Nk + 63) / 64) * 64, "gn_attention_fwd: vt row stride %d must cover round_up(Nk=%d, 64)", d->vt_rs, d->Nk);
+  if (d->v_rowmajor) GN_REQUIRE(d->D == 64 && d->vt_rs >= d->heads * d->D, "gn_attention_fwd: row-major V needs D = 64 and a row stride >= heads * D");
+  else GN_REQUIRE(d->vt_rs >= ((d->Nk + 63) / 64) * 64, "gn_attention_fwd: vt row stride %d must cover round_up(Nk=%d, 64)", d->vt_rs, d->Nk);
   GN_REQUIRE(((uintptr_t)d->q & 15) == 0 && ((uintptr_t)d->k & 15) == 0 && ((uintptr_t)d->vt & 15) == 0 && ((uintptr_t)d->o & 7) == 0, "gn_attention_fwd: pointer alignment");
   GN_REQUIRE(d->q_bs % 8 == 0 && d->k_bs % 8 == 0 && d->vt_bs % 8 == 0 && d->o_bs % 4 == 0, "gn_attention_fwd: batch strides alignment");
   GN_REQUIRE(d->scale > 0.0f, "gn_attention_fwd: scale must be positive");
@@ -409,6 +439,7 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
     if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
     else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
     else if (ov == 3) gn_launch_attention_pipe(p, d->B, ctx->stream);
+    else if (d->v_rowmajor) launch_attn<64, 4, 1, true>(p, d->B, ctx->stream);
     else launch_attn<64, 4, 1>(p, d->B, ctx->stream);
   }
   GN_LAUNCH_CHECK();

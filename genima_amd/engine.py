@@ -464,9 +464,10 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ attention
     def attention(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, Nk: Optional[int] = None,
                   causal: bool = False, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
-                  lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  lse: Optional[torch.Tensor] = None, v_rowmajor: bool = False) -> torch.Tensor:
         """q: [B, Nq, heads*D] view (last dim contiguous, may be a column slice), k: [B, Nk, heads*D] view,
-        vt: [B, heads*D, Nk_pad] (V transposed).  Returns o [B, Nq, heads*D].  lse: optional f32 [B, heads, Nq] (training)."""
+        vt: [B, heads*D, Nk_pad] (V transposed) -- or, with v_rowmajor (D = 64), V itself as a [B, Nk, heads*D] view.
+        Returns o [B, Nq, heads*D].  lse: optional f32 [B, heads, Nq] (training)."""
         B, Nq, Cq = q.shape
         D = Cq // heads
         Nk = k.shape[1] if Nk is None else Nk
@@ -478,6 +479,7 @@ class Engine:
         d.q_rs, d.k_rs, d.vt_rs, d.o_rs = q.stride(1), k.stride(1), vt.stride(1), out.stride(1)
         d.B, d.heads, d.Nq, d.Nk, d.D, d.causal, d.scale = B, heads, Nq, Nk, D, int(causal), float(D) ** -0.5
         d.lse = _ptr(lse)
+        d.v_rowmajor = int(v_rowmajor)
         if self.record:
             check(self.lib.gn_program_add_attention(self._prog, C.byref(d)), "gn_program_add_attention")
             self._keepalive(q, k, vt, out)

@@ -125,6 +125,8 @@ typedef struct gn_attn_desc {
   float scale;
   float* lse;                        /* optional f32 [B][heads][Nq]: log2-domain log-sum-exp of the scaled scores, kept for
                                         gn_attention_bwd (training); NULL in inference */
+  int32_t v_rowmajor;                /* 1 (D = 64): `vt` is V itself, row-major [B][Nk][vt_rs] with head h at column h*D (what a plain
+                                        q | k | v projection writes); the kernel transposes out of its LDS tile (ds_read_b64_tr_b16) */
 } gn_attn_desc;
 int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d);
 

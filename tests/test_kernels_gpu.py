@@ -169,6 +169,22 @@ def test_attention_strided_qk_and_spike(engine):
     assert_close(o, ref, rel=2e-3, what="strided/spiked attention")
 
 
+@pytest.mark.parametrize("heads,Nq,Nk,causal", [(5, 512, 512, False), (4, 200, 77, False), (2, 77, 77, True)])
+def test_attention_rowmajor_v(engine, heads, Nq, Nk, causal):
+    """gn_attn_desc.v_rowmajor: V handed over row-major (a column slice of a q | k | v projection) and transposed out of the LDS tile
+    by the kernel -- bit-identical to the V^T path, ragged key counts included."""
+    C = heads * 64
+    q, kv = randn_h(2, Nq, C, seed=21), randn_h(2, Nk, 2 * C, seed=22)
+    k, v = kv[:, :, :C], kv[:, :, C:]
+    pad = (Nk + 63) // 64 * 64
+    vt = torch.zeros(2, C, pad, dtype=torch.float16, device="cuda")
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    o1 = engine.attention(q, k, vt, heads, Nk=Nk, causal=causal).clone()
+    o2 = engine.attention(q, k, v, heads, Nk=Nk, causal=causal, v_rowmajor=True)
+    assert torch.equal(o1, o2)
+    assert_close(o2, ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, causal=causal), rel=2e-3, what="row-major V attention")
+
+
 # ---------------------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("B,H,W,C,act", [(2, 64, 64, 320, 1), (1, 8, 8, 1280, 1), (2, 32, 32, 128, 0), (1, 128, 128, 128, 1),
                                          (1, 16, 16, 2560, 1), (2, 7, 9, 64, 1)])
