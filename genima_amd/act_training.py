@@ -127,8 +127,7 @@ class ACTTrainer:
     def _block(self, g: Graph, hv: Var, p: str, c: int, stride: int, film: Optional[Var], bi: int, rows_pf: int) -> Var:
         net, bn = self.cn, self.bn
         x_in = hv
-        if stride == 2:  # 1x1 / 3x3 stride-2 convs of the block's first unit; the 1x1 shortcut sub-samples explicitly (copy4d)
-            pass
+        # (stride 2: the 3x3 conv strides itself; the 1x1 shortcut below sub-samples explicitly through copy4d)
         y = g.conv(net, hv, p + ".conv1.weight", None, stride=stride)
         rows_all = y.t.numel() // c
         y = g.film(y, *bn[p + ".bn1"], rows_all)
