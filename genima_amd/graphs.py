@@ -71,15 +71,25 @@ def _shift_for(W, shifts: Optional[torch.Tensor], prefix: str):
 # ------------------------------------------------------------------------------------------------ blocks
 def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float):
     with E.scope(p):
+        has_sc = (p + ".conv_shortcut.weight") in W
+        # the 1x1 shortcut conv only reads the block input: where the program's side stream is idle (the UNet decoder, after the
+        # ControlNet has been joined) AND the batch is too small to fill the chip, it runs there beside GroupNorm -> conv1 -> GroupNorm
+        side = has_sc and getattr(E, "side_free", False) and E.record
+        if has_sc:
+            if side:
+                E.fork()
+            sc = E.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"], ksize=1, x2=x2, name="sc")
+            if side:
+                E.main()
+        else:
+            assert x2 is None
+            sc = x
         h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps, act=ACT_SILU, x2=x2, name="n1")
         sh, ld = _shift_for(W, shifts, p) if (p + ".time_emb_proj.weight") in W else (None, 0)
         h = E.conv2d(h, W[p + ".conv1.weight"], W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
         h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
-        if (p + ".conv_shortcut.weight") in W:
-            sc = E.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"], ksize=1, x2=x2, name="sc")
-        else:
-            assert x2 is None
-            sc = x
+        if side:
+            E.join()
         return E.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], residual=sc, name="c2")
 
 
@@ -165,6 +175,7 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
         h = _emit_mid(E, W, cfg, h, shifts, kv)
         if before_residuals is not None:
             before_residuals()
+            E.side_free = x8.shape[0] * x8.shape[1] * x8.shape[2] <= 4096  # the caller joined its side stream: free for the decoder at small batch
         # the residual adds only feed the decoder, so they sit after the mid block (same values; lets the encoder + mid overlap the ControlNet)
         if down_res is not None:
             skips = [E.add(s, r, name=f"skip_add{i}") for i, (s, r) in enumerate(zip(skips, down_res))]
@@ -179,6 +190,7 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
             if i != nlev - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
+        E.side_free = False
         h = E.groupnorm(h, W["conv_norm_out.weight"], W["conv_norm_out.bias"], G, eps, act=ACT_SILU, name="norm_out")
         return E.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], name="conv_out")
 
