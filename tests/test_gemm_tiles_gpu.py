@@ -92,3 +92,65 @@ def test_f32_accumulate_and_transposed_every_tile(eng, tile_override, tile):
     full = a.float().cpu() @ w3.float().cpu().t() + b3.float().cpu()
     assert_close(qk.reshape(M, 2 * Cq), full[:, : 2 * Cq], what=f"tile {tile} q|k part")
     assert_close(vt.view(Bn, Cq, pad)[:, :, :rows], full[:, 2 * Cq:].view(Bn, rows, Cq).permute(0, 2, 1), what=f"tile {tile} V^T part")
+
+
+def test_linear_random_shapes_and_tiles(eng, tile_override):
+    """Seeded sweep: random (M, N, K) -- row / column / reduction tails everywhere --, random tile, random epilogue (bias, residual before or
+    after the activation, activation) against torch; the tails decide which loader / epilogue branches run, so the fixed shapes above are
+    not enough on their own."""
+    import random
+
+    rnd = random.Random(1234)
+    for case in range(80):
+        tile = rnd.randint(1, N_TILES)
+        M = rnd.choice([1, 7, 31, 33, 64, 100, 129, 255, 300, 777, 1024, 2050])
+        N = 4 * rnd.randint(1, 100) if rnd.random() < 0.5 else rnd.choice([64, 128, 160, 320, 328, 640, 72, 8])
+        K = 8 * rnd.randint(1, 40) if rnd.random() < 0.5 else rnd.choice([64, 128, 320, 1024])
+        act = rnd.choice([0, 0, 1, 2, 4])
+        use_b, use_r, rfirst = rnd.random() < 0.7, rnd.random() < 0.6, rnd.random() < 0.3
+        tile_override(tile)
+        x, w = randn_h(M, K, seed=case), randn_h(N, K, seed=1000 + case, scale=K ** -0.5)
+        b = randn_h(N, seed=2000 + case, scale=0.3) if use_b else None
+        r = randn_h(M, N, seed=3000 + case) if use_r else None
+        if use_r and rfirst and act:
+            # residual before the activation goes through conv2d's flag; Linear adds it after: build the conv equivalent (1x1)
+            y = eng.conv2d(x.view(1, 1, M, K), w, b, ksize=1, residual=r.view(1, 1, M, N), act=act, residual_before_act=True).view(M, N) if K % 8 == 0 else None
+            ref = ACTS[act](x.float().cpu() @ w.float().cpu().t() + (b.float().cpu() if use_b else 0) + r.float().cpu())
+        else:
+            y = eng.linear(x, w, b, act=act, residual=r)
+            ref = ACTS[act](x.float().cpu() @ w.float().cpu().t() + (b.float().cpu() if use_b else 0)) + (r.float().cpu() if use_r else 0)
+        if y is not None:
+            assert_close(y, ref, what=f"case {case}: tile {tile} {M}x{N}x{K} act {act} bias {use_b} res {use_r} first {rfirst}")
+
+
+def test_conv_random_shapes_and_tiles(eng, tile_override):
+    """Seeded sweep of the implicit-GEMM conv: kernel 1 / 3, stride 1 / 2, virtual concat, fused nearest-2x upsample, ragged maps and
+    channel counts, random tile, shift / residual epilogues -- against torch's conv2d on the same f16 inputs."""
+    import random
+
+    rnd = random.Random(4321)
+    for case in range(48):
+        tile = rnd.randint(1, N_TILES)
+        B, H, W = rnd.choice([1, 2, 3]), rnd.choice([5, 8, 12, 17]), rnd.choice([6, 8, 16, 19])
+        C1, C2 = 8 * rnd.randint(1, 20), rnd.choice([0, 0, 8 * rnd.randint(1, 12)])
+        Cout = 4 * rnd.randint(2, 60)
+        k = rnd.choice([1, 3, 3])
+        stride = rnd.choice([1, 1, 2]) if k == 3 else 1
+        ups = k == 3 and stride == 1 and rnd.random() < 0.25
+        tile_override(tile)
+        x = randn_h(B, H, W, C1, seed=case)
+        x2 = randn_h(B, H, W, C2, seed=500 + case) if C2 else None
+        Cin = C1 + C2
+        w = randn_h(Cout, k * k * Cin, seed=1000 + case, scale=(k * k * Cin) ** -0.5)
+        b = randn_h(Cout, seed=1500 + case, scale=0.3)
+        xin = torch.cat([x, x2], -1) if C2 else x
+        xt = xin.float().cpu().permute(0, 3, 1, 2)
+        if ups:
+            xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+        wt = w.float().cpu().view(Cout, k, k, Cin).permute(0, 3, 1, 2)
+        ref = F.conv2d(xt, wt, b.float().cpu(), stride=stride, padding=k // 2).permute(0, 2, 3, 1)
+        shift = randn_h(B, Cout, seed=2000 + case) if rnd.random() < 0.4 else None
+        res = randn_h(*ref.shape, seed=2500 + case) if rnd.random() < 0.5 else None
+        y = eng.conv2d(x, w, b, ksize=k, stride=stride, x2=x2, shift=shift, residual=res, upsample2x=ups)
+        want = ref + (shift.float().cpu()[:, None, None, :] if shift is not None else 0) + (res.float().cpu() if res is not None else 0)
+        assert_close(y, want, what=f"case {case}: tile {tile} conv k{k} s{stride} ups {ups} {C1}+{C2}->{Cout} @{H}x{W} b{B}")
