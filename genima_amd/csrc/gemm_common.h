@@ -426,20 +426,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       for (int i = 0; i < TM; ++i) {
         const int m = mbase + i * 32 + l31;
         if (m >= p.M) continue;
+        const bool wide = (p.ldo & 7) == 0 && ((uintptr_t)p.out & 15) == 0 && (p.N & 127) == 0;  // whole hidden | gate blocks, 16-byte rows
 #pragma unroll
-        for (int j = 0; j < TN; j += 2)
+        for (int j = 0; j < TN; j += 2) {
+          f16x4 o[4];
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int nh = nbase + j * 32 + 8 * g + 4 * hi;
-            if (nh + 32 < p.N) {
-              const int oc = ((nbase + j * 32) >> 1) + 8 * g + 4 * hi;
-              f16x4 o;
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                o[e] = (f16)((acc[j][i][4 * g + e] + (float)bh[j / 2][g][e]) * gelu_fast(acc[j + 1][i][4 * g + e] + (float)bg[j / 2][g][e]));
-              *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + oc) = o;
+            for (int e = 0; e < 4; ++e)
+              o[g][e] = (f16)((acc[j][i][4 * g + e] + (float)bh[j / 2][g][e]) * gelu_fast(acc[j + 1][i][4 * g + e] + (float)bg[j / 2][g][e]));
+          const int ocb = (nbase + j * 32) >> 1;  // first output column of this hidden | gate pair of tiles
+          if (wide) {
+            // as in the row-major path: lanes l / l + 32 trade channel groups so that each owns 8 consecutive outputs (one 16-byte store
+            // instead of two 8-byte ones; the K = 320 GEGLU launches are bound by the store path)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+              const uint2 ua = *reinterpret_cast<const uint2*>(&o[g]), ub = *reinterpret_cast<const uint2*>(&o[g + 1]);
+              const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+              const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+              if (nbase + j * 32 + 32 < p.N)
+                *reinterpret_cast<uint4*>(p.out + (long)m * p.ldo + ocb + 8 * g + 8 * hi) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int nh = nbase + j * 32 + 8 * g + 4 * hi;
+              if (nh + 32 < p.N) *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + ocb + 8 * g + 4 * hi) = o[g];
             }
           }
+        }
       }
     }
   } else {
