@@ -204,6 +204,33 @@ __device__ __forceinline__ void epilogue_tile_math(const GemmParams& p, float (&
   }
 }
 
+// The shift / residual vectors of one 32-column tile for this lane: channel groups g = 0..3 at columns 8 g + 4 hi + (0..3).  Row-major
+// rows whose 8-channel groups are 16-byte aligned are fetched as TWO 16-byte loads per lane instead of four 8-byte ones (the load path is
+// issue-bound like the store path): lane l takes columns 8 g .. 8 g + 7, lane l + 32 columns 8 (g + 1) .. + 7, and one
+// v_permlane32_swap per dword hands each lane its halves of both groups.
+__device__ __forceinline__ void load_groups4(const f16* row, int col0, int hi, int N, bool wide, f16x4 (&a)[4]) {
+  const f16x4 zero = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+  if (wide) {
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      const int col = col0 + 8 * g + 8 * hi;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row && col < N) v = *reinterpret_cast<const uint4*>(row + col);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(v.x, v.z, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(v.y, v.w, false, false);
+      const uint2 lo = make_uint2(r0[0], r1[0]), hi2 = make_uint2(r0[1], r1[1]);
+      a[g] = *reinterpret_cast<const f16x4*>(&lo);
+      a[g + 1] = *reinterpret_cast<const f16x4*>(&hi2);
+    }
+  } else {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int nb = col0 + 8 * g + 4 * hi;
+      a[g] = (row && nb < N) ? *reinterpret_cast<const f16x4*>(row + nb) : zero;
+    }
+  }
+}
+
 // Residual values of a whole wave tile, requested BEFORE the K loop: the epilogue's residual read is then a register move instead of a
 // memory round trip at the end of the workgroup (with every residual / bias load removed the tiled b8 call is 5 ms shorter: most of
 // that is latency the K loop can hide).  Costs TM x TN x 8 registers for the length of the loop; kernels opt in where they fit.
@@ -213,17 +240,13 @@ struct EpiPre { f16x4 r[TM][TN][4]; };
 template <int TM, int TN>
 __device__ __forceinline__ bool epilogue_prefetch(const GemmParams& p, EpiPre<TM, TN>& pre, int mbase, int nbase, int l31, int hi) {
   if (!(p.res && !p.shift && p.splitk <= 1 && p.out_mode == GN_OUT_ROWMAJOR && p.act != GN_ACT_GEGLU)) return false;  // wave-uniform
-  const f16x4 zero = {(f16)0.0f, (f16)0.0f, (f16)0.0f, (f16)0.0f};
+  const bool wide = (p.ldr & 7) == 0 && (p.N & 7) == 0 && ((uintptr_t)p.res & 15) == 0;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int m = mbase + i * 32 + l31;
+    const f16* row = m < p.M ? p.res + (long)m * p.ldr : nullptr;  // (lanes l and l + 32 share the row: the swap pairs agree)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nb = nbase + j * 32 + 8 * g + 4 * hi;
-        pre.r[i][j][g] = (m < p.M && nb < p.N) ? *reinterpret_cast<const f16x4*>(p.res + (long)m * p.ldr + nb) : zero;
-      }
+    for (int j = 0; j < TN; ++j) load_groups4(row, nbase + j * 32, hi, p.N, wide, pre.r[i][j]);
   }
   return true;
 }
@@ -258,27 +281,20 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
     for (int j = 0; j < TN; ++j) load_bias(j, bv[RICH ? j : 0]);
   }
   f16x4 ax[PIPE ? 2 : 1][RICH ? TN : 1][4];
+  const bool aux_wide = (p.N & 7) == 0 && (aux_is_res ? ((p.ldr & 7) == 0 && ((uintptr_t)p.res & 15) == 0)
+                                                      : (has_shift && (p.ldshift & 7) == 0 && ((uintptr_t)p.shift & 15) == 0));
   auto load_aux1 = [&](int i, int j, f16x4 (&a)[4]) {
     const int m = mbase + i * 32 + l31;
     const f16* row = nullptr;
     if (m < p.M) row = aux_is_res ? p.res + (long)m * p.ldr : p.shift + (long)(m / p.rpb) * p.ldshift;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int nb = nbase + j * 32 + 8 * g + 4 * hi;
-      a[g] = (row && nb < p.N) ? *reinterpret_cast<const f16x4*>(row + nb) : zero;
-    }
+    load_groups4(row, nbase + j * 32, hi, p.N, aux_wide, a);
   };
   auto load_aux = [&](int i, f16x4 (&a)[RICH ? TN : 1][4]) {
     const int m = mbase + i * 32 + l31;
     const f16* row = nullptr;
     if (m < p.M) row = aux_is_res ? p.res + (long)m * p.ldr : p.shift + (long)(m / p.rpb) * p.ldshift;
 #pragma unroll
-    for (int j = 0; j < (RICH ? TN : 1); ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nb = nbase + j * 32 + 8 * g + 4 * hi;
-        a[j][g] = (row && nb < p.N) ? *reinterpret_cast<const f16x4*>(row + nb) : zero;
-      }
+    for (int j = 0; j < (RICH ? TN : 1); ++j) load_groups4(row, nbase + j * 32, hi, p.N, aux_wide, a[j]);
   };
   const bool wide = p.out_mode == GN_OUT_ROWMAJOR && (p.ldo & 7) == 0 && (p.N & 7) == 0 && ((uintptr_t)p.out & 15) == 0;
   if (PIPE && (has_shift || has_res) && !pre_ok) load_aux(0, ax[0]);
