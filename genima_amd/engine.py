@@ -226,16 +226,23 @@ class Engine:
             ms = race(c)
             if ms < best_ms:
                 best, best_ms = c, ms
-        # K splits of the winning tile: the library's heuristic aims at ~1.5 workgroups per CU; for the long-K, few-tile launches (the
-        # 16x16 / 8x8 latent levels) the right count is whatever makes the grid a multiple of the 256 CUs.  3 % margin against noise.
-        if best < 100 and d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8 and not d.out2:
-            tile = best
-            for sk in (1, 2, 3, 4, 6, 8):
-                if sk * 512 > d.K:
-                    break
-                ms = race(tile + 100 * sk)
-                if ms < 0.97 * best_ms:
-                    best, best_ms = tile + 100 * sk, ms
+        # K splits: the library's heuristic aims at ~1.5 workgroups per CU; for the long-K, few-tile launches (the 16x16 / 8x8 latent
+        # levels) the right count is whatever makes the grid fit the 256 CUs.  Raced for the winning tile and -- because its heuristic
+        # split (made for the 2-3-workgroups-per-CU tiles) can leave the one-workgroup-per-CU ping-pong tile a 1.6-round grid that loses
+        # the tile race although 256 x 256 with the right split wins (conv 1280 -> 1280 @ 16 x 16: tile 9 92 us, tile 15 / 5 slices 78) --
+        # for tile 15 as well wherever its output grid is smaller than the chip.  3 % margin against noise.
+        if d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8 and not d.out2:
+            tiles = [best % 100]
+            pp_blocks = -(-d.M // 256) * -(-d.N // 256)
+            if 15 in cands and 15 not in tiles and d.K >= 2048 and d.K % 64 == 0 and pp_blocks < 128:
+                tiles.append(15)
+            for tile in tiles:
+                for sk in (1, 2, 3, 4, 5, 6, 8):
+                    if sk * 512 > d.K or tile + 100 * sk == best or (tile == 15 and tile != tiles[0] and not 128 < pp_blocks * sk <= 256):
+                        continue
+                    ms = race(tile + 100 * sk)
+                    if ms < 0.97 * best_ms:
+                        best, best_ms = tile + 100 * sk, ms
         self.lib.gn_event_destroy(e0)
         self.lib.gn_event_destroy(e1)
         table[key] = best
