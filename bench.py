@@ -380,6 +380,9 @@ def main():
     # parallel with the bucketed RCCL reduce-scatter + all-gather of the flat gradient overlapped with the backward
     if not args.no_train:
         del pipe, act_agent
+        import gc
+
+        gc.collect()  # the recorded programs sit in reference cycles: free them (and their device buffers) now, not inside a timed train step
         torch.cuda.empty_cache()
         try:
             import bench_train

@@ -218,8 +218,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
 // hardware writes ZEROS to LDS for them (tools/probes/lds_dma_probe.hip verifies this on gfx950), so the conv zero padding
 // costs nothing.  Freed registers allow 128x64 wave tiles (256x256 block, 8 waves).
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool LNF = false>
 __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 128, WM* WN)) void gemm_dma_kernel(const GemmParams pin) {
+  static_assert(!LNF || (!CONV && 4 % WN == 0), "LayerNorm fold: dense problems, K steps dealt over 1 / 2 / 4 column waves");
   const GemmParams p = batch_offset(pin);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -375,6 +376,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  LnStats<TM> lnst;  // LNF: row sums / sums of squares of the raw A rows (gemm_common.h ln_fold_apply)
+  if constexpr (LNF) ln_stats_init(lnst);
+
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) dma_tile(cur ^ 1);  // lands under this tile's MFMAs; buf[cur^1] was last read before the previous barrier
@@ -395,12 +399,17 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+      if constexpr (LNF) {
+        if (WN == 1 || (kk % WN) == wn) ln_stats_step(lnst, fa);  // wave-uniform: this wave's share of the K steps
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
   }
 
+  if constexpr (LNF)  // (the barrier that ended the K loop freed the LDS tiles)
+    ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn, n0 + wn * WTN, l31, hi);
   gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
 }
 
@@ -565,6 +574,8 @@ void launch_dma(const GemmParams& p, bool conv, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1);
   if (conv)
     hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
+  else if (p.ln_c1)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, false, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
 }
@@ -662,6 +673,10 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (ov >= 0 && ov < kNumCfg) best = ov;
   if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
   if (geglu && !kCfg[best].geglu) best = 1;
+  if (d->ln_c1) {  // LayerNorm fold: the LDS-DMA kernels (two-stage and ring) carry it
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22};
+    best = to_dma[best];
+  }
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
     static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1};
@@ -686,7 +701,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
       if (sk < 1) sk = 1;
     }
   }
-  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8 || d->out2) sk = 1;
+  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8 || d->out2 || d->ln_c1) sk = 1;
   int kper = (int)(cdiv64(cdiv64(K, sk), BK) * BK);
   sk = (int)cdiv64(K, kper);
   pl.splitk = sk;
@@ -739,6 +754,12 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     GN_REQUIRE(d->split_n > 0 && d->split_n < d->N && d->split_n % 32 == 0, "gn_gemm: split_n (%d) must be a multiple of 32 inside (0, N)", d->split_n);
     GN_REQUIRE(d->rows_per_batch > 0 && d->M % d->rows_per_batch == 0 && d->ldo2 >= d->rows_per_batch, "gn_gemm: out2 needs rows_per_batch | M and ldo2 >= rows_per_batch");
     GN_REQUIRE(d->N % 8 == 0 && d->ldo % 8 == 0 && ((uintptr_t)d->out & 15) == 0, "gn_gemm: out2 needs the 16-byte row-major store path for out");
+  }
+  p.ln_c1 = d->ln_c1; p.ln_eps = d->ln_eps;
+  if (d->ln_c1) {
+    GN_REQUIRE(!d->conv && d->batch <= 1 && !d->fp8 && d->out_mode != GN_OUT_F32, "gn_gemm: ln_c1 (LayerNorm fold) is for dense f16 Linears");
+    GN_REQUIRE(dma_eligible(d), "gn_gemm: ln_c1 needs an LDS-DMA eligible problem (16-byte aligned rows, 32-bit operand extents)");
+    GN_REQUIRE(((uintptr_t)d->ln_c1 & 15) == 0 && d->ln_eps > 0.0f && d->bias, "gn_gemm: ln_c1 must be 16-byte aligned, ln_eps > 0, and bias must hold c2");
   }
   p.nbatch = d->batch > 1 ? d->batch : 0;
   p.binner = p.nbatch ? (d->batch_inner > 0 ? d->batch_inner : 1) : 0;

@@ -36,6 +36,8 @@ struct GemmParams {
   f16* out2;                             // two-destination output: columns >= split_n go here, batch-transposed (row stride ldo2)
   long ldo2;
   int split_n;
+  const float* ln_c1;                    // LayerNorm folded into the GEMM (ln_fold_apply below): per-column sums of the gamma-scaled weight
+  float ln_eps;
 };
 
 // batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
@@ -482,6 +484,105 @@ template <int TM, int TN, bool RICH = (TM * TN <= 4)>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi, int z) {
   EpiPre<TM, TN> none;  // never read
   gemm_epilogue<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, z, none, false);
+}
+
+// ---- LayerNorm folded into the consuming Linear (gn_gemm_desc::ln_c1; SURVEY.md K7: "LN -> QKV without a round trip") ---------------------
+// With W' = W * gamma (column-wise, folded into the packed weight), c1[n] = sum_k W'[n, k] and c2[n] = sum_k W[n, k] * beta[k] + b[n]:
+//   Linear(LayerNorm(x))[m, n] = rstd[m] * (sum_k x[m, k] W'[n, k] - mean[m] * c1[n]) + c2[n]
+// so the GEMM runs on the RAW rows and needs only each row's mean / rstd -- which it can take from the A fragments it reads anyway (every
+// workgroup walks the whole K range of its rows; no split-K in this mode).  The K steps are dealt round-robin to the WN waves that share a
+// row band (each A fragment is summed by exactly one of them: 8 v_dot2_f32_f16 per fragment), the partial sums meet in LDS after the K loop.
+// c1 is summed from the f16-rounded W' the MFMA multiplies, so the subtraction is exact algebra on the same numbers: the result is the GEMM
+// of the exactly centred rows (no f16 rounding of the normalised activations at all -- closer to the fp32 reference than LN -> f16 -> GEMM).
+template <int TM>
+struct LnStats {
+  float s1[TM], s2[TM];
+};
+template <int TM>
+__device__ __forceinline__ void ln_stats_init(LnStats<TM>& st) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) st.s1[i] = st.s2[i] = 0.0f;
+}
+template <int TM>
+__device__ __forceinline__ void ln_stats_step(LnStats<TM>& st, const f16x8 (&fa)[TM]) {
+  const f16x2 ones = {(f16)1.0f, (f16)1.0f};
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const f16x2 h0 = __builtin_shufflevector(fa[i], fa[i], 0, 1), h1 = __builtin_shufflevector(fa[i], fa[i], 2, 3);
+    const f16x2 h2 = __builtin_shufflevector(fa[i], fa[i], 4, 5), h3 = __builtin_shufflevector(fa[i], fa[i], 6, 7);
+    st.s1[i] = __builtin_amdgcn_fdot2(h0, ones, st.s1[i], false);
+    st.s2[i] = __builtin_amdgcn_fdot2(h0, h0, st.s2[i], false);
+    st.s1[i] = __builtin_amdgcn_fdot2(h1, ones, st.s1[i], false);
+    st.s2[i] = __builtin_amdgcn_fdot2(h1, h1, st.s2[i], false);
+    st.s1[i] = __builtin_amdgcn_fdot2(h2, ones, st.s1[i], false);
+    st.s2[i] = __builtin_amdgcn_fdot2(h2, h2, st.s2[i], false);
+    st.s1[i] = __builtin_amdgcn_fdot2(h3, ones, st.s1[i], false);
+    st.s2[i] = __builtin_amdgcn_fdot2(h3, h3, st.s2[i], false);
+  }
+}
+// after the K loop (every wave of the workgroup calls it; `lds` = WN * BM * 2 floats no wave is reading any more):
+// acc <- rstd * (acc - mean * c1[n]); the usual epilogue follows with c2 as the bias
+template <int TM, int TN, int WN, int BM>
+__device__ __forceinline__ void ln_fold_apply(const GemmParams& p, f32x16 (&acc)[TN][TM], LnStats<TM>& st, float* lds, int row0, int wn,
+                                              int nbase, int l31, int hi) {
+  // the c1 vector of this wave's columns first: its L2 round trip runs under the statistics exchange below (issued after it, every
+  // workgroup would pay that latency again between its K loop and its epilogue)
+  float4 c1[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = nbase + j * 32 + 8 * g + 4 * hi;
+      c1[j][g] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (n + 3 < p.N) c1[j][g] = *reinterpret_cast<const float4*>(p.ln_c1 + n);
+    }
+  float mean[TM], rstd[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {  // the two lane halves hold the two 8-element halves of every 16-element K step
+    st.s1[i] += __shfl_xor(st.s1[i], 32);
+    st.s2[i] += __shfl_xor(st.s2[i], 32);
+  }
+  if constexpr (WN > 1) {
+    if (hi == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        *reinterpret_cast<float2*>(lds + ((wn * BM) + row0 + i * 32 + l31) * 2) = make_float2(st.s1[i], st.s2[i]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      float a = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) {  // fixed order: every wave of a row band computes the same bits
+        const float2 v = *reinterpret_cast<const float2*>(lds + ((w * BM) + row0 + i * 32 + l31) * 2);
+        a += v.x;
+        b += v.y;
+      }
+      st.s1[i] = a;
+      st.s2[i] = b;
+    }
+  }
+  const float invk = 1.0f / (float)p.K;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    mean[i] = st.s1[i] * invk;
+    const float var = fmaxf(st.s2[i] * invk - mean[i] * mean[i], 0.0f);
+    rstd[i] = __frsqrt_rn(var + p.ln_eps);
+    mean[i] *= -rstd[i];  // now -rstd * mean
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 c = c1[j][g];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        acc[j][i][4 * g + 0] = rstd[i] * acc[j][i][4 * g + 0] + mean[i] * c.x;
+        acc[j][i][4 * g + 1] = rstd[i] * acc[j][i][4 * g + 1] + mean[i] * c.y;
+        acc[j][i][4 * g + 2] = rstd[i] * acc[j][i][4 * g + 2] + mean[i] * c.z;
+        acc[j][i][4 * g + 3] = rstd[i] * acc[j][i][4 * g + 3] + mean[i] * c.w;
+      }
+    }
 }
 
 // LDS-DMA (`buffer_load_dwordx4 ... lds`) plumbing shared by the DMA-staged kernels

@@ -18,8 +18,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 #undef GN_VMCNT_CASE
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, bool LNF = false>
 __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 128, WM* WN)) void gemm_s3_kernel(const GemmParams pin) {
+  static_assert(!LNF || (!CONV && 4 % WN == 0), "LayerNorm fold: dense problems, K steps dealt over 1 / 2 / 4 column waves");
   const GemmParams p = batch_offset(pin);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -181,6 +182,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
+  LnStats<TM> lnst;  // LNF: row sums / sums of squares of the raw A rows (gemm_common.h ln_fold_apply)
+  if constexpr (LNF) ln_stats_init(lnst);
+
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const int nxt2 = cur >= 1 ? cur - 1 : 2;  // (cur + 2) % 3
@@ -202,6 +206,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
 #pragma unroll
         for (int i = 0; i < TM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+      if constexpr (LNF) {
+        if (WN == 1 || (kk % WN) == wn) ln_stats_step(lnst, fa);  // wave-uniform: this wave's share of the K steps
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     wait_vmcnt<NIN>();
@@ -211,6 +218,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead zero fills
 
+  if constexpr (LNF) {
+    __syncthreads();  // every wave's run-ahead fills have landed: the LDS ring is free for the row statistics
+    ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn, n0 + wn * WTN, l31, hi);
+  }
   gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
 }
 
@@ -218,6 +229,8 @@ template <int BM, int BN, int WM, int WN>
 void launch_s3(const GemmParams& p, bool conv, dim3 grid, hipStream_t st) {
   if (conv)
     hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
+  else if (p.ln_c1)
+    hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, false, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else
     hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, false>), grid, dim3(WM * WN * 64), 0, st, p);
 }

@@ -69,6 +69,7 @@ class Engine:
     def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None):
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
+        self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise GenimaHipError("the Genima HIP engine needs a ROCm device (torch device 'cuda:N'); there is no CPU path")
@@ -185,6 +186,8 @@ class Engine:
             key += "|fp8"
         if d.out2:
             key += f"|o2{int(d.split_n)}"
+        if d.ln_c1:
+            key += "|ln"
         return key
 
     @staticmethod
@@ -205,6 +208,8 @@ class Engine:
             cands = [table[key]] + [c for c in challengers if c != table[key] % 100 and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19))]
         if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
+        if d.ln_c1:  # the LayerNorm fold lives in the LDS-DMA kernels (the library maps the other tiles onto them)
+            cands = [c for c in cands if c % 100 >= 7 and c % 100 != 15]
         e0, e1 = self.event(), self.event()
 
         def race(plan: int) -> float:
@@ -331,11 +336,13 @@ class Engine:
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
                transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0,
-               split_n: int = 0, out2: Optional[torch.Tensor] = None):
+               split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5):
         """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
         transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel).
         split_n > 0: ONE launch with two destinations (the q | k | v projections of a self-attention block): columns [0, split_n)
-        row-major -> y [.., split_n], columns [split_n, N) batch-transposed -> y2 [b, N - split_n, pad_cols]; returns (y, y2)."""
+        row-major -> y [.., split_n], columns [split_n, N) batch-transposed -> y2 [b, N - split_n, pad_cols]; returns (y, y2).
+        ln_c1 (f32 [N]): LayerNorm folded into this Linear -- x holds the RAW rows, w the gamma-scaled weight, bias c2 (packing.fold_layernorm;
+        gn_gemm_desc.ln_c1): y = act(LayerNorm(x) @ W.T + b) without the LayerNorm launch or its round trip through memory."""
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
@@ -372,7 +379,10 @@ class Engine:
         d.lda, d.ldw = x.stride(-2) if x.dim() > 1 else K, w.stride(0)
         d.ldr = residual.stride(-2) if residual is not None else 0
         d.act, d.splitk, d.out_scale = act, splitk, 1.0
-        self._gemm(d, (x, w, bias, residual, out, out2))
+        if ln_c1 is not None:
+            assert bias is not None and ln_c1.dtype == torch.float32 and ln_c1.numel() == N and not transposed_out
+            d.ln_c1, d.ln_eps = _ptr(ln_c1), float(ln_eps)
+        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1))
         return (out, out2) if split_n else out
 
     # ---- fp8 (OCP e4m3) Linear: SURVEY section 8 a15 / BASELINE configs[4] "fp8 MFMA" -------------------------------------------

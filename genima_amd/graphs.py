@@ -107,6 +107,14 @@ def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[
     return kv
 
 
+def _ln_fold(E: Engine, W, lin: str):
+    """-> (ln_weight, ln_c1, ln_c2) of a Linear whose LayerNorm was folded at pack time, or None (no fold in the dict, the engine routes
+    Linears through the fp8 MFMA -- its quantisation pass wants the normalised rows --, or GN_LN_FOLD=0)."""
+    if lin + ".ln_weight" not in W or E._fp8_weights or not getattr(E, "ln_fold", True):
+        return None
+    return W[lin + ".ln_weight"], W[lin + ".ln_c1"], W[lin + ".ln_c2"]
+
+
 def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
     B, H, Wd, Cc = x.shape
     N = H * Wd
@@ -117,21 +125,35 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
         while f"{p}.transformer_blocks.{k}.norm1.weight" in W:
             b = f"{p}.transformer_blocks.{k}"
             with E.scope(f"tb{k}"):
-                n = E.layernorm(h, W[b + ".norm1.weight"], W[b + ".norm1.bias"], name="ln1")
-                if b + ".attn1.to_qkv.weight" in W:  # q | k | v in one two-destination launch (q, k row-major + V^T)
-                    qk, vt = E.linear(n, W[b + ".attn1.to_qkv.weight"], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
+                # LayerNorm folded into the consuming Linear where the packed dict carries the folded weights (packing.fold_layernorms):
+                # the Linear reads the raw rows and takes mean / rstd from its own K loop -- no LayerNorm launch, no round trip
+                fold = _ln_fold(E, W, b + ".attn1.to_qkv")
+                if fold:
+                    qk, vt = E.linear(h, fold[0], fold[2], ln_c1=fold[1], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
                 else:
-                    qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")
-                    vt = E.linear(n, W[b + ".attn1.to_v.weight"], transposed_out=True, rows_per_batch=N, pad_cols=_rup(N, 64), name="vt")
+                    n = E.layernorm(h, W[b + ".norm1.weight"], W[b + ".norm1.bias"], name="ln1")
+                    if b + ".attn1.to_qkv.weight" in W:  # q | k | v in one two-destination launch (q, k row-major + V^T)
+                        qk, vt = E.linear(n, W[b + ".attn1.to_qkv.weight"], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
+                    else:
+                        qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")
+                        vt = E.linear(n, W[b + ".attn1.to_v.weight"], transposed_out=True, rows_per_batch=N, pad_cols=_rup(N, 64), name="vt")
                 a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
                 h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
-                n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")
-                q = E.linear(n, W[b + ".attn2.to_q.weight"], name="cq")
+                fold = _ln_fold(E, W, b + ".attn2.to_q")
+                if fold:
+                    q = E.linear(h, fold[0], fold[2], ln_c1=fold[1], name="cq")
+                else:
+                    n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")
+                    q = E.linear(n, W[b + ".attn2.to_q.weight"], name="cq")
                 ck, cvt = kv[b + ".attn2"]
                 a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
                 h = E.linear(a, W[b + ".attn2.to_out.0.weight"], W[b + ".attn2.to_out.0.bias"], residual=h, name="cao")
-                n = E.layernorm(h, W[b + ".norm3.weight"], W[b + ".norm3.bias"], name="ln3")
-                g = E.linear(n, W[b + ".ff.net.0.proj.weight"], W[b + ".ff.net.0.proj.bias"], act=ACT_GEGLU, name="ffg")
+                fold = _ln_fold(E, W, b + ".ff.net.0.proj")
+                if fold:
+                    g = E.linear(h, fold[0], fold[2], ln_c1=fold[1], act=ACT_GEGLU, name="ffg")
+                else:
+                    n = E.layernorm(h, W[b + ".norm3.weight"], W[b + ".norm3.bias"], name="ln3")
+                    g = E.linear(n, W[b + ".ff.net.0.proj.weight"], W[b + ".ff.net.0.proj.bias"], act=ACT_GEGLU, name="ffg")
                 h = E.linear(g, W[b + ".ff.net.2.weight"], W[b + ".ff.net.2.bias"], residual=h, name="ffo")
             k += 1
         out = E.linear(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"], residual=x.view(B, N, Cc), name="pout")
@@ -334,18 +356,26 @@ def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor, hidden: Optional[List[t
         for i in range(cfg["num_hidden_layers"]):
             p = f"text_model.encoder.layers.{i}"
             with E.scope(f"l{i}"):
-                n = E.layernorm(x, W[p + ".layer_norm1.weight"], W[p + ".layer_norm1.bias"], eps, name="ln1")
-                if p + ".self_attn.qkv_proj.weight" in W:  # q | k | v in one two-destination launch
-                    qk, vt = E.linear(n, W[p + ".self_attn.qkv_proj.weight"], W[p + ".self_attn.qkv_proj.bias"], split_n=2 * D,
-                                      rows_per_batch=L, pad_cols=_rup(L, 64), name="qk")
+                fold = _ln_fold(E, W, p + ".self_attn.qkv_proj")
+                if fold:  # LayerNorm folded into the q | k | v launch (packing.fold_layernorms)
+                    qk, vt = E.linear(x, fold[0], fold[2], ln_c1=fold[1], ln_eps=eps, split_n=2 * D, rows_per_batch=L, pad_cols=_rup(L, 64), name="qk")
                 else:
-                    qk = E.linear(n, W[p + ".self_attn.qk_proj.weight"], W[p + ".self_attn.qk_proj.bias"], name="qk")
-                    vt = E.linear(n, W[p + ".self_attn.v_proj.weight"], W[p + ".self_attn.v_proj.bias"], transposed_out=True,
-                                  rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
+                    n = E.layernorm(x, W[p + ".layer_norm1.weight"], W[p + ".layer_norm1.bias"], eps, name="ln1")
+                    if p + ".self_attn.qkv_proj.weight" in W:  # q | k | v in one two-destination launch
+                        qk, vt = E.linear(n, W[p + ".self_attn.qkv_proj.weight"], W[p + ".self_attn.qkv_proj.bias"], split_n=2 * D,
+                                          rows_per_batch=L, pad_cols=_rup(L, 64), name="qk")
+                    else:
+                        qk = E.linear(n, W[p + ".self_attn.qk_proj.weight"], W[p + ".self_attn.qk_proj.bias"], name="qk")
+                        vt = E.linear(n, W[p + ".self_attn.v_proj.weight"], W[p + ".self_attn.v_proj.bias"], transposed_out=True,
+                                      rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
                 a = E.attention(qk[:, :, :D], qk[:, :, D:], vt, heads, causal=True, name="sa")
                 x = E.linear(a, W[p + ".self_attn.out_proj.weight"], W[p + ".self_attn.out_proj.bias"], residual=x, name="o")
-                n = E.layernorm(x, W[p + ".layer_norm2.weight"], W[p + ".layer_norm2.bias"], eps, name="ln2")
-                h = E.linear(n, W[p + ".mlp.fc1.weight"], W[p + ".mlp.fc1.bias"], act=act, name="fc1")
+                fold = _ln_fold(E, W, p + ".mlp.fc1")
+                if fold:
+                    h = E.linear(x, fold[0], fold[2], ln_c1=fold[1], ln_eps=eps, act=act, name="fc1")
+                else:
+                    n = E.layernorm(x, W[p + ".layer_norm2.weight"], W[p + ".layer_norm2.bias"], eps, name="ln2")
+                    h = E.linear(n, W[p + ".mlp.fc1.weight"], W[p + ".mlp.fc1.bias"], act=act, name="fc1")
                 x = E.linear(h, W[p + ".mlp.fc2.weight"], W[p + ".mlp.fc2.bias"], residual=x, name="fc2")
                 if hidden is not None:
                     hidden.append(x)

@@ -91,6 +91,39 @@ def unpack_state_dict(packed: Dict[str, torch.Tensor], schema: Dict[str, tuple],
     return out
 
 
+# (LayerNorm, consuming Linear) pairs whose LayerNorm is folded into the Linear's launch (gn_gemm_desc.ln_c1, csrc/gemm_common.h
+# ln_fold_apply): diffusers BasicTransformerBlock norm1 -> attn1 q | k | v, norm2 -> attn2.to_q, norm3 -> the GEGLU projection;
+# CLIPEncoderLayer layer_norm1 -> q | k | v, layer_norm2 -> fc1.
+_LN_FOLDS = ((".norm1", ".attn1.to_qkv"), (".norm2", ".attn2.to_q"), (".norm3", ".ff.net.0.proj"),
+             (".layer_norm1", ".self_attn.qkv_proj"), (".layer_norm2", ".mlp.fc1"))
+
+
+def fold_layernorms(packed: Dict[str, torch.Tensor]) -> None:
+    """For every pair of _LN_FOLDS present in a PACKED f16 dict add ``<linear>.ln_weight`` = W * gamma (f16, the packed row order of W:
+    q | k | v concatenated, GEGLU interleaved), ``.ln_c1`` = row sums of that f16-rounded matrix (f32) and ``.ln_c2`` = W @ beta + b (f16).
+    Linear(LayerNorm(x)) = rstd * (x @ ln_weight.T - mean * ln_c1) + ln_c2: the inference graphs then skip the LayerNorm launch."""
+    for name in list(packed.keys()):
+        for ln, lin in _LN_FOLDS:
+            if not name.endswith(ln + ".weight"):
+                continue
+            base = name[: -len(ln + ".weight")]
+            wn = base + lin + ".weight"
+            if wn not in packed or packed[wn].dim() != 2:
+                continue
+            gamma, beta = packed[name].float(), packed[base + ln + ".bias"].float()
+            w = packed[wn].float()
+            if w.shape[1] != gamma.numel():
+                continue
+            wg = (w * gamma[None, :]).to(torch.float16)
+            c2 = w @ beta
+            bn = base + lin + ".bias"
+            if bn in packed:
+                c2 = c2 + packed[bn].float()
+            packed[base + lin + ".ln_weight"] = wg.contiguous()
+            packed[base + lin + ".ln_c1"] = wg.float().sum(dim=1).contiguous()
+            packed[base + lin + ".ln_c2"] = c2.to(torch.float16).contiguous()
+
+
 def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
     """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries).
     ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams)."""
@@ -144,6 +177,8 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
                 if qn == ".attn1.to_q.weight" and base + ".attn1.to_v.weight" in sd and qb not in sd:
                     # q | k | v as ONE launch (two-destination GEMM: q, k row-major + V^T): the inference graphs' self-attention
                     out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
+    if dtype == torch.float16:
+        fold_layernorms(out)
     meta = {}
     if temb_w:
         out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(dtype).contiguous()

@@ -101,6 +101,14 @@ typedef struct gn_gemm_desc {
   void* out2;
   int64_t ldo2;
   int32_t split_n;
+  /* LayerNorm folded into the Linear that consumes it (diffusers BasicTransformerBlock.norm1 -> attn1.to_q/k/v, norm2 -> attn2.to_q,
+   * norm3 -> ff.net[0].proj; CLIPEncoderLayer.layer_norm1/2 -> q/k/v, fc1: a LayerNorm kernel + a cuBLAS call each in the reference).
+   * `a` holds the RAW rows; `w` the gamma-scaled weight W'[n, k] = W[n, k] * gamma[k] (f16); `ln_c1` f32 [N] = sum_k W'[n, k] over the
+   * f16-rounded W'; `bias` holds c2[n] = sum_k W[n, k] * beta[k] + b[n].  The kernel takes each row's mean / rstd (biased variance,
+   * ln_eps) from the A fragments of its K loop and emits rstd * (a . W'^T - mean * c1) + c2 through the usual epilogue (activation,
+   * GEGLU, residual, out2 ...).  Dense f16 Linears on the LDS-DMA tiles (7..14, 16..23); K is never split.  NULL = off. */
+  float ln_eps;
+  const float* ln_c1;
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */

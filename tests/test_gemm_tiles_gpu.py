@@ -154,3 +154,55 @@ def test_conv_random_shapes_and_tiles(eng, tile_override):
         y = eng.conv2d(x, w, b, ksize=k, stride=stride, x2=x2, shift=shift, residual=res, upsample2x=ups)
         want = ref + (shift.float().cpu()[:, None, None, :] if shift is not None else 0) + (res.float().cpu() if res is not None else 0)
         assert_close(y, want, what=f"case {case}: tile {tile} conv k{k} s{stride} ups {ups} {C1}+{C2}->{Cout} @{H}x{W} b{B}")
+
+
+DMA_TILES = [t for t in range(7, N_TILES + 1) if t != 15]  # the kernels that carry the LayerNorm fold (the library maps the others onto them)
+
+
+def _fold(w, gamma, beta, b):
+    """packing.fold_layernorms on one Linear (same arithmetic: f16-rounded W * gamma, f32 row sums of the rounded matrix, c2 in f16)."""
+    wg = (w.float() * gamma.float()[None, :]).half()
+    c1 = wg.float().sum(dim=1).contiguous()
+    c2 = (w.float() @ beta.float() + (b.float() if b is not None else 0)).half()
+    return wg.contiguous(), c1, c2
+
+
+@pytest.mark.parametrize("tile", DMA_TILES)
+def test_layernorm_fold_every_tile(eng, tile_override, tile):
+    """gn_gemm_desc.ln_c1: Linear(LayerNorm(x)) from the RAW rows (row statistics out of the K loop's A fragments) against torch's
+    layer_norm + linear in fp32 -- plain + residual, activation, GEGLU, the two-destination q | k | v epilogue; rows with a large mean
+    (|mean| = 6 sigma) so that the mean * c1 cancellation is exercised; ragged M / N / K tails."""
+    tile_override(tile)
+    for (M, N, K) in ((1000, 328, 320), (300, 192, 200)):
+        x = (randn_h(M, K, seed=21).float() * 0.7 + randn_h(M, 1, seed=22).float() * 4.0).half()
+        w, b = randn_h(N, K, seed=23, scale=K ** -0.5), randn_h(N, seed=24, scale=0.3)
+        gamma, beta = (1.0 + 0.3 * randn_h(K, seed=25).float()).half(), randn_h(K, seed=26, scale=0.2)
+        r = randn_h(M, N, seed=27)
+        ln = F.layer_norm(x.float().cpu(), (K,), gamma.float().cpu(), beta.float().cpu(), 1e-5)
+        base = ln @ w.float().cpu().t() + b.float().cpu()
+        wg, c1, c2 = _fold(w, gamma, beta, b)
+        y = eng.linear(x, wg, c2, ln_c1=c1, residual=r)
+        assert_close(y, base + r.float().cpu(), what=f"tile {tile} ln-fold {M}x{N}x{K} +res")
+        y = eng.linear(x, wg, c2, ln_c1=c1, act=2)
+        assert_close(y, F.gelu(base), what=f"tile {tile} ln-fold {M}x{N}x{K} gelu")
+    # GEGLU (hidden | gate interleaved in 32-column blocks by packing.pack_geglu) and the q | k | v two-destination epilogue
+    from genima_amd.packing import pack_geglu
+
+    M, K, Nh = 520, 320, 192
+    x = (randn_h(M, K, seed=31).float() + randn_h(M, 1, seed=32).float() * 3.0).half()
+    w, b = randn_h(2 * Nh, K, seed=33, scale=K ** -0.5), randn_h(2 * Nh, seed=34, scale=0.3)
+    gamma, beta = (1.0 + 0.3 * randn_h(K, seed=35).float()).half(), randn_h(K, seed=36, scale=0.2)
+    ln = F.layer_norm(x.float().cpu(), (K,), gamma.float().cpu(), beta.float().cpu(), 1e-5)
+    full = ln @ w.float().cpu().t() + b.float().cpu()
+    want = full[:, :Nh] * F.gelu(full[:, Nh:])
+    wp, bp = pack_geglu(w.float(), b.float())
+    wg, c1, c2 = _fold(wp.cuda(), gamma, beta, bp.cuda())
+    y = eng.linear(x, wg, c2, ln_c1=c1, act=5)  # (tiles whose wave tile is narrower than a hidden | gate pair: the library substitutes 128 x 128)
+    assert_close(y, want, what=f"tile {tile} ln-fold GEGLU")
+    Bn, rows, pad, Cq = 2, 260, 320, 96
+    w3 = randn_h(3 * Cq, K, seed=37, scale=K ** -0.5)
+    wg, c1, c2 = _fold(w3, gamma, beta, None)
+    qk, vt = eng.linear(x.view(Bn, rows, K), wg, c2, ln_c1=c1, split_n=2 * Cq, rows_per_batch=rows, pad_cols=pad)
+    full = ln @ w3.float().cpu().t()
+    assert_close(qk.reshape(M, 2 * Cq), full[:, : 2 * Cq], what=f"tile {tile} ln-fold q|k")
+    assert_close(vt.view(Bn, Cq, pad)[:, :, :rows], full[:, 2 * Cq:].view(Bn, rows, Cq).permute(0, 2, 1), what=f"tile {tile} ln-fold V^T")

@@ -22,3 +22,37 @@ def test_controlnet_and_unet_pack_unpack_roundtrip():
     fam = configs.family("tiny")
     _roundtrip(schema.controlnet_schema(fam["controlnet"]), 2)
     _roundtrip(schema.unet_schema(fam["unet"]), 1)
+
+
+def test_layernorm_fold_entries_reproduce_layernorm_then_linear():
+    """packing.fold_layernorms: rstd * (x @ ln_weight.T - mean * ln_c1) + ln_c2 == Linear(LayerNorm(x)) for every folded pair of a packed
+    UNet and CLIP tower (the identity the HIP GEMM's gn_gemm_desc.ln_c1 mode evaluates), GEGLU row interleave and q | k | v concat included."""
+    import torch.nn.functional as F
+
+    fam = configs.family("tiny")
+    for sch, seed in ((schema.unet_schema(fam["unet"]), 1), (schema.clip_text_schema(fam["text"]), 3)):
+        sd = weights.synth_state_dict(sch, seed)
+        for k in sd:  # non-trivial affine parameters
+            if k.endswith(("norm1.weight", "norm2.weight", "norm3.weight")):
+                sd[k] = 1.0 + 0.2 * torch.randn_like(sd[k])
+            if k.endswith(("norm1.bias", "norm2.bias", "norm3.bias")):
+                sd[k] = 0.1 * torch.randn_like(sd[k])
+        packed = pack_state_dict(sd, "cpu")
+        folded = [k[: -len(".ln_weight")] for k in packed if k.endswith(".ln_weight")]
+        assert folded, "no LayerNorm was folded"
+        for lin in folded:
+            wg, c1, c2 = packed[lin + ".ln_weight"].float(), packed[lin + ".ln_c1"], packed[lin + ".ln_c2"].float()
+            w = packed[lin + ".weight"].float()
+            b = packed[lin + ".bias"].float() if lin + ".bias" in packed else 0.0
+            ln = {".attn1.to_qkv": ".norm1", ".attn2.to_q": ".norm2", ".ff.net.0.proj": ".norm3", ".self_attn.qkv_proj": ".layer_norm1", ".mlp.fc1": ".layer_norm2"}
+            suffix = next(s for s in ln if lin.endswith(s))
+            pre = lin[: -len(suffix)] + ln[suffix]
+            gamma, beta = packed[pre + ".weight"].float(), packed[pre + ".bias"].float()
+            K = w.shape[1]
+            x = torch.randn(37, K) * 0.8 + torch.randn(37, 1) * 2.0
+            want = F.layer_norm(x, (K,), gamma, beta, 1e-5) @ w.t() + b
+            mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+            got = torch.rsqrt(var + 1e-5) * (x @ wg.t() - mean * c1[None, :]) + c2[None, :]
+            assert c1.dtype == torch.float32
+            err = float((got - want).abs().max()) / float(want.abs().max())
+            assert err < 2e-3, (lin, err)  # f16 rounding of W * gamma and of c2
