@@ -32,6 +32,12 @@
 
 #include "attention_common.h"
 
+// waves per SIMD the 4-wave x 32-row D = 64 kernels are held to (register budget 512 / 3 = 170): the V^T kernel fits anyway (167 with
+// -amdgpu-mfma-vgpr-form), the row-major-V one needs the hint (184 -> 168: 222 -> 206-216 us at 8 x 5 x 4096^2)
+#ifndef GN_ATTN_WAVES
+#define GN_ATTN_WAVES 3
+#endif
+
 namespace {
 
 // VROW (D = 64 only): `vt` points at V in row-major form [B][Nk][vt_rs] (head h at column h * D) -- the layout a plain q | k | v
@@ -42,7 +48,7 @@ typedef __attribute__((address_space(3))) attn_h4* attn_lds_h4_ptr;
 struct AttnH8 { attn_h4 lo, hi; };
 
 template <int D, int NW, int TQ, bool VROW = false>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, (D == 64 && NW == 4 && TQ == 1 && GN_ATTN_WAVES > 0) ? GN_ATTN_WAVES : 1) void attn_fwd_kernel(const AttnParams p) {
   static_assert(!VROW || D == 64, "row-major V: the LDS-DMA (D = 64) path only");
   constexpr int NT = NW * 64;
   constexpr int QB = NW * TQ * 32;   // query rows per block
@@ -268,6 +274,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     // accumulator r of sub-tile u holds key j0 + 32u + 16(r>>3) + 8hi + (r&7)
     f16x8 pf[TQ][2][2];
     float psum[TQ];
+    // (row sum on the f32 exponentials with v_pk_add_f32 instead of v_dot2c on the packed pairs: measured 1-2 % slower -- the pairs have to
+    // stay live in f32 until the add, 76 bytes of scratch at three waves per SIMD)
     auto exps = [&](int tq) {
       float acc = 0.0f;
 #pragma unroll

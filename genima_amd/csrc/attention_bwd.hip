@@ -14,6 +14,15 @@
 // gn_transpose2d (96 transposes per step, twice the streamed bytes and LDS).
 #include "common.h"
 
+// waves per SIMD passed to __launch_bounds__: with the hint the dK / dV kernel comes out at 166 VGPRs (three waves per SIMD) instead of 206
+// (two): 818 -> 799 us at 8 x 5 x 4096^2, 132 -> 124 us at 8 x 10 x 1024^2; three for the dQ kernel spills
+#ifndef GN_ATTNB_DQ_WAVES
+#define GN_ATTNB_DQ_WAVES 2
+#endif
+#ifndef GN_ATTNB_DKV_WAVES
+#define GN_ATTNB_DKV_WAVES 2
+#endif
+
 namespace {
 
 constexpr int D = 64;          // head dim
@@ -126,7 +135,7 @@ __device__ __forceinline__ f16x8 tr_frag(const unsigned char* tile, const TrOffs
   return __builtin_bit_cast(f16x8, BwdH8{lo, hi});
 }
 
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, GN_ATTNB_DQ_WAVES) void attn_bwd_dq_kernel(const AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnBwdParams p)
 // ---- dK, dV ----------------------------------------------------------------------------------------------------------------
 constexpr int KV_BUF = 2 * TILE + 2 * 64 * 4;  // Q, dO tiles + lse + delta of the query tile
 
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(const AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * KV_BUF];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;

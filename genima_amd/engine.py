@@ -70,6 +70,10 @@ class Engine:
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
+        # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
+        # launch + V^T.  Measured neutral in the call (107.59 vs 107.67 ms tiled b8, same box) although the kernel alone is 4-7 % faster at
+        # 4096 keys: off by default, kept for hosts that hold V row-major
+        self.rowmajor_v = os.environ.get("GN_ROWMAJOR_V", "0") == "1"
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise GenimaHipError("the Genima HIP engine needs a ROCm device (torch device 'cuda:N'); there is no CPU path")

@@ -128,16 +128,26 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                 # LayerNorm folded into the consuming Linear where the packed dict carries the folded weights (packing.fold_layernorms):
                 # the Linear reads the raw rows and takes mean / rstd from its own K loop -- no LayerNorm launch, no round trip
                 fold = _ln_fold(E, W, b + ".attn1.to_qkv")
-                if fold:
+                # V row-major (head dim 64): q | k | v is then ONE plain [.., 3C] launch and the attention kernel transposes V out of its LDS
+                # tile (gn_attn_desc.v_rowmajor) -- no batch-transposed V^T epilogue (2-byte stores) on the projection
+                vrow = getattr(E, "rowmajor_v", False) and Cc // heads == 64 and b + ".attn1.to_qkv.weight" in W
+                if fold and vrow:
+                    qkv = E.linear(h, fold[0], fold[2], ln_c1=fold[1], name="qkv")
+                elif fold:
                     qk, vt = E.linear(h, fold[0], fold[2], ln_c1=fold[1], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
                 else:
                     n = E.layernorm(h, W[b + ".norm1.weight"], W[b + ".norm1.bias"], name="ln1")
-                    if b + ".attn1.to_qkv.weight" in W:  # q | k | v in one two-destination launch (q, k row-major + V^T)
+                    if vrow:
+                        qkv = E.linear(n, W[b + ".attn1.to_qkv.weight"], name="qkv")
+                    elif b + ".attn1.to_qkv.weight" in W:  # q | k | v in one two-destination launch (q, k row-major + V^T)
                         qk, vt = E.linear(n, W[b + ".attn1.to_qkv.weight"], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
                     else:
                         qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")
                         vt = E.linear(n, W[b + ".attn1.to_v.weight"], transposed_out=True, rows_per_batch=N, pad_cols=_rup(N, 64), name="vt")
-                a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
+                if vrow:
+                    a = E.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads, v_rowmajor=True, name="sa")
+                else:
+                    a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
                 h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
                 fold = _ln_fold(E, W, b + ".attn2.to_q")
                 if fold:
