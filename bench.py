@@ -46,7 +46,7 @@ WORKLOADS = {
 GFLOP_PER_CALL = {512: 8000.0, 256: 1888.0}
 
 
-PMC_TRAFFIC_FILE = "r02_v4_pmc_traffic_tiled_b8.json"
+PMC_TRAFFIC_FILE = "r02_v6_pmc_traffic_tiled_b8.json"
 
 
 def pmc_traffic_per_launch(family: str):
