@@ -104,6 +104,9 @@ SIGNATURES = {
     "gn_gather_rows": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_argmax_rows_i32": (_I32, [_P, _P, _P, _I32, _I32]),
     "gn_copy4d": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),
+    "gn_pack_conv_weight": (_I32, [_P, _P, _I32, _P, _I32, _I32, _I32, _I32]),
+    "gn_pack_geglu_rows": (_I32, [_P, _P, _I32, _P, _I32, _I64]),
+    "gn_pack_fold_layernorm": (_I32, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I64]),
     "gn_program_add_image_normalize_u8": (_I32, [_P, _P, _P, _I64, _I32, _F, _F, _F, _F, _F, _F]),
     "gn_program_add_gather_rows": (_I32, [_P, _P, _P, _P, _I32, _I32, _I32]),
     "gn_program_add_copy4d": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),

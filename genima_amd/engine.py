@@ -482,6 +482,27 @@ class Engine:
         self._gemm(d, (x, x2, w, bias, shift, residual, out))
         return out
 
+    # ------------------------------------------------------------------------------------------------ weight repacking (gn_pack_*)
+    def pack_conv_weight(self, w: torch.Tensor) -> torch.Tensor:
+        """OIHW f32 / f16 device tensor -> [round_up(O, 8), KH * KW * round_up(I, 8)] f16 (gn_pack_conv_weight)."""
+        assert w.dim() == 4 and w.is_cuda and w.dtype in (torch.float32, torch.float16) and not self.record
+        w = w.contiguous()
+        O, I, KH, KW = w.shape
+        out = torch.empty((_round_up(O, 8), KH * KW * _round_up(I, 8)), dtype=F16, device=self.device)
+        check(self.lib.gn_pack_conv_weight(self._ctx, _ptr(w), int(w.dtype == torch.float16), _ptr(out), O, I, KH, KW), "gn_pack_conv_weight")
+        return out
+
+    def pack_geglu(self, w: torch.Tensor, b: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """GEGLU.proj weight [2H, K] and bias [2H] (hidden rows, then gate rows) -> 32-row blocks hidden | gate, f16 (gn_pack_geglu_rows)."""
+        assert w.dim() == 2 and w.is_cuda and w.dtype == b.dtype and w.dtype in (torch.float32, torch.float16) and not self.record
+        w, b = w.contiguous(), b.contiguous()
+        H, K = w.shape[0] // 2, w.shape[1]
+        wp, bp = torch.empty((2 * H, K), dtype=F16, device=self.device), torch.empty((2 * H,), dtype=F16, device=self.device)
+        f16 = int(w.dtype == torch.float16)
+        check(self.lib.gn_pack_geglu_rows(self._ctx, _ptr(w), f16, _ptr(wp), H, K), "gn_pack_geglu_rows")
+        check(self.lib.gn_pack_geglu_rows(self._ctx, _ptr(b), f16, _ptr(bp), H, 1), "gn_pack_geglu_rows")
+        return wp, bp
+
     # ------------------------------------------------------------------------------------------------ attention
     def attention(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, Nk: Optional[int] = None,
                   causal: bool = False, out: Optional[torch.Tensor] = None, name: Optional[str] = None,

@@ -110,15 +110,15 @@ def fold_layernorms(packed: Dict[str, torch.Tensor]) -> None:
             wn = base + lin + ".weight"
             if wn not in packed or packed[wn].dim() != 2:
                 continue
-            gamma, beta = packed[name].float(), packed[base + ln + ".bias"].float()
             w = packed[wn].float()
+            gamma, beta = packed[name].float().to(w.device), packed[base + ln + ".bias"].float().to(w.device)
             if w.shape[1] != gamma.numel():
                 continue
             wg = (w * gamma[None, :]).to(torch.float16)
             c2 = w @ beta
             bn = base + lin + ".bias"
             if bn in packed:
-                c2 = c2 + packed[bn].float()
+                c2 = c2 + packed[bn].float().to(w.device)
             packed[base + lin + ".ln_weight"] = wg.contiguous()
             packed[base + lin + ".ln_c1"] = wg.float().sum(dim=1).contiguous()
             packed[base + lin + ".ln_c2"] = c2.to(torch.float16).contiguous()
@@ -129,17 +129,27 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
     ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams)."""
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     temb_w, temb_b, temb_slices, off = [], [], OrderedDict(), 0
+    # f16 copies for a ROCm device: the two layout shuffles run as the library's own gn_pack_* kernels on the uploaded tensors (the same
+    # entry points a non-Python host calls; bit-identical to the torch restatements above, tests/test_kernels_gpu.py)
+    hip = None
+    if dtype == torch.float16 and torch.device(device).type == "cuda" and torch.cuda.is_available():
+        from .engine import Engine
+
+        hip = Engine(torch.device(device))
     for name, t in sd.items():
         t = t.detach().to(torch.float32)
         if t.dim() == 4:
-            out[name] = pack_conv_weight(t, dtype=dtype)
+            out[name] = hip.pack_conv_weight(t.to(hip.device)) if hip is not None else pack_conv_weight(t, dtype=dtype)
             bn = name[: -len("weight")] + "bias"
             if bn in sd:
                 out[bn] = pack_vec(sd[bn].detach().float(), out[name].shape[0], dtype=dtype)
         elif t.dim() == 2:
             if name.endswith("ff.net.0.proj.weight"):
                 bn = name[: -len("weight")] + "bias"
-                wp, bp = pack_geglu(t, sd[bn].detach().float(), dtype=dtype)
+                if hip is not None:
+                    wp, bp = hip.pack_geglu(t.to(hip.device), sd[bn].detach().float().to(hip.device))
+                else:
+                    wp, bp = pack_geglu(t, sd[bn].detach().float(), dtype=dtype)
                 out[name], out[bn] = wp, bp
                 continue
             if name.endswith("time_emb_proj.weight"):
@@ -186,5 +196,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
         meta["temb_slices"] = temb_slices
         meta["temb_total"] = off
     dev = OrderedDict((k, v.to(device)) for k, v in out.items())
+    if hip is not None:
+        hip.synchronize()  # the packing kernels ran on this engine's stream: finished before any other engine reads the weights
     dev["__meta__"] = meta  # type: ignore[assignment]
     return dev

@@ -203,6 +203,19 @@ int32_t gn_image_f16_to_u8(gn_ctx* ctx, const void* in, uint8_t* out, int64_t pi
  * (m_c = 1/(255 std_c), a_c = -mean_c/std_c; channels >= 3 zero) */
 int32_t gn_image_normalize_u8(gn_ctx* ctx, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad, float m0, float m1,
                               float m2, float a0, float a1, float a2);
+/* ---- weight repacking (explicit gn_pack_* calls into caller-owned buffers; genima_amd/packing.py is the Python
+ * host's torch restatement of the same layouts, bit-identical on the two copies: tests/test_kernels_gpu.py) -------------------------
+ * diffusers Conv2d.weight OIHW (f32, or f16 when src_f16) -> dst f16 [round_up(O, 8)][KH * KW * round_up(I, 8)] with
+ * dst[o][(kh * KW + kw) * Ip + c] = src[o][c][kh][kw], zero padding: the W operand of gn_gemm(conv) */
+int32_t gn_pack_conv_weight(gn_ctx* ctx, const void* src_oihw, int32_t src_f16, void* dst, int32_t O, int32_t I, int32_t KH, int32_t KW);
+/* diffusers GEGLU.proj weight [2H, K] (or its bias: K = 1), hidden rows first then gate rows -> alternating 32-row blocks
+ * [hidden 0..31 | gate 0..31 | hidden 32..63 | ...], the order GN_ACT_GEGLU's epilogue pairs up.  H % 32 == 0 */
+int32_t gn_pack_geglu_rows(gn_ctx* ctx, const void* src, int32_t src_f16, void* dst, int32_t H, int64_t K);
+/* operands of gn_gemm_desc::ln_c1 from a packed f16 Linear weight w [N, K] (row stride ldw) and its LayerNorm's gamma / beta [K]
+ * (+ the Linear's bias [N] or NULL): ln_weight = f16(w * gamma) [N, K] (row stride ldw), ln_c1[n] = sum_k ln_weight[n, k] (f32),
+ * ln_c2[n] = f16(sum_k w[n, k] * beta[k] + bias[n]) */
+int32_t gn_pack_fold_layernorm(gn_ctx* ctx, const void* w, const void* gamma, const void* beta, const void* bias, void* ln_weight,
+                               float* ln_c1, void* ln_c2, int32_t N, int32_t K, int64_t ldw);
 /* out[b, :] = x[b, idx[b], :]  (CLIP EOT-token pooling, controller/method/genima_act.py:337-343) */
 int32_t gn_gather_rows(gn_ctx* ctx, const void* x, const int32_t* idx, void* out, int32_t B, int32_t L, int32_t D);
 /* out[i] = index of the first maximum of row i of an int32 [rows, cols] matrix (EOT = highest token id) */

@@ -274,3 +274,41 @@ def test_misc_ops(engine):
     mp = engine.maxpool3x3s2(x)
     ref = F.max_pool2d(x.float().cpu().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(mp.float().cpu(), ref)
+
+
+def test_pack_entry_points_match_the_python_packers(engine):
+    """gn_pack_conv_weight / gn_pack_geglu_rows / gn_pack_fold_layernorm (the C-ABI repacking a non-Python host calls) against
+    genima_amd/packing.py on the same tensors: the two layout shuffles bit for bit (f32 and f16 sources, channel counts that need
+    padding), the LayerNorm fold's W * gamma bit for bit and its sums to f32 / f16 rounding."""
+    import ctypes as C
+
+    from genima_amd import packing
+    from genima_amd.engine import check
+
+    E = engine
+    for (O, I, KH, KW) in ((20, 12, 3, 3), (64, 64, 1, 1), (8, 3, 7, 7), (136, 320, 3, 3)):
+        w = torch.randn(O, I, KH, KW, device="cuda") * 0.1
+        want = packing.pack_conv_weight(w)
+        for src in (w, w.half()):
+            got = torch.full_like(want, float("nan"))
+            check(E.lib.gn_pack_conv_weight(E._ctx, C.c_void_p(src.data_ptr()), int(src.dtype == torch.float16), C.c_void_p(got.data_ptr()), O, I, KH, KW), "gn_pack_conv_weight")
+            ref = want if src.dtype == torch.float32 else packing.pack_conv_weight(src.float())
+            assert torch.equal(got, ref), (O, I, KH, KW, src.dtype)
+    for (H, K) in ((64, 40), (1280, 320)):
+        w, b = torch.randn(2 * H, K, device="cuda") * 0.1, torch.randn(2 * H, device="cuda")
+        wp, bp = packing.pack_geglu(w, b)
+        gw, gb = torch.empty_like(wp), torch.empty_like(bp)
+        check(E.lib.gn_pack_geglu_rows(E._ctx, C.c_void_p(w.data_ptr()), 0, C.c_void_p(gw.data_ptr()), H, K), "gn_pack_geglu_rows")
+        check(E.lib.gn_pack_geglu_rows(E._ctx, C.c_void_p(b.data_ptr()), 0, C.c_void_p(gb.data_ptr()), H, 1), "gn_pack_geglu_rows")
+        assert torch.equal(gw, wp) and torch.equal(gb, bp)
+    N, K = 960, 320
+    packed = {"tb.norm1.weight": (1 + 0.2 * torch.randn(K, device="cuda")).half(), "tb.norm1.bias": (0.1 * torch.randn(K, device="cuda")).half(),
+              "tb.attn1.to_qkv.weight": (torch.randn(N, K, device="cuda") * K ** -0.5).half()}
+    packing.fold_layernorms(packed)
+    wg, c1, c2 = torch.empty(N, K, device="cuda", dtype=torch.float16), torch.empty(N, device="cuda"), torch.empty(N, device="cuda", dtype=torch.float16)
+    check(E.lib.gn_pack_fold_layernorm(E._ctx, C.c_void_p(packed["tb.attn1.to_qkv.weight"].data_ptr()), C.c_void_p(packed["tb.norm1.weight"].data_ptr()),
+                                       C.c_void_p(packed["tb.norm1.bias"].data_ptr()), None, C.c_void_p(wg.data_ptr()), C.c_void_p(c1.data_ptr()),
+                                       C.c_void_p(c2.data_ptr()), N, K, K), "gn_pack_fold_layernorm")
+    assert torch.equal(wg, packed["tb.attn1.to_qkv.ln_weight"])
+    assert float((c1 - packed["tb.attn1.to_qkv.ln_c1"]).abs().max()) <= 1e-5 * float(packed["tb.attn1.to_qkv.ln_c1"].abs().max()) + 1e-6
+    assert float((c2.float() - packed["tb.attn1.to_qkv.ln_c2"].float()).abs().max()) <= 2e-3 * float(packed["tb.attn1.to_qkv.ln_c2"].float().abs().max())
