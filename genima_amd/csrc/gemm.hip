@@ -230,7 +230,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // DMA instructions per wave per tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES) + (LNF ? BN * 4 : 0)];  // + the workgroup's c1 values (LNF)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -372,6 +372,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   bool use_pre = false;
   if constexpr (PRE) use_pre = epilogue_prefetch<TM, TN>(p, pre, m0 + wm * WTM, n0 + wn * WTN, l31, hi);  // lands under the K loop
 
+  if constexpr (LNF) ln_c1_to_lds<BN>(p, reinterpret_cast<float*>(smem + 2 * (A_BYTES + B_BYTES)), n0);
   dma_tile(0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -409,7 +410,8 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   }
 
   if constexpr (LNF)  // (the barrier that ended the K loop freed the LDS tiles)
-    ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn, n0 + wn * WTN, l31, hi);
+    ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn,
+                                  reinterpret_cast<const float*>(smem + 2 * (A_BYTES + B_BYTES)) + wn * WTN, l31, hi);
   gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
 }
 

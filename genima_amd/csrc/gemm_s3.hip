@@ -30,7 +30,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // DMA instructions per wave per tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (A_BYTES + B_BYTES)];  // ONE LDS object (a second one makes hipcc drain vmcnt)
+  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (A_BYTES + B_BYTES) + (LNF ? BN * 4 : 0)];  // ONE LDS object (a second one makes hipcc drain vmcnt)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -176,6 +176,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   EpiPre<TM, TN> pre;
   bool use_pre = false;
   if constexpr (PRE) use_pre = epilogue_prefetch<TM, TN>(p, pre, m0 + wm * WTM, n0 + wn * WTN, l31, hi);  // older than every DMA: retired by the first counted wait
+  if constexpr (LNF) {  // the workgroup's c1 values -> the tail of the LDS object, before any DMA is in flight
+    ln_c1_to_lds<BN>(p, reinterpret_cast<float*>(smem + 3 * (A_BYTES + B_BYTES)), n0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the raw s_barrier below does not wait for the ds_write)
+  }
   dma_tile(0);
   dma_tile(1);  // past the last K tile the offsets are out of range: zero fill, no fetch -- the count stays the same on every path
   wait_vmcnt<NIN>();
@@ -220,7 +224,8 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
 
   if constexpr (LNF) {
     __syncthreads();  // every wave's run-ahead fills have landed: the LDS ring is free for the row statistics
-    ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn, n0 + wn * WTN, l31, hi);
+    ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn,
+                                  reinterpret_cast<const float*>(smem + 3 * (A_BYTES + B_BYTES)) + wn * WTN, l31, hi);
   }
   gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
 }
