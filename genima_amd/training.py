@@ -624,12 +624,17 @@ class ControlNetTrainer:
 
     def __init__(self, E: Engine, unet_cfg, controlnet_cfg, unet_W, controlnet_sd, *, lr: float = 1e-5, betas=(0.9, 0.999),
                  weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, loss_scale: float = 65536.0,
-                 growth_interval: int = 2000, allreduce=None, gradient_accumulation_steps: int = 1, lr_lambda=None):
+                 growth_interval: int = 2000, allreduce=None, gradient_accumulation_steps: int = 1, lr_lambda=None, gc_freeze: bool = True):
         """``gradient_accumulation_steps``: micro-batches per optimizer step (``accelerator.accumulate`` + the 1/N loss scaling of
         ``accelerator.backward``, diffusion/train_controlnet_genima.py:1319, :1402); ``lr_lambda``: step -> multiplier of ``lr``
         (train_loop.get_scheduler = the reference's ``get_scheduler(args.lr_scheduler, ...)``, :1206-1213), advanced once per APPLIED
         optimizer step as accelerate's scheduler wrapper does (a step skipped by the GradScaler does not advance it)."""
         self.E, self.unet_cfg, self.cn_cfg = E, unet_cfg, controlnet_cfg
+        # ``gc_freeze``: the step is an eager Python tape (a few thousand short-lived objects per step); left alone, the cyclic collector's
+        # full passes re-scan every long-lived object of the process (weights, trainer state) about once a step -- 0.8 ms pauses that the
+        # GPU sits out (rocprofv3: 3 ms of a 69 ms step).  After the second step everything alive is moved to the permanent generation
+        # (gc.freeze(): never scanned again, and never collected -- call gc.unfreeze() when disposing of a trainer for good)
+        self._gc_freeze, self._steps_seen = bool(gc_freeze) and os.environ.get("GN_GC_FREEZE", "1") != "0", 0
         self.unet = FrozenParams(E, unet_W)
         self.cn = TrainParams(E, controlnet_sd)
         self.lr, self.betas, self.wd, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
@@ -823,4 +828,11 @@ class ControlNetTrainer:
             E.copy4d(pen_g, ctx[:, :, dl:], (1, 1, B, L), (0, 0, L * dg, dg), (0, 0, L * (dl + dg), dl + dg), dg)
             R = float(x8.shape[1])
             added = (pooled, torch.tensor([[R, R, 0.0, 0.0, R, R]] * B, dtype=F32, device=dev))
-        return self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8, added)
+        loss = self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8, added)
+        self._steps_seen += 1
+        if self._gc_freeze and self._steps_seen == 2:
+            import gc
+
+            gc.collect()
+            gc.freeze()
+        return loss
