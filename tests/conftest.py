@@ -28,3 +28,14 @@ def engine():
     from genima_amd.engine import Engine
 
     return Engine("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _collector_sees_everything_between_tests():
+    """ControlNetTrainer(gc_freeze=True) parks every live object in the permanent generation after its second step (training.py);
+    between tests they go back under the collector, so a finished test's trainer (and its device buffers) is reclaimed."""
+    yield
+    import gc
+
+    gc.unfreeze()
+    gc.collect()
