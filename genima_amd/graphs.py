@@ -69,7 +69,8 @@ def _shift_for(W, shifts: Optional[torch.Tensor], prefix: str):
 
 
 # ------------------------------------------------------------------------------------------------ blocks
-def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float):
+def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, eps_in: Optional[float] = None):
+    """eps_in: norm1's epsilon when the block input carries a scaled residual stream (packing.scale_vae_stream); default eps."""
     with E.scope(p):
         has_sc = (p + ".conv_shortcut.weight") in W
         # the 1x1 shortcut conv only reads the block input: where the program's side stream is idle (the UNet decoder, after the
@@ -84,7 +85,7 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float):
         else:
             assert x2 is None
             sc = x
-        h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps, act=ACT_SILU, x2=x2, name="n1")
+        h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, act=ACT_SILU, x2=x2, name="n1")
         sh, ld = _shift_for(W, shifts, p) if (p + ".time_emb_proj.weight") in W else (None, 0)
         h = E.conv2d(h, W[p + ".conv1.weight"], W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
         h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
@@ -256,13 +257,19 @@ def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, co
 
 
 # ------------------------------------------------------------------------------------------------ AutoencoderKL
+def _vae_eps(W) -> float:
+    """epsilon of the GroupNorms that read the VAE's residual stream: 1e-6 x (stream scale)^2 (packing.scale_vae_stream)."""
+    meta = W.get("__meta__") or {}
+    return 1e-6 * float(meta.get("vae_stream_scale", 1.0)) ** 2
+
+
 def _emit_vae_attention(E: Engine, W, p: str, x, groups: int):
     """Single-head, d = C attention of the VAE mid block: QK^T and PV as plain MFMA GEMMs around a row softmax (the d=512
     head does not fit the flash kernel's register tile; it is 1.4 % of the decoder's FLOPs)."""
     B, H, Wd, Cc = x.shape
     N = H * Wd
     with E.scope(p):
-        h = E.groupnorm(x, W[p + ".group_norm.weight"], W[p + ".group_norm.bias"], groups, 1e-6, name="gn").view(B, N, Cc)
+        h = E.groupnorm(x, W[p + ".group_norm.weight"], W[p + ".group_norm.bias"], groups, _vae_eps(W), name="gn").view(B, N, Cc)
         q = E.linear(h, W[p + ".to_q.weight"], W[p + ".to_q.bias"], name="q")
         k = E.linear(h, W[p + ".to_k.weight"], W[p + ".to_k.bias"], name="k")
         Np = _rup(N, 64)
@@ -278,9 +285,9 @@ def _emit_vae_attention(E: Engine, W, p: str, x, groups: int):
 
 
 def _emit_vae_mid(E, W, p, h, G):
-    h = emit_resnet(E, W, p + ".resnets.0", h, None, None, G, 1e-6)
+    h = emit_resnet(E, W, p + ".resnets.0", h, None, None, G, 1e-6, eps_in=_vae_eps(W))
     h = _emit_vae_attention(E, W, p + ".attentions.0", h, G)
-    return emit_resnet(E, W, p + ".resnets.1", h, None, None, G, 1e-6)
+    return emit_resnet(E, W, p + ".resnets.1", h, None, None, G, 1e-6, eps_in=_vae_eps(W))
 
 
 def emit_vae_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
@@ -293,11 +300,11 @@ def emit_vae_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
         h = _emit_vae_mid(E, W, "decoder.mid_block", h, G)
         for i in range(n):
             for j in range(cfg["layers_per_block"] + 1):
-                h = emit_resnet(E, W, f"decoder.up_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6)
+                h = emit_resnet(E, W, f"decoder.up_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6, eps_in=_vae_eps(W))
             if i != n - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
-        h = E.groupnorm(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, 1e-6, act=ACT_SILU, name="norm_out")
+        h = E.groupnorm(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, _vae_eps(W), act=ACT_SILU, name="norm_out")
         return E.conv2d(h, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], name="conv_out")
 
 
@@ -309,12 +316,12 @@ def emit_vae_encode_moments(E: Engine, W, cfg, x8: torch.Tensor) -> torch.Tensor
         h = E.conv2d(x8, W["encoder.conv_in.weight"], W["encoder.conv_in.bias"], name="conv_in")
         for i in range(n):
             for j in range(cfg["layers_per_block"]):
-                h = emit_resnet(E, W, f"encoder.down_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6)
+                h = emit_resnet(E, W, f"encoder.down_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6, eps_in=_vae_eps(W))
             if i != n - 1:
                 p = f"encoder.down_blocks.{i}.downsamplers.0.conv"
                 h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, pad=(0, 0, 1, 1), name=p)  # F.pad (0,1,0,1)
         h = _emit_vae_mid(E, W, "encoder.mid_block", h, G)
-        h = E.groupnorm(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], G, 1e-6, act=ACT_SILU, name="norm_out")
+        h = E.groupnorm(h, W["encoder.conv_norm_out.weight"], W["encoder.conv_norm_out.bias"], G, _vae_eps(W), act=ACT_SILU, name="norm_out")
         h = E.conv2d(h, W["encoder.conv_out.weight"], W["encoder.conv_out.bias"], name="conv_out")
         return E.conv2d(h, W["quant_conv.weight"], W["quant_conv.bias"], ksize=1, name="quant")
 

@@ -259,6 +259,23 @@ class DiagonalGaussianDistribution:
 
 class AutoencoderKL(HipModule):
     schema_fn = staticmethod(schema.vae_schema)
+    stream_scale = 1.0  # != 1: the residual stream is carried scaled (enable_stream_scaling)
+
+    def enable_stream_scaling(self, s: float = 1.0 / 64.0):
+        """The f16 answer to diffusers' ``force_upcast`` / ``pipe.upcast_vae()`` (the stock SDXL VAE's residual stream exceeds f16's range,
+        so diffusers decodes in fp32): keep f16 storage but carry the stream multiplied by ``s`` -- an exact re-parametrisation of the
+        weights (packing.scale_vae_stream) with the stream GroupNorms' eps scaled by s^2.  Outputs are unchanged up to f16 rounding."""
+        self.stream_scale = float(s)
+        if self.W is not None:
+            self._pack()
+        return self
+
+    def _pack(self):
+        if self.stream_scale == 1.0:
+            return super()._pack()
+        self.W = packing.pack_state_dict(packing.scale_vae_stream(self._sd, self.stream_scale), self.device)
+        self.W["__meta__"]["vae_stream_scale"] = self.stream_scale
+        self._pack_gen += 1
 
     def decode(self, z, return_dict=True, **kw):
         E = self.engine()

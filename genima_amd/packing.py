@@ -91,6 +91,22 @@ def unpack_state_dict(packed: Dict[str, torch.Tensor], schema: Dict[str, tuple],
     return out
 
 
+def scale_vae_stream(sd: Dict[str, torch.Tensor], s: float) -> "OrderedDict[str, torch.Tensor]":
+    """AutoencoderKL weights re-parametrised so that the RESIDUAL STREAM of the encoder and the decoder carries ``s`` times its values
+    (s = 1/64: the stock SDXL VAE's stream exceeds f16's 65 504 -- diffusers' ``force_upcast`` runs it in fp32 for that reason).  Exact in
+    real arithmetic: everything that WRITES the stream is scaled (conv_in, each ResnetBlock2D's conv2, the attention's to_out: weight and
+    bias; convs that map the stream to the stream -- conv_shortcut, up / down samplers -- keep their weight and scale their bias), and
+    everything that READS it is a GroupNorm, which is scale-invariant once its eps is multiplied by s^2 (graphs.emit_vae_* read
+    ``__meta__["vae_stream_scale"]``).  Returns a new dict; tensors that do not change are shared."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in sd.items():
+        head = k.startswith(("decoder.", "encoder."))
+        both = head and (k.split(".", 1)[1].startswith("conv_in.") or ".conv2." in k or ".to_out.0." in k)
+        bias_only = head and k.endswith(".bias") and (".conv_shortcut." in k or ".upsamplers." in k or ".downsamplers." in k)
+        out[k] = v * s if (both or bias_only) else v
+    return out
+
+
 # (LayerNorm, consuming Linear) pairs whose LayerNorm is folded into the Linear's launch (gn_gemm_desc.ln_c1, csrc/gemm_common.h
 # ln_fold_apply): diffusers BasicTransformerBlock norm1 -> attn1 q | k | v, norm2 -> attn2.to_q, norm3 -> the GEGLU projection;
 # CLIPEncoderLayer layer_norm1 -> q | k | v, layer_norm2 -> fc1.

@@ -150,8 +150,11 @@ class StableDiffusionControlNetPipeline:
 
     def upcast_vae(self):
         """diffusers casts the VAE to fp32 here.  The HIP VAE stores activations in f16 and accumulates in f32: the SD-2.x VAE and
-        the SDXL fp16-fix VAE are in range in that format, so there is nothing to upcast; a VAE that needs fp32 activations
-        (``force_upcast``) is rejected when the SDXL pipeline is built, not silently run in f16."""
+        the SDXL fp16-fix VAE are in range in that format; for a VAE whose residual stream is not (``force_upcast``) this switches the
+        stream scaling on (host.AutoencoderKL.enable_stream_scaling), which is what the SDXL pipeline's from_pretrained does by itself."""
+        if hasattr(self.vae, "enable_stream_scaling") and getattr(self.vae, "stream_scale", 1.0) == 1.0:
+            self.vae.enable_stream_scaling()
+            self._progs.clear() if hasattr(self, "_progs") else None
         return None
 
     def enable_vae_slicing(self):
@@ -379,10 +382,10 @@ class StableDiffusionXLControlNetPipeline(StableDiffusionControlNetPipeline):
         vae = AutoencoderKL.from_pretrained(path, "vae", variant=variant)
         # diffusers' SDXL pipeline decodes in fp32 when vae.config.force_upcast is set (the stock SDXL VAE overflows f16 and yields
         # NaN / black images); the HIP VAE keeps f16 activations, so such a VAE is refused here instead of producing garbage
+        # the HIP VAE keeps f16 activations: such a VAE runs with its residual stream carried at 1/64 (host.AutoencoderKL.enable_stream_scaling,
+        # an exact re-parametrisation of the weights), not silently in plain f16; allow_fp16_vae=True skips that for a VAE known to be in range
         if vae.config.get("force_upcast", True) and not allow_fp16_vae:
-            raise NotImplementedError(f"{os.path.join(path, 'vae')} sets force_upcast (the stock SDXL VAE overflows in f16); use the fp16-fix "
-                                      "VAE (madebyollin/sdxl-vae-fp16-fix, the trainer's --pretrained_vae_model_name_or_path) or a "
-                                      "taesdxl autoencoder, or pass allow_fp16_vae=True if this VAE is known to be f16-safe")
+            vae.enable_stream_scaling()
         text = CLIPTextModel.from_pretrained(path, "text_encoder", variant=variant)
         text2 = CLIPTextModelWithProjection.from_pretrained(path, "text_encoder_2", variant=variant)
         with open(os.path.join(path, "scheduler", "scheduler_config.json")) as f:

@@ -116,7 +116,7 @@ def test_real_weights_need_the_real_tokenizer_and_sdxl_force_upcast(tmp_path):
     assert isinstance(pipe.tokenizer, CLIPTokenizer)
     ids = pipe.encode_ids(["open"])[0].tolist()
     assert ids[:3] == [vocab[BOS], vocab["open</w>"], vocab[EOS]] and ids[3:] == [vocab["!"]] * 74
-    # SDXL: a VAE that asks for the fp32 decode is refused unless the caller vouches for it
+    # SDXL: a VAE that asks for the fp32 decode gets the stream-scaled f16 decode unless the caller vouches for plain f16
     xl = str(tmp_path / "xl")
     famx = configs.family("tiny-xl")
     _write_component(xl, "unet", famx["unet"], schema.unet_schema, 1)
@@ -126,10 +126,10 @@ def test_real_weights_need_the_real_tokenizer_and_sdxl_force_upcast(tmp_path):
     os.makedirs(os.path.join(xl, "scheduler"))
     with open(os.path.join(xl, "scheduler", "scheduler_config.json"), "w") as f:
         json.dump(dict(configs.SD_TURBO_SCHEDULER, _class_name="EulerAncestralDiscreteScheduler"), f)
-    with pytest.raises(NotImplementedError, match="force_upcast"):
-        StableDiffusionXLControlNetPipeline.from_pretrained(xl, allow_hash_tokenizer=True)
+    p1 = StableDiffusionXLControlNetPipeline.from_pretrained(xl, allow_hash_tokenizer=True)
+    assert p1.vae.stream_scale == 1.0 / 64.0  # force_upcast: the residual stream is carried scaled, not run in plain f16
     p2 = StableDiffusionXLControlNetPipeline.from_pretrained(xl, allow_hash_tokenizer=True, allow_fp16_vae=True)
-    assert isinstance(p2.tokenizer_2, HashTokenizer)
+    assert isinstance(p2.tokenizer_2, HashTokenizer) and p2.vae.stream_scale == 1.0
 
 
 def test_taesd_schema_and_prediction_type():

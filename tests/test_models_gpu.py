@@ -108,6 +108,37 @@ def test_vae_decode_and_encode():
     _report("vae encode logvar", dist.logvar.cpu(), lv16, lv32, 3e-3, 1e-2)
 
 
+def test_vae_stream_scaling_is_exact_and_survives_an_out_of_range_stream():
+    """AutoencoderKL.enable_stream_scaling (the f16 answer to diffusers' force_upcast / upcast_vae, packing.scale_vae_stream): (a) on an
+    ordinary VAE the scaled-stream decode / encode equal the fp32 oracle ON THE ORIGINAL WEIGHTS as well as the plain path does -- the
+    re-parametrisation changes nothing but rounding; (b) on a VAE whose residual stream leaves f16's range (conv_in x 3e4, the stock SDXL
+    VAE's failure) the plain f16 decode is not finite, the scaled one still matches the fp32 oracle."""
+    cfg = FAM["vae"]
+    sd = _r16(weights.synth_state_dict(schema.vae_schema(cfg), 3))
+    g = torch.Generator().manual_seed(5)
+    z = q16(torch.randn(2, 4, 16, 16, generator=g))
+    x = q16(torch.rand(2, 3, 128, 128, generator=g) * 2 - 1)
+    vae = AutoencoderKL(cfg, sd).to("cuda").enable_stream_scaling()
+    assert vae.W["__meta__"]["vae_stream_scale"] == 1.0 / 64.0
+    with torch.no_grad():
+        _report("vae decode, scaled stream", vae.decode(z.half()).sample.float().cpu(), O.vae_decode(sd, cfg, z, q16), O.vae_decode(sd, cfg, z), 3e-3, 1e-2)
+        m16, _ = O.vae_encode_moments(sd, cfg, x, q16)
+        m32, _ = O.vae_encode_moments(sd, cfg, x)
+    _report("vae encode mean, scaled stream", vae.encode(x.half()).latent_dist.mean.cpu(), m16, m32, 3e-3, 1e-2)
+    big = dict(sd)
+    for k in ("decoder.conv_in.weight", "decoder.conv_in.bias"):
+        big[k] = sd[k] * 3.0e4
+    with torch.no_grad():
+        ref = O.vae_decode(big, cfg, z)
+    plain = AutoencoderKL(cfg, big).to("cuda").decode(z.half()).sample.float().cpu()
+    assert not torch.isfinite(plain).all() or rel_l2(plain, ref) > 0.1, "the test VAE was meant to overflow plain f16"
+    scaled = AutoencoderKL(cfg, big).to("cuda").enable_stream_scaling().decode(z.half()).sample.float().cpu()
+    assert torch.isfinite(scaled).all()
+    e = rel_l2(scaled, ref)
+    print(f"vae decode, stream ~1e5, scaled by 1/64: rel-L2 vs fp32 oracle {e:.2e}")
+    assert e <= 5e-3, e
+
+
 def _oracle_pipeline(pipe, ids, img_u8, latents, steps, q):
     """Appendix D loop on the CPU oracle with the same weights."""
     from oracle import scheduler as OS
