@@ -29,6 +29,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# multi-process GPU work on these hosts needs dmabuf IPC (RCCL / device-tensor sharing fail with hipIpcGetMemHandle otherwise)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
