@@ -58,8 +58,10 @@ def save_tune_table():
     for path in (TUNE_PATH, os.path.join(os.path.dirname(os.path.dirname(TUNE_PATH)), "gpurun_out", "gemm_tune_gfx950.json")):
         try:
             if os.path.isdir(os.path.dirname(path)):
-                with open(path, "w") as f:
+                tmp = f"{path}.{os.getpid()}.tmp"  # several ranks may save at once: each writes its own file, the rename is atomic
+                with open(tmp, "w") as f:
                     json.dump(dict(sorted(_tune_table().items())), f, indent=0)
+                os.replace(tmp, path)
         except OSError:
             pass
     _tune_dirty[0] = False
