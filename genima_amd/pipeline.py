@@ -173,15 +173,19 @@ class StableDiffusionControlNetPipeline:
     def _fill_prompt_inputs(self, io, kw):
         """Per-call inputs beyond ids / image / noise (SDXL: the second tower's ids)."""
 
-    def _build(self, B: int, H: int, W: int, steps: int):
+    def _build(self, B: int, H: int, W: int, steps: int, guidance: Optional[float] = None):
+        """guidance (> 1): classifier-free guidance as diffusers' pipeline runs it -- the ControlNet and the UNet see the batch twice
+        (rows [0, B): the negative prompts, rows [B, 2B): the prompts; same latents, same control images) and the step uses
+        eps_uncond + guidance * (eps_text - eps_uncond).  The reference's configs run guidance_scale = 0.0 (no doubling)."""
         dev = self.device
         E = Engine(dev, record=True)
         s = self.vae_scale_factor
         h, w = H // s, W // s
         L = self.tokenizer.model_max_length if hasattr(self.tokenizer, "model_max_length") else 77
         io = SimpleNamespace()
-        io.ids = E.buf("in_ids", (B, L), dtype=torch.int32, zero=True)
-        io.image_u8 = E.buf("in_image", (B, H, W, 3), dtype=torch.uint8, zero=True)
+        Bn = 2 * B if guidance else B  # rows the networks see
+        io.ids = E.buf("in_ids", (Bn, L), dtype=torch.int32, zero=True)
+        io.image_u8 = E.buf("in_image", (Bn, H, W, 3), dtype=torch.uint8, zero=True)
         Cl = self.unet.config["in_channels"]
         io.noise = E.buf("in_noise", (B, h, w, Cl), zero=True)       # unit-variance draws (randn_tensor), NHWC
         io.latents = E.buf("latents", (B, h, w, Cl), zero=True)
@@ -196,7 +200,7 @@ class StableDiffusionControlNetPipeline:
         cemb = graphs.emit_controlnet_cond(E, self.controlnet.W, self.controlnet.config, cond8)
         if self.two_streams:
             E.main()
-        ctx, added = self._emit_prompt(E, io, B, L, H, W)
+        ctx, added = self._emit_prompt(E, io, Bn, L, H, W)
         kv_cn = graphs.emit_cross_kv(E, self.controlnet.W, ctx, "cn")
         kv_un = graphs.emit_cross_kv(E, self.unet.W, ctx, "unet")
         if self.two_streams:
@@ -217,9 +221,14 @@ class StableDiffusionControlNetPipeline:
         io.first_step_op = E.num_ops
         for i in range(steps):
             sigma, sigma_next = (0.0, 0.0) if linear else (float(sch.sigmas[i]), float(sch.sigmas[i + 1]))
-            t_dev = torch.full((B,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
+            t_dev = torch.full((Bn,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
             E._keepalive(t_dev)
-            x8 = E.scale_pad(io.latents, sch.input_scale(i), 8, name="x8")
+            if guidance:  # latent_model_input = torch.cat([latents] * 2)
+                x8 = E.buf("x8", (Bn, h, w, 8))
+                E.scale_pad(io.latents, sch.input_scale(i), 8, out=x8[:B])
+                E.scale_pad(io.latents, sch.input_scale(i), 8, out=x8[B:])
+            else:
+                x8 = E.scale_pad(io.latents, sch.input_scale(i), 8, name="x8")
             # the ControlNet and the UNet encoder + mid block both read only x8: the ControlNet runs on the program's side stream and is
             # joined where the UNet consumes its residuals (fills the CUs the small-M deep-level kernels leave idle)
             if self.two_streams:
@@ -229,6 +238,8 @@ class StableDiffusionControlNetPipeline:
                 E.main()
             eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid, added=added,
                                    before_residuals=E.join if self.two_streams else None)
+            if guidance:  # noise_pred = uncond + guidance_scale * (text - uncond)
+                eps = E.add_noise(eps[:B], eps[B:], scalar(1.0 - guidance), scalar(guidance), name="eps_cfg")
             if ancestral:
                 sigma_down, sigma_up = sch.ancestral_sigmas(i)
                 E.euler_step(io.latents, eps, sigma, sigma_down)
@@ -268,17 +279,17 @@ class StableDiffusionControlNetPipeline:
     def _modules(self):
         return (self.vae, self.text_encoder, self.unet, self.controlnet)
 
-    def program(self, B, H, W, steps):
+    def program(self, B, H, W, steps, guidance: Optional[float] = None):
         # a recorded program bakes in the scheduler's tables and the packed weights' addresses: swapping pipe.scheduler /
         # pipe.controlnet / pipe.vae or re-packing a module (load_state_dict) must not replay the stale program
         sch = self.scheduler
         key = (B, H, W, steps, id(sch), type(sch).__name__, getattr(sch.config, "timestep_spacing", None),
-               tuple((id(m), m._pack_gen) for m in self._modules()))
+               tuple((id(m), m._pack_gen) for m in self._modules()), guidance)
         if key not in self._progs:
-            self._progs = {k: v for k, v in self._progs.items() if k[4:] == key[4:]}  # drop programs of replaced modules
+            self._progs = {k: v for k, v in self._progs.items() if k[4:8] == key[4:8]}  # drop programs of replaced modules
             if self.unet.W is None:
                 raise GenimaHipError("pipeline is not on a ROCm device: call pipe.to('cuda') first (no CPU fallback)")
-            self._progs[key] = self._build(B, H, W, steps)
+            self._progs[key] = self._build(B, H, W, steps, guidance)
         return self._progs[key]
 
     # ---- the call ------------------------------------------------------------------------------------------------------
@@ -303,16 +314,23 @@ class StableDiffusionControlNetPipeline:
     def __call__(self, prompt=None, image=None, negative_prompt=None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
                  generator=None, latents: Optional[torch.Tensor] = None, output_type: str = "pil", prompt_ids=None,
                  height=None, width=None, return_dict: bool = True, **kw):
-        if guidance_scale > 1.0:
-            raise NotImplementedError("classifier-free guidance (guidance_scale > 1) is not on the Genima hot path "
-                                      "(the reference always runs guidance_scale=0.0; SURVEY.md Appendix D.1)")
+        guidance = float(guidance_scale) if guidance_scale > 1.0 else None  # diffusers: do_classifier_free_guidance = guidance_scale > 1
+        if guidance and type(self)._emit_prompt is not StableDiffusionControlNetPipeline._emit_prompt:
+            raise NotImplementedError("classifier-free guidance (guidance_scale > 1) is built for the SD-2.x pipeline only; the SDXL-Turbo "
+                                      "agent of the reference runs guidance_scale=0.0 (SURVEY.md Appendix D.1)")
         if prompt_ids is None:
             prompt_ids = self.encode_ids(prompt)
         B = prompt_ids.shape[0]
         img_u8 = self._images_to_u8(image, B)
         assert img_u8.shape[0] == B, "one control image per prompt"
         H, W = int(img_u8.shape[1]), int(img_u8.shape[2])
-        io = self.program(B, H, W, num_inference_steps)
+        if guidance:  # rows [0, B): negative prompts ("" by default, as diffusers), rows [B, 2B): the prompts
+            neg = "" if negative_prompt is None else negative_prompt
+            neg_ids = self.encode_ids([neg] * B if isinstance(neg, str) else list(neg))
+            assert neg_ids.shape == prompt_ids.shape, "one negative prompt per prompt"
+            prompt_ids = torch.cat([neg_ids, prompt_ids], dim=0)
+            img_u8 = torch.cat([img_u8, img_u8], dim=0)
+        io = self.program(B, H, W, num_inference_steps, guidance)
         E: Engine = io.engine
         s = self.vae_scale_factor
         C = self.unet.config["in_channels"]

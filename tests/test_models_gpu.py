@@ -139,13 +139,15 @@ def test_vae_stream_scaling_is_exact_and_survives_an_out_of_range_stream():
     assert e <= 5e-3, e
 
 
-def _oracle_pipeline(pipe, ids, img_u8, latents, steps, q):
-    """Appendix D loop on the CPU oracle with the same weights."""
+def _oracle_pipeline(pipe, ids, img_u8, latents, steps, q, guidance=None, neg_ids=None):
+    """Appendix D loop on the CPU oracle with the same weights.  guidance: diffusers' classifier-free guidance -- both networks on the
+    negative and on the positive prompt, noise_pred = uncond + guidance * (text - uncond)."""
     from oracle import scheduler as OS
 
     sd_t, sd_c, sd_u, sd_v = (m.state_dict() for m in (pipe.text_encoder, pipe.controlnet, pipe.unet, pipe.vae))
     ts, sig, init = OS.euler_set_timesteps(configs.SD_TURBO_SCHEDULER, steps)
     ctx = O.clip_text_forward(sd_t, pipe.text_encoder.config, ids, q)
+    nctx = O.clip_text_forward(sd_t, pipe.text_encoder.config, neg_ids, q) if guidance else None
     cond = q(img_u8.permute(0, 3, 1, 2).float() / 255.0)
     x = q(latents * init)
     for i in range(steps):
@@ -153,9 +155,44 @@ def _oracle_pipeline(pipe, ids, img_u8, latents, steps, q):
         t = torch.full((x.shape[0],), float(ts[i]))
         down, mid = O.controlnet_forward(sd_c, pipe.controlnet.config, xs, t, ctx, cond, q=q)
         eps = O.unet_forward(sd_u, pipe.unet.config, xs, t, ctx, down, mid, q=q)
+        if guidance:
+            down, mid = O.controlnet_forward(sd_c, pipe.controlnet.config, xs, t, nctx, cond, q=q)
+            eps_u = O.unet_forward(sd_u, pipe.unet.config, xs, t, nctx, down, mid, q=q)
+            eps = q(eps_u + guidance * (eps - eps_u))
         x = q(torch.from_numpy(OS.euler_step(eps.numpy(), float(sig[i]), float(sig[i + 1]), x.numpy())))
     img = O.vae_decode(sd_v, pipe.vae.config, q(x / pipe.vae.config["scaling_factor"]), q)
     return x, img
+
+
+def test_pipeline_classifier_free_guidance():
+    """guidance_scale > 1 (diffusers' do_classifier_free_guidance; the reference's configs run 0.0): negative | positive prompt rows through
+    the ControlNet and the UNet, eps = uncond + g (text - uncond), against the oracle loop; guidance 0.0 afterwards still replays the
+    single-batch program."""
+    from genima_amd.pipeline import StableDiffusionControlNetPipeline
+
+    pipe = StableDiffusionControlNetPipeline.from_synthetic(FAM, seed=21)
+    for m in (pipe.vae, pipe.text_encoder, pipe.unet, pipe.controlnet):
+        m.load_state_dict(_r16(m.state_dict()))
+    cn = pipe.controlnet.state_dict()  # the synthetic ControlNet's zero convs are zero: give the residuals something to say
+    for k in cn:
+        if k.startswith(("controlnet_down_blocks", "controlnet_mid_block")) and k.endswith("weight"):
+            cn[k] = q16(torch.randn(cn[k].shape, generator=torch.Generator().manual_seed(len(k))) * 0.05)
+    pipe.controlnet.load_state_dict(cn)
+    pipe.to("cuda")
+    B, steps, g_scale = 2, 3, 3.0
+    img_u8 = torch.from_numpy(weights.counter_bytes(3, "ctrl", B * 128 * 128 * 3).reshape(B, 128, 128, 3))
+    prompts, negs = ["tiled perspectives of a robot arm executing 'open the box'"] * B, ["blurry"] * B
+    ids, nids = pipe.encode_ids(prompts), pipe.encode_ids(negs)
+    lat = q16(torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(4)))
+    out = pipe(prompt=prompts, negative_prompt="blurry", image=img_u8, num_inference_steps=steps, guidance_scale=g_scale, latents=lat.half(), output_type="latent")
+    with torch.no_grad():
+        x16, _ = _oracle_pipeline(pipe, ids, img_u8, lat, steps, q16, guidance=g_scale, neg_ids=nids)
+        x32, _ = _oracle_pipeline(pipe, ids, img_u8, lat, steps, lambda t: t, guidance=g_scale, neg_ids=nids)
+        x_plain, _ = _oracle_pipeline(pipe, ids, img_u8, lat, steps, lambda t: t)
+    _report("pipeline latents, guidance 3", out.images.float().cpu(), x16, x32, 6e-3, 3e-2)
+    assert rel_l2(x32, x_plain) > 5e-2, "the guided and the unguided trajectories should differ for this test to mean anything"
+    out0 = pipe(prompt=prompts, image=img_u8, num_inference_steps=steps, guidance_scale=0.0, latents=lat.half(), output_type="latent")
+    assert rel_l2(out0.images.float().cpu(), x_plain) < 6e-3
 
 
 @pytest.mark.parametrize("graph", [False, True])
