@@ -225,9 +225,14 @@ def main():
     ap.add_argument("--dump-ops", default=None, help="write the per-(kernel, shape) HIP-event timing table of one call to this CSV")
     args = ap.parse_args()
 
+    from genima_amd.dist import maybe_self_launch
+
+    maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)  # --gpus N > 1 without a launcher: become the launcher
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available() or local >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} of {world} needs ROCm device {local}, {torch.cuda.device_count()} visible")
     if world > 1:
         import torch.distributed as dist
 

@@ -149,7 +149,11 @@ def run(args, quiet: bool = False):
 
 
 def main():
-    line = run(parse_args())
+    args = parse_args()
+    from genima_amd.dist import maybe_self_launch
+
+    maybe_self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)  # --gpus N > 1 without a launcher: become the launcher
+    line = run(args)
     if line is not None:
         print(json.dumps(line))
 

@@ -26,6 +26,36 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     return rank, local, world
 
 
+def self_launch_command(script: str, argv, n_ranks: int, port: int = None):
+    """The command line that runs ``script argv`` as ``n_ranks`` processes of one node, one per GPU -- exactly what the driver's
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P`` wrapper does (the
+    role of ``accelerate launch`` in front of diffusion/train_controlnet_genima.py:1216-1218)."""
+    import socket
+    import sys
+
+    if port is None:
+        with socket.socket() as s:  # a free port on the loopback (the container hostname may not resolve)
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_ranks}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
+def maybe_self_launch(script: str, argv, n_ranks: int) -> None:
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it (WORLD_SIZE unset): re-run the same command under
+    torch.distributed.run and exit with its status; rank 0 of the children prints the single JSON line.  Returns when the process is
+    already one of the ranks (or N == 1)."""
+    import subprocess
+    import sys
+
+    if n_ranks <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    cmd = self_launch_command(script, argv, n_ranks)
+    print(f"[genima_amd.dist] launching {n_ranks} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    sys.exit(subprocess.run(cmd, env=env).returncode)
+
+
 def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, balanced, exhaustive partition of ``n_items`` episodes over ``world`` ranks."""
     base, rem = divmod(n_items, world)

@@ -74,3 +74,106 @@ def test_two_rank_gloo():
     assert res[0][2] == res[1][2] == 2.0
     expect = (torch.arange(11, dtype=torch.float32) * 1.5).tolist()
     assert res[0][3] == expect and res[1][3] == expect
+
+
+class _FakeWork:
+    def __init__(self, log, tag):
+        self.log, self.tag = log, tag
+
+    def wait(self):
+        self.log.append(("wait",) + self.tag)
+
+
+def _worker_rccl_order(rank, world, port, q):
+    """The async branch the RCCL backend takes (`reduce_scatter_tensor` + `all_gather_into_tensor` with async_op=True, waited in
+    finish()), driven at world size 2: the collectives are gloo-backed shims behind torch.distributed's names, so the ISSUE ORDER and
+    the arithmetic of dist.GradBuckets' nccl path are executed for real with two ranks (no 2-GPU box is available to the builder)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    gd.init_from_env("gloo")
+    log = []
+    real_reduce, real_all_gather, real_all_reduce = dist.reduce, dist.all_gather, dist.all_reduce
+
+    def reduce_scatter_tensor(out, inp, op=None, async_op=False):
+        chunks = inp.view(world, -1).clone()
+        for r in range(world):
+            real_reduce(chunks[r], dst=r, op=dist.ReduceOp.SUM)
+        out.copy_(chunks[rank])
+        log.append(("rs", inp.data_ptr(), inp.numel(), async_op))
+        return _FakeWork(log, ("rs", inp.data_ptr()))
+
+    def all_gather_into_tensor(out, inp, async_op=False):
+        parts = [torch.empty_like(inp) for _ in range(world)]
+        real_all_gather(parts, inp.clone())
+        out.copy_(torch.cat(parts))
+        log.append(("ag", out.data_ptr(), out.numel(), async_op))
+        return _FakeWork(log, ("ag", out.data_ptr()))
+
+    def all_reduce(t, op=None, async_op=False):
+        real_all_reduce(t, op=dist.ReduceOp.SUM)
+        log.append(("ar", t.data_ptr(), t.numel(), async_op))
+        return _FakeWork(log, ("ar", t.data_ptr()))
+
+    gd.dist.reduce_scatter_tensor, gd.dist.all_gather_into_tensor, gd.dist.all_reduce = reduce_scatter_tensor, all_gather_into_tensor, all_reduce
+    gd.dist.get_backend = lambda *a, **k: "nccl"
+    layout = {f"p{i}": (100 * i, (100,)) for i in range(10)}
+    first_use = {f"p{i}": i for i in range(10)}
+    base = torch.arange(1003, dtype=torch.float32)  # 1003: the last bucket keeps an odd tail -> the small all-reduce
+    layout["tail"] = (1000, (3,))
+    first_use["tail"] = 9
+    grad = base * (rank + 1)
+    bk = gd.GradBuckets(n_buckets=4, align=8)
+    bk.begin(grad, layout, first_use, 10)
+    for i in range(10, -1, -1):
+        bk.entry_done(i)
+    issued = [e for e in log if e[0] != "wait"]
+    assert not any(e[0] == "wait" for e in log), "no collective may be waited on inside the backward walk"
+    assert all(e[3] for e in issued), "the RCCL path must issue asynchronously"
+    # buckets fire from the end of the buffer to its front; inside a bucket: reduce-scatter, all-gather, (tail all-reduce)
+    kinds = [e[0] for e in issued]
+    assert kinds[:3] == ["rs", "ag", "ar"] and kinds[3:] == ["rs", "ag"] * (len(bk.ranges) - 1), kinds
+    starts = [e[1] for e in issued if e[0] == "rs"]
+    assert starts == sorted(starts, reverse=True)
+    n_works = len(bk.works)
+    assert bk.finish() == world
+    assert sum(1 for e in log if e[0] == "wait") == n_works == len(issued)
+    assert torch.equal(grad, base * 3)
+    q.put(rank)
+    real_all_reduce(torch.zeros(1))
+    dist.destroy_process_group()
+
+
+def test_two_rank_async_bucket_issue_order():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_rccl_order, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert sorted(q.get(timeout=120) for _ in range(2)) == [0, 1]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with no launcher around it re-runs itself under torch.distributed.run: both
+    ranks start (and, without GPUs here, each stops at its device check -- not at the old WORLD_SIZE assertion)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HIP_VISIBLE_DEVICES"] = env["CUDA_VISIBLE_DEVICES"] = ""  # same outcome on a GPU box: the ranks find no device
+    for script in ("bench.py", "bench_train.py"):
+        r = subprocess.run([sys.executable, os.path.join(root, script), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert "launching 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr, r.stderr[-2000:]
+        assert "AssertionError: --gpus" not in r.stderr
+        if script == "bench.py":
+            assert "rank 0 of 2 needs ROCm device 0" in r.stderr and "rank 1 of 2 needs ROCm device 1" in r.stderr, r.stderr[-2000:]
+        assert r.returncode != 0
+    cmd = gd.self_launch_command("bench.py", ["--gpus", "4"], 4, port=1234)
+    assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "1234"]
+    assert cmd[9:] == ["bench.py", "--gpus", "4"]
