@@ -270,31 +270,109 @@ _ROBOBASE_ALIASES = {  # [VERIFY] names: the MT-ACT lineage calls the token proj
     "proj_text_emb.weight": "task_proj.weight", "proj_text_emb.bias": "task_proj.bias",
     "task_emb_proj.weight": "task_proj.weight", "task_emb_proj.bias": "task_proj.bias",
 }
+_CVAE_PREFIXES = ("encoder.layers.", "cls_embed.", "encoder_action_proj.", "encoder_joint_proj.", "latent_proj.")  # training-only weights
 
 
 def robobase_key_map(key: str) -> Optional[str]:
-    """RoboBase ``latest.pt`` ``ckpt["agent"]`` key -> this module's key (None: not a weight of the inference forward, e.g. the CVAE
-    posterior encoder ``actor.actor_model.encoder.*`` / ``cls_embed`` / ``latent_proj``, optimizer-free buffers, duplicates)."""
+    """RoboBase ``latest.pt`` ``ckpt["agent"]`` key -> this module's key (None: not a weight this package holds -- the ResNet's unused
+    ``fc``, ``num_batches_tracked`` counters).  The CVAE posterior encoder (``actor.actor_model.encoder.layers.*`` / ``cls_embed`` /
+    ``encoder_*_proj`` / ``latent_proj``) maps onto the training schema's names (act_training.act_train_schema)."""
     for src, dst in _ROBOBASE_PREFIXES:
         if key.startswith(src):
             k = dst + key[len(src):]
             k = _ROBOBASE_ALIASES.get(k, k)
-            if k.startswith("encoder.layers.") or k.startswith("backbone.fc.") or k.endswith("num_batches_tracked"):
-                return None  # "encoder.layers" under actor_model = the CVAE style encoder (training only)
+            if k.startswith("backbone.fc.") or k.endswith("num_batches_tracked"):
+                return None
+            if k.startswith("encoder.layers.") and (src == "encoder." or src == "actor.encoder_model."):
+                return None  # the image encoder has no ``layers``: only ``actor_model.encoder`` is the CVAE style encoder
             return k
     return _ROBOBASE_ALIASES.get(key, key)
+
+
+def robobase_key_names(key: str, aliases: Optional[Dict[str, str]] = None):
+    """This module's key -> EVERY path RoboBase's ``agent.state_dict()`` lists it under (the inverse of ``robobase_key_map``):
+    ``GenimaACT`` registers ``self.encoder``, ``self.actor_model`` and ``self.actor`` (= GenimaACTPolicy holding both again as
+    ``.encoder_model`` / ``.actor_model``; controller/method/genima_act.py:221-249), and ``nn.Module.state_dict()`` does not dedupe
+    shared submodules -- the reference's gate (controller/eval_genima.py:94-100) walks all of them.  ``aliases`` renames leaf modules
+    (own name -> checkpoint name, e.g. ``{"task_proj": "proj_text_emb"}``) for the [VERIFY] items of SURVEY.md Appendix E."""
+    if aliases:
+        head = key.split(".")[0]
+        if head in aliases:
+            key = aliases[head] + key[len(head):]
+    if key.startswith("backbone."):
+        body = "backbone.0.body." + key[len("backbone."):]
+        return ["encoder." + body, "actor.encoder_model." + body]
+    if key.startswith("input_proj."):
+        return ["encoder." + key, "actor.encoder_model." + key]
+    if key.startswith("projection_layer."):
+        return ["actor." + key]
+    return ["actor_model." + key, "actor.actor_model." + key]
+
+
+_HF2OPENAI_CLIP = (("text_model.embeddings.token_embedding.weight", "token_embedding.weight"),
+                   ("text_model.embeddings.position_embedding.weight", "positional_embedding"),
+                   ("text_model.final_layer_norm.", "ln_final."), ("text_projection.weight", "text_projection"))
+
+
+def clip_hf_to_openai(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    """transformers ``CLIPTextModelWithProjection`` names -> the openai ``clip`` package's (``clip.load("ViT-B/32")`` with ``.visual``
+    deleted: controller/method/genima_act.py:314-346): q|k|v re-fused into ``attn.in_proj_*``, ``text_projection`` stored [width, proj]."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    layers = sorted({int(m.group(1)) for k in sd for m in [re.match(r"text_model\.encoder\.layers\.(\d+)\.", k)] if m})
+    for src, dst in _HF2OPENAI_CLIP:
+        for k, v in sd.items():
+            if k == src:
+                out[dst] = v.t().contiguous() if dst == "text_projection" else v
+            elif src.endswith(".") and k.startswith(src):
+                out[dst + k[len(src):]] = v
+    for i in layers:
+        p, q = f"text_model.encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        for wb in ("weight", "bias"):
+            out[q + "attn.in_proj_" + wb] = torch.cat([sd[p + f"self_attn.{n}_proj.{wb}"] for n in "qkv"], dim=0)
+            out[q + "attn.out_proj." + wb] = sd[p + "self_attn.out_proj." + wb]
+            out[q + "ln_1." + wb], out[q + "ln_2." + wb] = sd[p + "layer_norm1." + wb], sd[p + "layer_norm2." + wb]
+            out[q + "mlp.c_fc." + wb], out[q + "mlp.c_proj." + wb] = sd[p + "mlp.fc1." + wb], sd[p + "mlp.fc2." + wb]
+    return out
+
+
+def clip_openai_to_hf(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    """The inverse: an openai ``clip`` text-side state dict (keys optionally prefixed ``clip_model.``) -> transformers names."""
+    sd = {(k[len("clip_model."):] if k.startswith("clip_model.") else k): v for k, v in sd.items()}
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    out["text_model.embeddings.token_embedding.weight"] = sd["token_embedding.weight"]
+    out["text_model.embeddings.position_embedding.weight"] = sd["positional_embedding"]
+    i = 0
+    while f"transformer.resblocks.{i}.attn.in_proj_weight" in sd:
+        p, q = f"text_model.encoder.layers.{i}.", f"transformer.resblocks.{i}."
+        for wb in ("weight", "bias"):
+            for n, part in zip("qkv", sd[q + "attn.in_proj_" + wb].chunk(3, dim=0)):
+                out[p + f"self_attn.{n}_proj.{wb}"] = part.contiguous()
+            out[p + "self_attn.out_proj." + wb] = sd[q + "attn.out_proj." + wb]
+            out[p + "layer_norm1." + wb], out[p + "layer_norm2." + wb] = sd[q + "ln_1." + wb], sd[q + "ln_2." + wb]
+            out[p + "mlp.fc1." + wb], out[p + "mlp.fc2." + wb] = sd[q + "mlp.c_fc." + wb], sd[q + "mlp.c_proj." + wb]
+        i += 1
+    out["text_model.final_layer_norm.weight"], out["text_model.final_layer_norm.bias"] = sd["ln_final.weight"], sd["ln_final.bias"]
+    out["text_projection.weight"] = sd["text_projection"].t().contiguous()
+    return out
 
 
 class GenimaACT:
     """Controller plugin (``method._target_: method.genima_act.GenimaACT``, controller/cfgs/method/genima_act.yaml:3-4)."""
 
     def __init__(self, config: Optional[dict] = None, state_dict=None, clip_config: Optional[dict] = None, clip_state_dict=None,
-                 device="cuda", seed: int = 0, **hydra_kwargs):
+                 device="cuda", seed: int = 0, key_aliases: Optional[Dict[str, str]] = None, **hydra_kwargs):
+        self.key_aliases = dict(key_aliases or {})  # own leaf-module name -> checkpoint name ([VERIFY] items; settable from the method YAML)
+        self._sd_train: "OrderedDict[str, torch.Tensor]" = OrderedDict()  # CVAE posterior encoder (training only), once loaded / trained
+        self._clip_used = False
         self.config = FrozenConfig(dict(config or configs.ACT_POLICY))
         self.clip_config = FrozenConfig(dict(clip_config or configs.ACT_CLIP_TEXT))
         self._schema = act_schema(self.config)
         self._sd = OrderedDict((k, v.float()) for k, v in (state_dict or weights.synth_state_dict(self._schema, seed + 31)).items())
         self._clip_sd = clip_state_dict or weights.synth_state_dict(schema.clip_text_schema(self.clip_config), seed + 32)
+        from .act_training import act_train_schema  # the CVAE posterior encoder is a registered module of the reference's agent too
+
+        cvae = OrderedDict((k, v) for k, v in act_train_schema(self.config).items() if k not in self._schema)
+        self._sd_train = OrderedDict((k, v.float()) for k, v in weights.synth_state_dict(cvae, seed + 33).items())
         self.device = torch.device(device)
         self.training = False
         self.W = self.Wclip = None
@@ -317,16 +395,45 @@ class GenimaACT:
         self.training = mode
         return self
 
+    def _own_state(self) -> "OrderedDict[str, torch.Tensor]":
+        """Forward weights (+ the CVAE posterior encoder once ``update`` ran or a checkpoint carried it), pulled lazily from the trainer."""
+        tr = getattr(self, "_trainer", None)
+        if tr is not None and getattr(self, "_stale_host", False):
+            for k, v in tr.state_dict().items():
+                (self._sd if k in self._sd else self._sd_train)[k] = v.detach().float().cpu()
+            self._stale_host = False
+        own = OrderedDict(self._sd)
+        own.update(self._sd_train)
+        return own
+
     def state_dict(self):
-        return OrderedDict(("actor." + k, v) for k, v in self._sd.items())
+        """RoboBase's ``agent.state_dict()`` key set: every weight under each of its registrations (``encoder.*`` /
+        ``actor.encoder_model.*``, ``actor_model.*`` / ``actor.actor_model.*``, ``actor.projection_layer.*``), so the reference's
+        unchanged gate (controller/eval_genima.py:94-100: every non-clip key must be in ``ckpt["agent"]``) and ``save_snapshot``
+        (controller/train_act.py:262-279) see the names a RoboBase checkpoint holds.  ``clip_model.*`` (openai names) appears once the
+        text tower has been used, as in the reference (lazy ``clip.load`` on the first ``encode_clip_text``, genima_act.py:315-321)."""
+        out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        for k, v in self._own_state().items():
+            for name in robobase_key_names(k, self.key_aliases):
+                out[name] = v
+        if self._clip_used:
+            for k, v in clip_hf_to_openai(self._clip_sd).items():
+                out["clip_model." + k] = v
+        return out
 
     def load_state_dict(self, sd, strict: bool = False):
         """``agent.load_state_dict(ckpt["agent"], strict=False)`` (controller/eval_genima.py:91-103): RoboBase key families are mapped
         by ``robobase_key_map``; with ``strict=False`` unknown keys are reported, not fatal -- but a checkpoint that fills NONE of the
         forward's weights is an error (a silently random-initialised controller would act plausibly and wrongly)."""
+        inv = {v: k for k, v in self.key_aliases.items()}
         new = {}
         for k, v in sd.items():
+            if k.startswith("clip_model."):
+                continue
             m = robobase_key_map(k)
+            if m is not None and inv:
+                head = m.split(".")[0]
+                m = inv[head] + m[len(head):] if head in inv else m
             if m is not None and (m not in new or k.startswith("actor.")):  # duplicates carry the same tensor; prefer the actor.* path
                 new[m] = v
         missing = [k for k in self._schema if k not in new]
@@ -337,10 +444,24 @@ class GenimaACT:
         for k in self._schema:
             if k in new:
                 self._sd[k] = new[k].detach().float().cpu()
+        unexpected = []
+        for k, v in new.items():
+            if k in self._schema:
+                continue
+            if k.startswith(_CVAE_PREFIXES):
+                self._sd_train[k] = v.detach().float().cpu()
+            else:
+                unexpected.append(k)
+        clip_keys = {k: v for k, v in sd.items() if k.startswith("clip_model.")}
+        if clip_keys:  # a state dict taken after the first act() carries the text tower too (snapshots strip it)
+            self._clip_sd = OrderedDict((k, v.detach().float().cpu()) for k, v in clip_openai_to_hf(clip_keys).items())
+        self._trainer, self._stale_host = None, False  # a later update() starts from the loaded weights
         if self.W is not None:
             self.W = pack_act(self._sd, self.device)
+            if clip_keys:
+                self.Wclip = packing.pack_state_dict(self._clip_sd, self.device)
             self._progs = {}
-        return missing, [k for k in new if k not in self._schema]
+        return missing, unexpected
 
     # ---- recorded forward programs (one per input shape), replayed from C++ --------------------------------------------------
     def _program(self, B, V, H, Wd, lang: bool):
@@ -367,6 +488,7 @@ class GenimaACT:
     def _run(self, img_u8_nhwc, qpos, tokens):
         B, V, H, Wd, _ = img_u8_nhwc.shape
         lang = bool(self.config.get("use_lang_cond")) and tokens is not None
+        self._clip_used = self._clip_used or lang
         io = self._program(B, V, H, Wd, lang)
         io.img.copy_(img_u8_nhwc)
         io.qpos[:, : qpos.shape[1]].copy_(qpos.to(torch.float16))
@@ -380,6 +502,7 @@ class GenimaACT:
         """tokens int [B, fs, 77] -> (task_emb f32 [B, projection_dim], None) (controller/method/genima_act.py:314-346)."""
         if self.W is None:
             raise GenimaHipError("GenimaACT is not on a ROCm device")
+        self._clip_used = True
         E = Engine(self.device)
         tks = tokens.reshape(tokens.shape[0], -1, tokens.shape[-1])[:, 0].to(self.device, torch.int32).contiguous()
         x = graphs.emit_clip_text(E, self.Wclip, self.clip_config, tks)
@@ -404,9 +527,13 @@ class GenimaACT:
 
         if getattr(self, "_trainer", None) is None:
             sch = act_train_schema(self.config)
+            if int(self.config.get("frame_stack", 1)) > 1:
+                raise NotImplementedError("ACTTrainer does not apply projection_layer: frame_stack > 1 is inference-only here")
             sd = dict(self._sd)
-            extra = weights.synth_state_dict(OrderedDict((k, v) for k, v in sch.items() if k not in sd), 77)  # CVAE encoder: fresh init
-            sd.update(extra)
+            sd.update(self._sd_train)  # a checkpoint's CVAE posterior encoder, when one was loaded
+            fresh = OrderedDict((k, v) for k, v in sch.items() if k not in sd)
+            if fresh:
+                sd.update(weights.synth_state_dict(fresh, 77))  # CVAE encoder: fresh init
             self._trainer = ACTTrainer(Engine(self.device), self.config, sd, self.clip_config, self.Wclip, **trainer_kw)
             self._aug_gen = torch.Generator().manual_seed(0)
         batch = next(replay_iter)
@@ -425,14 +552,15 @@ class GenimaACT:
         metrics = tr.update(imgs, qpos, task, batch["action"].float())
         if "reward" in batch:
             metrics["batch_reward"] = float(batch["reward"].float().mean())
-        # the eval path reads the packed inference weights: refresh them from the trainer's masters
-        self._sd.update({k: v.cpu() for k, v in tr.state_dict().items() if k in self._sd})
-        self._dirty = True
+        # the eval path reads the packed inference weights and state_dict() the host copies: both are refreshed lazily (act() /
+        # _own_state()), not with a device sync + full-state D2H copy per training step
+        self._dirty = self._stale_host = True
         return metrics
 
     def act(self, obs: Dict[str, torch.Tensor], step: int = 0, eval_mode: bool = True) -> torch.Tensor:
         """obs: {'<cam>_rgb': uint8/float [B, fs, 3, H, W], 'low_dim_state': f32 [B, fs, state], 'lang_tokens': int [B, fs, 77]}."""
         if getattr(self, "_dirty", False):  # weights moved by update(): re-pack once before acting
+            self._own_state()
             self.W = pack_act(self._sd, self.device)
             self._progs, self._dirty = {}, False
         qpos = obs["low_dim_state"].to(self.device).flatten(1)

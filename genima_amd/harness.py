@@ -52,3 +52,27 @@ def control_step(diffusion_agent, controller_agent, obs: Dict[str, np.ndarray], 
         obs_dev = {k: torch.from_numpy(np.asarray(v)).to(device).unsqueeze(0) for k, v in obs.items()}
         actions = controller_agent.act(obs_dev, step=episode_step, eval_mode=True)[0]
     return actions.detach().float().cpu().numpy(), obs_dev, tiled_in, tiled_out
+
+
+def load_controller_ckpt(controller_agent, checkpoint_path, device="cpu"):
+    """``Workspace.load_controller_ckpt`` (controller/eval_genima.py:91-103), statement for statement: the gate that every non-clip key
+    of ``controller_agent.state_dict()`` is present in ``checkpoint["agent"]``, then ``load_state_dict(..., strict=False)``."""
+    checkpoint = torch.load(checkpoint_path, map_location=device, weights_only=False)
+    missing_keys = [k for k in controller_agent.state_dict().keys() if k not in checkpoint["agent"].keys() and "clip" not in k]
+    if len(missing_keys) > 0:
+        raise ValueError(f"Missing keys in controller checkpoint: {missing_keys}")
+    controller_agent.load_state_dict(checkpoint["agent"], strict=False)
+    return checkpoint
+
+
+def save_snapshot(controller_agent, path, cfg=None, epoch: int = 0, num_iters: int = 0):
+    """``ControllerWorkspace.save_snapshot`` (controller/train_act.py:262-279): ``{"cfg", "_epoch", "_num_iters", "agent"}`` with the
+    ``clip_model`` keys filtered out of the agent's state dict, written with ``torch.save``."""
+    import os
+
+    state_dict = {k: v for k, v in controller_agent.state_dict().items() if "clip_model" not in k}
+    payload = {"cfg": cfg, "_epoch": epoch, "_num_iters": num_iters, "agent": state_dict}
+    os.makedirs(os.path.dirname(os.path.abspath(str(path))), exist_ok=True)
+    with open(path, "wb") as f:
+        torch.save(payload, f)
+    return payload
