@@ -158,15 +158,22 @@ class DataLoader:
         self.rank, self.world, self.epoch = rank, world, 0
 
     def __len__(self):
-        n = len(range(self.rank, len(self.ds), self.world))
-        return (n + self.bs - 1) // self.bs
+        n_batches = (len(self.ds) + self.bs - 1) // self.bs
+        return (n_batches + self.world - 1) // self.world  # the same on every rank (a shorter rank would leave the others in a collective)
 
     def _batches(self) -> List[List[int]]:
         idx = list(range(len(self.ds)))
         if self.shuffle:
             random.Random(self.seed + self.epoch).shuffle(idx)
-        idx = idx[self.rank::self.world]  # data parallel: every rank sees a disjoint slice of the epoch's permutation
-        return [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
+        if self.world > 1 and idx:
+            # data parallel, as accelerate's prepared loader shards (BatchSamplerShard, even_batches=True): the epoch's permutation is
+            # cut into batches, batch k goes to rank k % world, and the tail is completed by wrapping round to the start of the
+            # permutation so that every rank runs the same number of full batches
+            unit = self.bs * self.world
+            total = (len(idx) + unit - 1) // unit * unit
+            idx = (idx * (total // len(idx) + 1))[:total]
+        batches = [idx[i:i + self.bs] for i in range(0, len(idx), self.bs)]
+        return batches[self.rank::self.world]
 
     def __iter__(self) -> Iterator[Dict[str, torch.Tensor]]:
         batches = self._batches()

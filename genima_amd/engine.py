@@ -242,7 +242,7 @@ class Engine:
         # split (made for the 2-3-workgroups-per-CU tiles) can leave the one-workgroup-per-CU ping-pong tile a 1.6-round grid that loses
         # the tile race although 256 x 256 with the right split wins (conv 1280 -> 1280 @ 16 x 16: tile 9 92 us, tile 15 / 5 slices 78) --
         # for tile 15 as well wherever its output grid is smaller than the chip.  3 % margin against noise.
-        if d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8 and not d.out2:
+        if d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8 and not d.out2 and not d.ln_c1:  # gn_gemm pins sk = 1 under ln_c1
             tiles = [best % 100]
             pp_blocks = -(-d.M // 256) * -(-d.N // 256)
             if 15 in cands and 15 not in tiles and d.K >= 2048 and d.K % 64 == 0 and pp_blocks < 128:

@@ -140,7 +140,9 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     n = E.layernorm(h, W[b + ".norm1.weight"], W[b + ".norm1.bias"], name="ln1")
                     if vrow:
                         qkv = E.linear(n, W[b + ".attn1.to_qkv.weight"], name="qkv")
-                    elif b + ".attn1.to_qkv.weight" in W:  # q | k | v in one two-destination launch (q, k row-major + V^T)
+                    elif b + ".attn1.to_qkv.weight" in W and not (E._fp8_weights and b + ".attn1.to_qk.weight" in W):
+                        # q | k | v in one two-destination launch (q, k row-major + V^T); with Linears routed to the fp8 MFMA the
+                        # registered copies are to_qk / to_v (the two-destination epilogue has no fp8 form)
                         qk, vt = E.linear(n, W[b + ".attn1.to_qkv.weight"], split_n=2 * Cc, rows_per_batch=N, pad_cols=_rup(N, 64), name="qk")
                     else:
                         qk = E.linear(n, W[b + ".attn1.to_qk.weight"], name="qk")

@@ -30,12 +30,14 @@ def get_scheduler(name: str, num_warmup_steps: int = 0, num_training_steps: Opti
         raise ValueError(f"lr scheduler {name!r} needs num_training_steps")
     if name == "linear":
         return lambda step: warm(step) if step < w else max(0.0, float(T - step) / float(max(1, T - w)))
-    if name == "cosine":  # get_cosine_schedule_with_warmup(num_cycles): the reference hands --lr_num_cycles (1) straight through
+    if name == "cosine":
+        # diffusers' get_scheduler forwards num_cycles only to COSINE_WITH_RESTARTS (and power only to POLYNOMIAL): plain "cosine" runs
+        # get_cosine_schedule_with_warmup with ITS default num_cycles = 0.5 -- half a cosine, down to 0 -- whatever --lr_num_cycles says
         def f(step):
             if step < w:
                 return warm(step)
             prog = float(step - w) / float(max(1, T - w))
-            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * prog)))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * prog)))
         return f
     if name == "cosine_with_restarts":
         def f(step):
@@ -124,9 +126,20 @@ class TrainLoop:
             tr.load_state(os.path.join(self.output_dir, path))
             self.global_step = int(path.split("-")[1])
             first_epoch = self.global_step // per_epoch
+        if self.global_step >= max_steps:  # a resumed run that is already complete trains nothing more
+            return self.global_step
         for _epoch in range(first_epoch, epochs):
-            for batch in dataloader:
-                loss = tr.train_step(batch)
+            it = iter(dataloader)
+            nxt = next(it, None)
+            while nxt is not None:
+                batch, nxt = nxt, next(it, None)
+                # the last batch of an epoch syncs whatever the micro-batch count (accelerate: end_of_dataloader forces sync_gradients),
+                # so an epoch makes ceil(n / accum) optimizer steps -- the ``per_epoch`` above -- and leaves nothing accumulated
+                tr.end_of_dataloader = nxt is None
+                try:
+                    loss = tr.train_step(batch)
+                finally:
+                    tr.end_of_dataloader = False
                 if tr.sync_gradients:
                     self.global_step += 1
                     if self.is_main and self.global_step % self.checkpointing_steps == 0:

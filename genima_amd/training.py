@@ -643,6 +643,9 @@ class ControlNetTrainer:
         self.grad_accum, self._micro = max(1, int(gradient_accumulation_steps)), 0
         self.lr_lambda, self.sched_step = lr_lambda, 0
         self.sync_gradients = True  # accelerator.sync_gradients: did the last step() call apply an optimizer step?
+        # accelerate's GradientState.end_of_dataloader: the loop sets it before the LAST batch of an epoch and the step then syncs
+        # whatever the micro-batch count is (accelerator._do_sync), so no accumulated gradient leaks into the next epoch
+        self.end_of_dataloader = False
         # data parallel: ``allreduce`` is either a callable(flat f32 grad buffer) that SUMS it over ranks in place and returns the
         # number of ranks (dist.allreduce_sum_flat: one exchange after the backward), or a dist.GradBuckets that launches the exchange
         # of each bucket of the flat buffer as soon as the backward walk has finished the last gradient in it (overlap with the rest)
@@ -677,7 +680,7 @@ class ControlNetTrainer:
         loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale / self.grad_accum)
         pred.cell[0] = dpred
         buckets = self.allreduce if hasattr(self.allreduce, "begin") else None
-        if buckets is not None and (self._micro + 1) % self.grad_accum == 0:  # exchange only the LAST micro-batch's (accumulated) gradient
+        if buckets is not None and self._will_sync():  # exchange only the LAST micro-batch's (accumulated) gradient
             buckets.begin(self.cn.grad, self.cn.layout, g.first_use, len(g.tape))
             g.on_entry_done = buckets.entry_done
         g.backward()
@@ -717,10 +720,13 @@ class ControlNetTrainer:
             self._clean = 0
         return True
 
+    def _will_sync(self) -> bool:
+        return (self._micro + 1) % self.grad_accum == 0 or self.end_of_dataloader
+
     def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=None) -> torch.Tensor:
         loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
-        self._micro += 1
-        self.sync_gradients = self._micro % self.grad_accum == 0
+        self.sync_gradients = self._will_sync()
+        self._micro = 0 if self.end_of_dataloader else self._micro + 1  # accelerate restarts its micro-step count with the dataloader
         if self.sync_gradients:  # gradients of the micro-batches accumulate in the flat buffer until here
             self.optimizer_step()
             self.update_scale()

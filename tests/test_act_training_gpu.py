@@ -117,3 +117,15 @@ def test_agent_update_surface_and_augmentations():
     assert out.shape == (1, 2, 64, 64, 8) and out.dtype == torch.float16 and float(out[..., 3:].abs().max()) == 0.0
     clean = act_augment(E, img, torch.Generator().manual_seed(5), p=0.0, noise_std=0.0)
     assert torch.equal(clean[..., :3].float().cpu(), (img.float() / 255.0).half().float().cpu())
+    # the checkpoint seam after training (controller/train_act.py:262-279 -> controller/eval_genima.py:91-103): the snapshot carries the
+    # trained weights under RoboBase's key paths and a fresh agent that passes the reference's gate acts identically
+    import tempfile
+
+    from genima_amd.harness import load_controller_ckpt, save_snapshot
+
+    with tempfile.TemporaryDirectory() as td:
+        payload = save_snapshot(agent, td + "/snapshots/exp/latest.pt", cfg={}, epoch=3, num_iters=3)
+        assert not any("clip_model" in k for k in payload["agent"]) and "actor.actor_model.encoder.layers.0.linear1.weight" in payload["agent"]
+        fresh = GenimaACT(cfg, None, ccfg, agent._clip_sd, device="cuda", seed=123)
+        load_controller_ckpt(fresh, td + "/snapshots/exp/latest.pt")
+    assert torch.equal(fresh.act(obs).cpu(), after)

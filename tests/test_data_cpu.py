@@ -81,6 +81,14 @@ def test_loader_epochs_shards_and_prefetch(tmp_path):
     flat = lambda bs: [i for b in bs for i in b]  # noqa: E731
     assert sorted(flat(b0) + flat(b1)) == list(range(24)) and not set(flat(b0)) & set(flat(b1))  # ranks see disjoint halves
     assert sorted(flat(a)) == list(range(24)) and flat(a) != list(range(24))
+    # ranks always run the same number of FULL batches (accelerate even_batches: the tail wraps round to the start of the permutation);
+    # a rank that ran out early would leave the others waiting in the gradient exchange
+    for n_items, world, bs in ((10, 4, 1), (24, 3, 5), (24, 2, 4), (7, 8, 2)):
+        loaders = [D.DataLoader(list(range(n_items)), bs, tok, 16, seed=1, rank=r, world=world) for r in range(world)]
+        per_rank = [ld._batches() for ld in loaders]
+        assert len({len(b) for b in per_rank}) == 1 and all(len(b) == len(ld) for b, ld in zip(per_rank, loaders))
+        assert all(len(x) == bs for b in per_rank for x in b)
+        assert set(flat([x for b in per_rank for x in b])) == set(range(n_items))
     x = [t["input_ids"].clone() for t in D.DataLoader(ds, 8, tok, 16, shuffle=False, prefetch=0)]
     y = [t["input_ids"].clone() for t in D.DataLoader(ds, 8, tok, 16, shuffle=False, prefetch=3)]
     assert all(torch.equal(p, q) for p, q in zip(x, y)) and len(x) == len(y) == 3

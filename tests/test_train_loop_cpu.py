@@ -27,7 +27,8 @@ def test_lr_schedules_match_transformers(name, kw):
     elif name == "linear":
         ref = TO.get_linear_schedule_with_warmup(opt, warm, total)
     elif name == "cosine":
-        ref = TO.get_cosine_schedule_with_warmup(opt, warm, total, num_cycles=kw["num_cycles"])
+        # diffusers' get_scheduler drops num_cycles for plain "cosine": the half cosine whatever --lr_num_cycles says
+        ref = TO.get_cosine_schedule_with_warmup(opt, warm, total)
     elif name == "cosine_with_restarts":
         ref = TO.get_cosine_with_hard_restarts_schedule_with_warmup(opt, warm, total, num_cycles=kw["num_cycles"])
     else:
@@ -60,10 +61,16 @@ class _FakeTrainer:
 
     def __init__(self, accum):
         self.grad_accum, self._micro, self.sync_gradients, self.steps, self.loaded = accum, 0, True, 0, None
+        self.end_of_dataloader, self.pending = False, 0
 
     def train_step(self, batch):
         self._micro += 1
-        self.sync_gradients = self._micro % self.grad_accum == 0
+        self.pending += 1
+        self.sync_gradients = self._micro % self.grad_accum == 0 or self.end_of_dataloader
+        if self.end_of_dataloader:
+            self._micro = 0
+        if self.sync_gradients:
+            self.pending = 0
         self.steps += int(self.sync_gradients)
         return float(batch)
 
@@ -95,3 +102,20 @@ def test_loop_accumulation_checkpoints_resume(tmp_path):
     tr3 = _FakeTrainer(1)
     loop3 = TrainLoop(tr3, str(tmp_path / "fresh"), max_train_steps=3, resume_from_checkpoint="latest", log=logs.append)
     assert loop3.run(data) == 3 and tr3.loaded is None and any("does not exist" in m for m in logs)
+
+
+def test_cosine_default_is_the_half_cosine():
+    """``--lr_scheduler cosine`` with the default ``--lr_num_cycles 1``: half a cosine to 0 at the end, not a full cycle back to peak."""
+    f = get_scheduler("cosine", 0, 100)  # num_cycles left at its default (1), as the reference passes it
+    assert abs(f(50) - 0.5) < 1e-12 and f(100) < 1e-12 and abs(f(25) - 0.5 * (1 + math.cos(math.pi * 0.25))) < 1e-12
+
+
+def test_epoch_end_flushes_partial_accumulation(tmp_path):
+    """7 micro-batches, accumulation 3: accelerate syncs at the end of the dataloader, so an epoch is ceil(7/3) = 3 optimizer steps and
+    nothing is carried into the next epoch; a resumed run that is already complete trains nothing."""
+    tr = _FakeTrainer(3)
+    loop = TrainLoop(tr, str(tmp_path), num_train_epochs=2, checkpointing_steps=6, log=lambda m: None)
+    assert loop.run(list(range(7))) == 6 and tr.steps == 6 and tr.pending == 0 and tr._micro == 0
+    tr2 = _FakeTrainer(3)
+    loop2 = TrainLoop(tr2, str(tmp_path), max_train_steps=6, resume_from_checkpoint="latest", log=lambda m: None)
+    assert loop2.run(list(range(7))) == 6 and tr2.steps == 0 and tr2.loaded.endswith("checkpoint-6")
