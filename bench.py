@@ -48,7 +48,20 @@ WORKLOADS = {
 GFLOP_PER_CALL = {512: 8000.0, 256: 1888.0}
 
 
-PMC_TRAFFIC_FILE = "r02_v6_pmc_traffic_tiled_b8.json"
+def _pmc_traffic_file():
+    """The newest committed PMC traffic summary (profiles/rNN_vM_pmc_traffic_tiled_b8.json; tools/probes/pmc_traffic.sh writes them and
+    stamps the commit + the library hash they were collected on)."""
+    import glob
+    import re
+
+    def key(p):
+        m = re.search(r"r(\d+)_v(\d+)_pmc_traffic_tiled_b8", p)
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_tiled_b8.json")), key=key)
+    return os.path.basename(files[-1]) if files else "none"
+
+
+PMC_TRAFFIC_FILE = _pmc_traffic_file()
 
 
 def pmc_traffic_per_launch(family: str):
@@ -61,6 +74,20 @@ def pmc_traffic_per_launch(family: str):
         fe, wr = d["FETCH_SIZE"][family], d["WRITE_SIZE"][family]
         return (2.0 * fe["sum_counter"] / fe["launches"] + wr["sum_counter"] / wr["launches"]) * 1024.0
     except (OSError, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
+def pmc_traffic_stamp():
+    """{"commit", "lib_sha16"} of the PMC passes and whether that library is the one loaded now."""
+    import hashlib
+
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)) as f:
+            st = json.load(f).get("stamp", {})
+        with open(os.path.join(ROOT, "genima_amd", "libgenima_hip.so"), "rb") as f:
+            st["same_library_as_this_run"] = hashlib.sha256(f.read()).hexdigest()[:16] == st.get("lib_sha16")
+        return st
+    except OSError:
         return None
 
 
@@ -181,10 +208,12 @@ def cpu_baseline(max_seconds=40.0):
                       f"each piece best of <= 2 runs; weights drawn in {gen_s:.0f} s, untimed"}
 
 
-def single_view_latency(pipe, dev, denoise_steps, rank, calls=10):
-    """BASELINE.json configs[1] as the evaluation loop sees it (B = frame_stack = 1, one 256x256 view): latency of one 5-step call with
-    the whole recorded program replayed as ONE hipGraph (the HIP form of the reference's ``torch_compile`` reduce-overhead flag)."""
-    B, H, W, desc = WORKLOADS["single_b1"]
+def single_view_latency(pipe, dev, denoise_steps, rank, calls=10, workload="single_b1"):
+    """BASELINE.json configs[1] as the evaluation loop sees it (B = frame_stack = 1, one 256x256 view) -- or, ``workload="tiled_b1"``, the
+    call the real evaluation loop makes (controller/eval_genima.py:202-211: ONE 4-view tiled 512x512 observation per control step):
+    latency of one 5-step call, stream replay of the recorded program and the same program as ONE hipGraph (the HIP form of the
+    reference's ``torch_compile`` reduce-overhead flag)."""
+    B, H, W, desc = WORKLOADS[workload]
     ids, img, lat = synthetic_inputs(pipe, B, H, W, dev, rank)
     res = {}
     for graph in (False, True):
@@ -202,7 +231,7 @@ def single_view_latency(pipe, dev, denoise_steps, rank, calls=10):
         res["hip_graph" if graph else "stream_replay"] = 1000.0 * ts[len(ts) // 2]
     pipe.enable_hip_graph(False)
     best = min(res.values())
-    return {"workload": desc, "ms_per_call_median": res, "images_per_sec": 1000.0 / best,
+    return {"workload": desc, "ms_per_call_median": res, "images_per_sec": (4.0 if H == 512 else 1.0) * 1000.0 / best,
             "weight_streaming_ideal_ms": 13.1e9 / 8e12 * 1e3,  # 13.1 GB of weights per call at 8 TB/s
             "frac_of_hbm_roofline": (13.1e9 / 8e12 * 1e3) / best}
 
@@ -358,6 +387,7 @@ def main():
                            "traffic_note": "HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes of this "
                                            f"workload (profiles/{PMC_TRAFFIC_FILE}: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; "
                                            "the x2 is MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction); not re-collected by this run",
+                           "traffic_stamp": pmc_traffic_stamp(),
                            "frac_of_sustained_mfma_rate": ach / MFMA_SUSTAINED_TF,
                            "sustained_note": f"a pure v_mfma_f32_32x32x16_f16 stream sustains {MFMA_SUSTAINED_TF:.0f} TFLOP/s on MI355X "
                                              "(19-21 ns per MFMA per SIMD at the ~1.6-1.7 GHz the chip holds under matrix load; "
@@ -382,6 +412,10 @@ def main():
             out["single_view_b1"] = single_view_latency(pipe, dev, args.denoise_steps, rank)
         except Exception as e:  # an extra must never cost the headline line
             out["single_view_b1"] = {"error": repr(e)[:300]}
+        try:
+            out["tiled_b1"] = single_view_latency(pipe, dev, args.denoise_steps, rank, workload="tiled_b1")
+        except Exception as e:
+            out["tiled_b1"] = {"error": repr(e)[:300]}
 
     # BASELINE.json's second metric on the same launch: the ControlNet fine-tune step (configs[3], per-GPU batch 8), N ranks data
     # parallel with the bucketed RCCL reduce-scatter + all-gather of the flat gradient overlapped with the backward

@@ -572,11 +572,14 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------------------------------------ small ops
-    def _small(self, fn_name: str, keep, *args):
+    def _small(self, fn_name: str, keep, *args, nbytes: Optional[float] = None):
+        """``nbytes``: the bytes the op actually touches when that is not the size of its operands (gathers read a few rows of a table)."""
         if self.record:
             check(getattr(self.lib, "gn_program_add_" + fn_name)(self._prog, *args), "gn_program_add_" + fn_name)
             self._keepalive(*keep)
-            self.meta.append(dict(kind=fn_name, flops=0.0, bytes=float(sum(t.numel() * t.element_size() for t in keep if t is not None)), shape=()))
+            if nbytes is None:
+                nbytes = float(sum(t.numel() * t.element_size() for t in keep if t is not None))
+            self.meta.append(dict(kind=fn_name, flops=0.0, bytes=float(nbytes), shape=()))
         else:
             check(getattr(self.lib, "gn_" + fn_name)(self._ctx, *args), "gn_" + fn_name)
 
@@ -651,7 +654,9 @@ class Engine:
         B, L = ids.shape
         D = tok.shape[1]
         out = self.buf(name, (B, L, D))
-        self._small("embedding", (ids, tok, pos, out), _ptr(ids), _ptr(tok), _ptr(pos), _ptr(out), B, L, D)
+        # B * L gathered table rows + L position rows read, B * L rows written (not the whole 100 MB token table)
+        self._small("embedding", (ids, tok, pos, out), _ptr(ids), _ptr(tok), _ptr(pos), _ptr(out), B, L, D,
+                    nbytes=4.0 * B * L + 2.0 * D * (2 * B * L + L))
         return out
 
     def softmax_rows(self, x: torch.Tensor, scale: float = 1.0):
@@ -672,7 +677,7 @@ class Engine:
         """x [B, L, D], idx int32 [B] -> [B, D]."""
         B, L, D = x.shape
         out = self.buf(name, (B, D))
-        self._small("gather_rows", (x, idx, out), _ptr(x), _ptr(idx), _ptr(out), B, L, D)
+        self._small("gather_rows", (x, idx, out), _ptr(x), _ptr(idx), _ptr(out), B, L, D, nbytes=4.0 * B + 4.0 * B * D)
         return out
 
     def argmax_rows(self, x: torch.Tensor, *, name=None):

@@ -176,10 +176,12 @@ def test_data_path_to_trainer_end_to_end(tmp_path):
     logs = []
     tr = trainer()
     loop = TrainLoop(tr, out, num_train_epochs=2, checkpointing_steps=1, checkpoints_total_limit=2, log=logs.append)
-    assert loop.run(loader) == 3  # 6 examples / batch 2 = 3 micro-batches per epoch, 2 per optimizer step -> 1 + 2 steps over 2 epochs
-    assert tr.opt_step == 3 and np.isfinite(float(loop.last_loss))
-    assert list_checkpoints(out) == ["checkpoint-2", "checkpoint-3"]
+    # 6 examples / batch 2 = 3 micro-batches per epoch, 2 per optimizer step: the epoch's last batch syncs on its own (accelerate's
+    # end_of_dataloader), so ceil(3 / 2) = 2 optimizer steps per epoch and nothing accumulated crosses the epoch boundary
+    assert loop.run(loader) == 4
+    assert tr.opt_step == 4 and tr._micro == 0 and np.isfinite(float(loop.last_loss))
+    assert list_checkpoints(out) == ["checkpoint-3", "checkpoint-4"]
     tr2 = trainer()
-    loop2 = TrainLoop(tr2, out, max_train_steps=4, checkpointing_steps=100, resume_from_checkpoint="latest", log=logs.append)
-    assert loop2.run(loader) == 4 and torch.equal(tr2.cn.exp_avg_sq > 0, tr2.cn.exp_avg_sq > 0)
-    assert any("Resuming from checkpoint checkpoint-3" in m for m in logs) and tr2.opt_step == 4
+    loop2 = TrainLoop(tr2, out, max_train_steps=5, checkpointing_steps=100, resume_from_checkpoint="latest", log=logs.append)
+    assert loop2.run(loader) == 5 and torch.equal(tr2.cn.exp_avg_sq > 0, tr2.cn.exp_avg_sq > 0)
+    assert any("Resuming from checkpoint checkpoint-4" in m for m in logs) and tr2.opt_step == 5

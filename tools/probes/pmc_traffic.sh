@@ -25,6 +25,12 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
                     agg[f]["launches"] += 1
                     break
     out[c] = agg
+import hashlib
+root = os.environ.get("GRAFT_REPO_ROOT", ".")
+# which code the counters belong to: the commit the caller passes in (the GPU box has no .git) and the hash of the library that ran
+out["stamp"] = {"commit": os.environ.get("GIT_COMMIT", "unknown"),
+                "lib_sha16": hashlib.sha256(open(root + "/genima_amd/libgenima_hip.so", "rb").read()).hexdigest()[:16],
+                "command": "python bench.py --steps 3 --warmup 0 --no-cpu-baseline --no-roofline --no-act --no-train --no-single-view"}
 json.dump(out, open(O + "/traffic.json", "w"), indent=1)
 g = out["FETCH_SIZE"]["gemm"], out["WRITE_SIZE"]["gemm"]
 print("gemm family: launches", g[0]["launches"], "bytes per launch", (2 * g[0]["sum_counter"] / max(1, g[0]["launches"]) + g[1]["sum_counter"] / max(1, g[1]["launches"])) * 1024)
