@@ -96,6 +96,7 @@ SIGNATURES = {
     "gn_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F]),
     "gn_timestep_embedding": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F]),
     "gn_scale_pad": (_I32, [_P, _P, _P, _I64, _I32, _I32, _F]),
+    "gn_scale_cat_pad": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _F]),
     "gn_euler_step": (_I32, [_P, _P, _P, _I64, _I32, _I32, _F, _F]),
     "gn_add_noise": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I64]),
     "gn_image_u8_to_f16": (_I32, [_P, _P, _P, _I64, _I32, _F, _F]),
@@ -146,6 +147,7 @@ SIGNATURES = {
     "gn_color_jitter": (_I32, [_P, _P, _P, _I32, _I64, _I32, _P, _P, _P]),
     "gn_reflect_pad_crop": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "gn_latent_sample":(_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _F]),
+    "gn_ema_flat": (_I32, [_P, _P, _P, _I64, _F]),
     "gn_cast_f32_f16": (_I32, [_P, _P, _P, _I64]),
     "gn_fill_f32": (_I32, [_P, _P, _I64, _F]),
     "gn_film_bwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32, _P, _P, _P]),
@@ -169,6 +171,7 @@ SIGNATURES = {
     "gn_program_add_layernorm": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F]),
     "gn_program_add_timestep_embedding": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F]),
     "gn_program_add_scale_pad": (_I32, [_P, _P, _P, _I64, _I32, _I32, _F]),
+    "gn_program_add_scale_cat_pad": (_I32, [_P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _F, _F]),
     "gn_program_add_euler_step": (_I32, [_P, _P, _P, _I64, _I32, _I32, _F, _F]),
     "gn_program_add_image_f16_to_u8": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_program_add_image_u8_to_f16": (_I32, [_P, _P, _P, _I64, _I32, _F, _F]),

@@ -137,3 +137,39 @@ class SDXLControlNetAgent(SDControlNetAgent):
     from .pipeline import StableDiffusionXLControlNetPipeline as pipeline_cls  # noqa: E402
 
     tiny_tag = "taesdxl"
+
+
+class SDPix2PixAgent(DiffusionAgent):
+    """InstructPix2Pix agent (controller/agent/sd_pix2pix_agent.py:11-60): the fine-tuned 8-channel UNet from
+    ``<diffusion_ckpt>/checkpoint-<max>/unet`` (natural sort; else ``<diffusion_ckpt>/unet``) inside the base checkpoint's pipeline."""
+
+    def load_checkpoint(self):
+        from .host import UNet2DConditionModel
+        from .pix2pix import StableDiffusionInstructPix2PixPipeline
+
+        cfg = self.eval_cfg
+        ckpt = cfg.diffusion_ckpt
+        synthetic = str(cfg.sd_ckpt).startswith("synthetic:")
+        unet = None
+        if not (synthetic and (not ckpt or str(ckpt).startswith("synthetic:"))):
+            if not ckpt or not os.path.isdir(str(ckpt)):
+                raise FileNotFoundError(f"diffusion_ckpt {ckpt!r} is not a directory (expected <dir>/checkpoint-N/unet or <dir>/unet)")
+            dirs = sorted([d for d in os.listdir(ckpt) if "checkpoint" in d], key=_natural_key)
+            root = os.path.join(ckpt, dirs[-1]) if dirs else ckpt
+            if not os.path.exists(os.path.join(root, "unet", "config.json")):
+                raise FileNotFoundError(f"no InstructPix2Pix UNet under {root}/unet (config.json + diffusion_pytorch_model.safetensors)")
+            unet = UNet2DConditionModel.from_pretrained(root, "unet")
+        if cfg.sd_ckpt and os.path.isdir(str(cfg.sd_ckpt)):
+            self.pipe = StableDiffusionInstructPix2PixPipeline.from_pretrained(cfg.sd_ckpt, unet=unet, variant="fp16")
+        elif synthetic:
+            self.pipe = StableDiffusionInstructPix2PixPipeline.from_synthetic(configs.family(str(cfg.sd_ckpt).split(":", 1)[1]))
+            if unet is not None:
+                self.pipe.unet = unet
+        else:
+            raise FileNotFoundError(f"sd_ckpt {cfg.sd_ckpt!r} is not a local diffusers directory (no network access); "
+                                    "use a local path or 'synthetic:<family>'")
+
+    def infer(self, *args, **kwargs):
+        return self.pipe(prompt=kwargs["prompts"], image=kwargs["images"], negative_prompt=kwargs.get("negative_prompts"),
+                         num_inference_steps=kwargs["num_inference_steps"], guidance_scale=kwargs["guidance_scale"],
+                         generator=kwargs.get("generator"))

@@ -225,6 +225,13 @@ def family(name: str) -> dict:
     elif name == "tiny-xl":
         fam = dict(unet=TINY_XL_UNET, controlnet=TINY_XL_CONTROLNET, vae=TINY_VAE, text=TINY_XL_TEXT_L, text_2=TINY_XL_TEXT_G,
                    scheduler=SD_TURBO_SCHEDULER, act=TINY_ACT_POLICY, act_text=TINY_ACT_CLIP_TEXT)
+    elif name in ("sd-turbo-pix2pix", "tiny-pix2pix"):
+        # InstructPix2Pix base (diffusion/train_instruct_pix2pix_genima.py:800-818): the same networks, the UNet's conv_in widened to
+        # latent_channels + image-latent channels = 8; no ControlNet
+        fam = family(name[: -len("-pix2pix")])
+        fam["unet"] = dict(fam["unet"], in_channels=8)
+        del fam["controlnet"]
+        return fam
     else:
         raise KeyError(f"unknown model family {name!r}")
     return copy.deepcopy(fam)

@@ -19,7 +19,7 @@ namespace {
 
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
-  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE, OP_FILM,
+  OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE, OP_FILM, OP_SCALE_CAT_PAD,
   OP_FORK, OP_MAIN, OP_JOIN  // stream control: ops after FORK go to the program's side stream until MAIN; JOIN makes main wait for it
 };
 
@@ -62,6 +62,7 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_LAYERNORM: return gn_layernorm_fwd(ctx, g.p0, g.p1, g.p2, g.p3, g.n0, g.i0, g.f0);
     case OP_TEMB: return gn_timestep_embedding(ctx, (const float*)g.p0, g.p3, g.i0, g.i1, g.i2, g.f0);
     case OP_SCALE_PAD: return gn_scale_pad(ctx, g.p0, g.p3, g.n0, g.i0, g.i1, g.f0);
+    case OP_SCALE_CAT_PAD: return gn_scale_cat_pad(ctx, g.p0, g.p1, g.p3, g.n0, g.i0, (int32_t)g.n1, g.i1, g.i2, g.i3, g.f0, g.f1);
     case OP_EULER: return gn_euler_step(ctx, g.p3, g.p0, g.n0, g.i0, g.i1, g.f0, g.f1);
     case OP_F16_TO_U8: return gn_image_f16_to_u8(ctx, g.p0, (uint8_t*)g.p3, g.n0, g.i0);
     case OP_U8_TO_F16: return gn_image_u8_to_f16(ctx, (const uint8_t*)g.p0, g.p3, g.n0, g.i0, g.f0, g.f1);
@@ -188,6 +189,10 @@ int32_t gn_program_add_timestep_embedding(gn_program* p, const float* t, void* o
 }
 int32_t gn_program_add_scale_pad(gn_program* p, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad, float scale) {
   return push_generic(p, OP_SCALE_PAD, x, nullptr, nullptr, out, pixels, 0, C, Cpad, 0, 0, scale, 0.f);
+}
+int32_t gn_program_add_scale_cat_pad(gn_program* p, const void* x, const void* x2, void* out, int64_t pixels, int32_t C, int32_t ld1,
+                                     int32_t C2, int32_t ld2, int32_t Cpad, float scale, float scale2) {
+  return push_generic(p, OP_SCALE_CAT_PAD, x, x2, nullptr, out, pixels, ld1, C, C2, ld2, Cpad, scale, scale2);
 }
 int32_t gn_program_add_euler_step(gn_program* p, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps, float sigma, float sigma_next) {
   return push_generic(p, OP_EULER, eps, nullptr, nullptr, x, pixels, 0, C, ld_eps, 0, 0, sigma, sigma_next);

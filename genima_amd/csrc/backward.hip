@@ -725,6 +725,19 @@ __global__ void fill_f32_kernel(float* __restrict__ x, long n, float v) {
 
 }  // namespace
 
+// EMAModel.step (diffusers training_utils; diffusion/train_instruct_pix2pix_genima.py:1271-1272): shadow -= (1 - decay) * (shadow - param)
+__global__ void ema_flat_kernel(float* __restrict__ shadow, const float* __restrict__ param, long n4, float one_minus_decay) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 s = reinterpret_cast<float4*>(shadow)[i];
+  const float4 q = reinterpret_cast<const float4*>(param)[i];
+  s.x = __fsub_rn(s.x, __fmul_rn(one_minus_decay, __fsub_rn(s.x, q.x)));
+  s.y = __fsub_rn(s.y, __fmul_rn(one_minus_decay, __fsub_rn(s.y, q.y)));
+  s.z = __fsub_rn(s.z, __fmul_rn(one_minus_decay, __fsub_rn(s.z, q.z)));
+  s.w = __fsub_rn(s.w, __fmul_rn(one_minus_decay, __fsub_rn(s.w, q.w)));
+  reinterpret_cast<float4*>(shadow)[i] = s;
+}
+
 extern "C" {
 
 int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
@@ -979,6 +992,12 @@ int32_t gn_latent_sample(gn_ctx* ctx, const void* moments, const void* eps, void
   GN_REQUIRE(ctx && moments && eps && out && pixels > 0 && C > 0 && ld_moments >= 2 * C && ld_eps >= C && ld_out >= C, "gn_latent_sample: bad arguments");
   hipLaunchKernelGGL(latent_sample_kernel, dim3(nblk(pixels * ld_out)), dim3(256), 0, ctx->stream, (const f16*)moments, (const f16*)eps, (f16*)out,
                      (long)pixels, C, ld_moments, ld_eps, ld_out, scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+int32_t gn_ema_flat(gn_ctx* ctx, float* shadow, const float* param, int64_t n, float one_minus_decay) {
+  GN_REQUIRE(ctx && shadow && param && n > 0 && n % 4 == 0, "gn_ema_flat: n must be a positive multiple of 4");
+  hipLaunchKernelGGL(ema_flat_kernel, dim3(nblk(n / 4)), dim3(256), 0, ctx->stream, shadow, param, (long)(n / 4), one_minus_decay);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -27,6 +27,20 @@ __global__ void scale_pad_kernel(const f16* __restrict__ x, f16* __restrict__ ou
   out[idx] = c < C ? (f16)((float)x[p * C + c] * scale) : (f16)0.0f;
 }
 
+// out[p, 0:C] = x[p * ld1 + 0:C] * scale | out[p, C:C+C2] = x2[p * ld2 + 0:C2] * scale2 | zeros up to Cpad: channel concatenation of two
+// narrow latent tensors into one 8-channel pixel (InstructPix2Pix: torch.cat([scaled noisy latents, image latents], dim=1))
+__global__ void scale_cat_pad_kernel(const f16* __restrict__ x, const f16* __restrict__ x2, f16* __restrict__ out, long pixels, int C,
+                                     int ld1, int C2, int ld2, int Cpad, float scale, float scale2) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pixels * Cpad) return;
+  const long p = idx / Cpad;
+  const int c = (int)(idx - p * Cpad);
+  float v = 0.0f;
+  if (c < C) v = (float)x[p * ld1 + c] * scale;
+  else if (c < C + C2) v = (float)x2[p * ld2 + (c - C)] * scale2;
+  out[idx] = (f16)v;
+}
+
 __global__ void euler_step_kernel(f16* __restrict__ x, const f16* __restrict__ eps, long pixels, int C, int ld, float sigma,
                                   float sigma_next) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -271,6 +285,15 @@ int32_t gn_timestep_embedding(gn_ctx* ctx, const float* t, void* out, int32_t B,
 int32_t gn_scale_pad(gn_ctx* ctx, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad, float scale) {
   GN_REQUIRE(ctx && x && out && pixels > 0 && C > 0 && Cpad >= C, "gn_scale_pad: bad arguments");
   hipLaunchKernelGGL(scale_pad_kernel, dim3(nblk(pixels * Cpad)), dim3(256), 0, ctx->stream, (const f16*)x, (f16*)out, (long)pixels, C, Cpad, scale);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_scale_cat_pad(gn_ctx* ctx, const void* x, const void* x2, void* out, int64_t pixels, int32_t C, int32_t ld1, int32_t C2,
+                         int32_t ld2, int32_t Cpad, float scale, float scale2) {
+  GN_REQUIRE(ctx && x && x2 && out && pixels > 0 && C > 0 && ld1 >= C && C2 > 0 && ld2 >= C2 && Cpad >= C + C2, "gn_scale_cat_pad: bad arguments");
+  hipLaunchKernelGGL(scale_cat_pad_kernel, dim3(nblk(pixels * Cpad)), dim3(256), 0, ctx->stream, (const f16*)x, (const f16*)x2, (f16*)out,
+                     (long)pixels, C, ld1, C2, ld2, Cpad, scale, scale2);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

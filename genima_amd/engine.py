@@ -597,6 +597,17 @@ class Engine:
         self._small("scale_pad", (x, out), _ptr(x), _ptr(out), x.numel() // Cc, Cc, cpad, float(scale))
         return out
 
+    def scale_cat_pad(self, x: torch.Tensor, c1: int, x2: torch.Tensor, c2: int, cpad: int, scale: float = 1.0, scale2: float = 1.0, *,
+                      out=None, name=None):
+        """out[..., :c1] = x[..., :c1] * scale | out[..., c1:c1+c2] = x2[..., :c2] * scale2 | zeros up to cpad (the pixel rows of x / x2
+        may be wider than c1 / c2: padded latents, VAE moments)."""
+        pixels = x.numel() // x.shape[-1]
+        if out is None:
+            out = self.buf(name, tuple(x.shape[:-1]) + (cpad,))
+        self._small("scale_cat_pad", (x, x2, out), _ptr(x), _ptr(x2), _ptr(out), pixels, c1, x.stride(-2), c2, x2.stride(-2), cpad,
+                    float(scale), float(scale2))
+        return out
+
     def euler_step(self, x: torch.Tensor, eps: torch.Tensor, sigma: float, sigma_next: float):
         """In place: x[..., C] <- x + eps[..., :C] * (sigma_next - sigma)."""
         Cc = x.shape[-1]

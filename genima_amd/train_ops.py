@@ -302,6 +302,27 @@ def groupnorm_bwd(E: Engine, s: GNSaved, dy, need_dx: bool = True, need_dx2: boo
     return dx, dx2
 
 
+def concat_channels(E: Engine, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[B, H, W, Ca] ++ [B, H, W, Cb] -> [B, H, W, Ca + Cb] (torch.cat(dim=1) of the NCHW reference): two strided copies."""
+    Bn, H, Wd, Ca = a.shape
+    Cb = b.shape[-1]
+    out = torch.empty((Bn, H, Wd, Ca + Cb), dtype=F16, device=E.device)
+    P = Bn * H * Wd
+    E.copy4d(a, out, (1, 1, 1, P), (0, 0, 0, Ca), (0, 0, 0, Ca + Cb), Ca)
+    E.copy4d(b, out[..., Ca:], (1, 1, 1, P), (0, 0, 0, Cb), (0, 0, 0, Ca + Cb), Cb)
+    return out
+
+
+def upsample_nearest2x(E: Engine, x: torch.Tensor) -> torch.Tensor:
+    """F.interpolate(scale_factor=2, mode="nearest") on NHWC as four strided copies (out[b, 2y+dy, 2x+dx] = x[b, y, x])."""
+    Bn, H, Wd, Cc = x.shape
+    out = torch.empty((Bn, 2 * H, 2 * Wd, Cc), dtype=F16, device=E.device)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            E.copy4d(x, out[:, dy:, dx:], (1, Bn, H, Wd), (0, H * Wd * Cc, Wd * Cc, Cc), (0, 4 * H * Wd * Cc, 4 * Wd * Cc, 2 * Cc), Cc)
+    return out
+
+
 def zero_upsample2x(E: Engine, x: torch.Tensor) -> torch.Tensor:
     B, H, W, Cc = x.shape
     out = torch.empty((B, 2 * H, 2 * W, Cc), dtype=F16, device=E.device)
@@ -359,6 +380,12 @@ def latent_sample(E: Engine, moments: torch.Tensor, eps: torch.Tensor, C_lat: in
 def cast_f32_f16(E: Engine, x: torch.Tensor, out: torch.Tensor):
     check(E.lib.gn_cast_f32_f16(E._ctx, _ptr(x), _ptr(out), x.numel()), "gn_cast_f32_f16")
     return out
+
+
+def ema_flat(E, shadow: torch.Tensor, param: torch.Tensor, one_minus_decay: float):
+    """shadow <- shadow - one_minus_decay * (shadow - param) on flat fp32 buffers (diffusers EMAModel.step)."""
+    assert shadow.numel() == param.numel() and shadow.numel() % 4 == 0
+    check(E.lib.gn_ema_flat(E._ctx, _ptr(shadow), _ptr(param), shadow.numel(), float(one_minus_decay)), "gn_ema_flat")
 
 
 def fill_f32(E: Engine, x: torch.Tensor, v: float = 0.0):

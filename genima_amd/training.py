@@ -258,19 +258,26 @@ class Graph:
             dy2 = dy.view(M, Cout)
             self.acc(residual, dy)
             if net.G is not None:
-                assert x2 is None and not upsample2x, "weight gradients of concat / upsample convs are not needed by the ControlNet"
                 assert M % 8 == 0, "conv wgrad needs B*Ho*Wo to be a multiple of 8"
                 sums = [(net.dshift[prefix] if sh_var is not None else None, B), (net.G[bn] if bn else None, 1)]  # time-shift and bias gradients
-                Kw = ksize * ksize * C1
-                if T.wgrad_ok(Cout, Kw, C1) and x.t.dim() == 4:  # straight from NHWC x and dY: no im2col^T, no transposes
+                # the forward's VIRTUAL operands (two-source channel concat of the UNet decoder, fused nearest-2x upsample) are made
+                # real for the weight gradient only -- a trainable UNet decoder exists in the InstructPix2Pix fine-tune alone
+                xw = x.t
+                if x2 is not None:
+                    xw = T.concat_channels(E, x.t, x2.t)
+                if upsample2x:
+                    xw = T.upsample_nearest2x(E, xw)
+                Cw = xw.shape[-1]
+                Kw = ksize * ksize * Cw
+                if T.wgrad_ok(Cout, Kw, Cw) and xw.dim() == 4:  # straight from NHWC x and dY: no im2col^T, no transposes
                     in_kernel = (Ho * Wo) % 64 == 0  # per-sample sums need row slices that tile a sample
-                    T.wgrad(E, dy2, x.t, net.G[wn], ksize=ksize, stride=stride, pad=ksize // 2, dbias=sums[1][0],
+                    T.wgrad(E, dy2, xw, net.G[wn], ksize=ksize, stride=stride, pad=ksize // 2, dbias=sums[1][0],
                             dshift=sums[0][0] if in_kernel else None, shift_groups=B)
                     if sums[0][0] is not None and not in_kernel:
                         T.colsum(E, dy2, sums[0][0], B, Ho * Wo, Cout, Cout)
                 else:
                     dyt = T.transpose2d_colsum(E, dy2, M, Cout, sums)
-                    cols = T.im2col_t(E, x.t, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, x.t.view(M, C1), M, C1)
+                    cols = T.im2col_t(E, xw, ksize, stride, ksize // 2) if ksize > 1 else T.transpose2d(E, xw.view(M, Cw), M, Cw)
                     T.gemm(E, dyt, cols, net.G[wn], Cout, Kw, M, M, M, Kw, f32_out=True, accumulate=True)
             if needs_in:
                 parts = ((x, 0, C1),) + (((x2, C1, C1 + C2),) if x2 is not None else ())
@@ -602,6 +609,31 @@ def t_unet(g: Graph, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tens
     return g.conv(net, hv, "conv_out.weight", "conv_out.bias")
 
 
+def t_unet_full(g: Graph, net: TrainParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx_pad: torch.Tensor, nk_valid: int,
+                added=None) -> Var:
+    """A fully TRAINABLE UNet forward with every activation kept (the InstructPix2Pix fine-tune optimises ``unet.parameters()``,
+    diffusion/train_instruct_pix2pix_genima.py:1112-1118, :1241-1247); x8 carries all of ``in_channels`` (8: noisy latents | image
+    latents) real channels."""
+    W = net.W
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    shifts = t_time_shifts(g, net, cfg, t_dev, x8.shape[0], added)
+    kv = t_cross_kv(g, net, Var(ctx_pad, needs=False), _attn2_prefixes(W, ("down_blocks.", "mid_block.", "up_blocks.")))
+    h = g.conv(net, Var(x8, needs=False), "conv_in.weight", "conv_in.bias")
+    h, skips = t_encoder(g, net, cfg, h, shifts, kv, nk_valid)
+    h = t_mid(g, net, cfg, h, shifts, kv, nk_valid)
+    nlev = len(cfg["block_out_channels"])
+    for i, btype in enumerate(cfg["up_block_types"]):
+        for j in range(cfg["layers_per_block"] + 1):
+            h = t_resnet(g, net, f"up_blocks.{i}.resnets.{j}", h, skips.pop(), shifts, G, eps)
+            if btype == "CrossAttnUpBlock2D":
+                h = t_transformer(g, net, f"up_blocks.{i}.attentions.{j}", h, kv, _heads(cfg, nlev - 1 - i), G, nk_valid)
+        if i != nlev - 1:
+            p = f"up_blocks.{i}.upsamplers.0.conv"
+            h = g.conv(net, h, p + ".weight", p + ".bias", upsample2x=True)
+    h = g.groupnorm(net, h, "conv_norm_out.weight", "conv_norm_out.bias", G, eps, ACT_SILU)
+    return g.conv(net, h, "conv_out.weight", "conv_out.bias")
+
+
 # =============================================================================================================== the step
 def pad_context(ctx: torch.Tensor) -> torch.Tensor:
     """[B, L, D] prompt states -> [B, rup(L, 8), D] with zero rows (their keys get zero attention weight, gn_softmax_rows_masked)."""
@@ -733,11 +765,16 @@ class ControlNetTrainer:
         return loss
 
     # ---- checkpoints: diffusers ControlNet directory + optimizer state (diffusion/train_controlnet_genima.py:1077-1105, 1416-1457, 1486)
-    def controlnet_state_dict(self) -> "OrderedDict[str, torch.Tensor]":
-        """fp32 diffusers-named ControlNet weights (the master copy un-packed)."""
+    trainable_subfolder = "controlnet"   # the diffusers directory a checkpoint holds for the trained network
+
+    def _trainable_schema(self):
         from . import schema
+        return schema.controlnet_schema(self.cn_cfg)
+
+    def controlnet_state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        """fp32 diffusers-named weights of the trained network (the master copy un-packed)."""
         from .packing import unpack_state_dict
-        return unpack_state_dict(self.cn.packed_master(), schema.controlnet_schema(self.cn_cfg), self.cn.temb_slices)
+        return unpack_state_dict(self.cn.packed_master(), self._trainable_schema(), self.cn.temb_slices)
 
     def save_pretrained(self, path: str):
         from . import weights
@@ -748,7 +785,7 @@ class ControlNetTrainer:
         import os
         from safetensors.torch import save_file
         d = os.path.join(output_dir, f"checkpoint-{global_step}")
-        self.save_pretrained(os.path.join(d, "controlnet"))
+        self.save_pretrained(os.path.join(d, self.trainable_subfolder))
         save_file({"exp_avg": self.cn.exp_avg.cpu(), "exp_avg_sq": self.cn.exp_avg_sq.cpu(),
                    "scalars": torch.tensor([self.opt_step, self.loss_scale, self._clean, global_step, self.sched_step], dtype=torch.float64)},
                   os.path.join(d, "optimizer_flat.safetensors"))
@@ -758,11 +795,11 @@ class ControlNetTrainer:
         """Resume from ``save_state``'s directory.  Returns the global step it was written at."""
         import os
         from safetensors.torch import load_file
-        from . import schema, weights
-        _, sd = weights.load_diffusers_dir(os.path.join(checkpoint_dir, "controlnet"))
-        sd = OrderedDict((k, sd[k]) for k in schema.controlnet_schema(self.cn_cfg))  # safetensors files are key-sorted
+        from . import weights
+        _, sd = weights.load_diffusers_dir(os.path.join(checkpoint_dir, self.trainable_subfolder))
+        sd = OrderedDict((k, sd[k]) for k in self._trainable_schema())  # safetensors files are key-sorted
         fresh = TrainParams(self.E, sd)
-        assert fresh.layout == self.cn.layout, "checkpoint does not match this ControlNet configuration"
+        assert fresh.layout == self.cn.layout, "checkpoint does not match this network's configuration"
         self.cn.master.copy_(fresh.master)
         st = load_file(os.path.join(checkpoint_dir, "optimizer_flat.safetensors"))
         self.cn.exp_avg.copy_(st["exp_avg"])

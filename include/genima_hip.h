@@ -191,6 +191,11 @@ int32_t gn_timestep_embedding(gn_ctx* ctx, const float* t, void* out, int32_t B,
 int32_t gn_scale_pad(gn_ctx* ctx, const void* x, void* out, int64_t pixels, int32_t C, int32_t Cpad, float scale);
 int32_t gn_euler_step(gn_ctx* ctx, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps, float sigma,
                       float sigma_next);
+/* InstructPix2Pix channel concatenation (diffusers StableDiffusionInstructPix2PixPipeline: cat([scale_model_input(latents), image_latents],
+ * dim=1); diffusion/train_instruct_pix2pix_genima.py:1236-1239): out[p, 0:C] = x[p*ld1 + 0:C] * scale, out[p, C:C+C2] = x2[p*ld2 + 0:C2] * scale2,
+ * out[p, C+C2:Cpad] = 0 */
+int32_t gn_scale_cat_pad(gn_ctx* ctx, const void* x, const void* x2, void* out, int64_t pixels, int32_t C, int32_t ld1, int32_t C2,
+                         int32_t ld2, int32_t Cpad, float scale, float scale2);
 int32_t gn_add_noise(gn_ctx* ctx, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac,
                      void* out, int32_t B, int64_t per_sample);
 
@@ -316,6 +321,9 @@ int32_t gn_adamw_flat(gn_ctx* ctx, float* param, float* grad, float* m, float* v
  * out[p, 0:C] = (mean + exp(0.5 * clamp(logvar, -30, 20)) * eps) * scale, out[p, C:ld_out] = 0 */
 int32_t gn_latent_sample(gn_ctx* ctx, const void* moments, const void* eps, void* out, int64_t pixels, int32_t C,
                          int32_t ld_moments, int32_t ld_eps, int32_t ld_out, float scale);
+/* EMAModel.step of the InstructPix2Pix fine-tune (diffusion/train_instruct_pix2pix_genima.py:821-824, :1271-1272) on the flat fp32
+ * buffers: shadow <- shadow - one_minus_decay * (shadow - param), f32 op order of diffusers' `s_param.sub_(one_minus_decay * (s_param - param))` */
+int32_t gn_ema_flat(gn_ctx* ctx, float* shadow, const float* param, int64_t n, float one_minus_decay);
 int32_t gn_cast_f32_f16(gn_ctx* ctx, const float* x, void* out, int64_t n);
 int32_t gn_fill_f32(gn_ctx* ctx, float* x, int64_t n, float v);
 
@@ -346,6 +354,8 @@ int32_t gn_program_add_scale_pad(gn_program* p, const void* x, void* out, int64_
                                  float scale);
 int32_t gn_program_add_euler_step(gn_program* p, void* x, const void* eps, int64_t pixels, int32_t C, int32_t ld_eps,
                                   float sigma, float sigma_next);
+int32_t gn_program_add_scale_cat_pad(gn_program* p, const void* x, const void* x2, void* out, int64_t pixels, int32_t C, int32_t ld1,
+                                     int32_t C2, int32_t ld2, int32_t Cpad, float scale, float scale2);
 int32_t gn_program_add_image_f16_to_u8(gn_program* p, const void* in, uint8_t* out, int64_t pixels, int32_t ld);
 int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* out, int64_t pixels, int32_t Cpad,
                                        float mul, float add);
