@@ -50,6 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="buckets", choices=["buckets", "flat", "abi", "abi-bf16"],
                     help="gradient exchange: bucketed RS+AG overlapped with the backward (default), one RS+AG after it, or the C-ABI "
                          "RCCL communicator (gn_comm_*; -bf16: bf16 on the wire)")
+    ap.add_argument("--no-graph", action="store_true", help="keep the forward + backward walk eager (default: captured into one hipGraph after two steps)")
     ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
     return ap.parse_args(argv)
 
@@ -80,7 +81,8 @@ def run(args, quiet: bool = False):
     if world > 1:
         exchange = {"buckets": lambda: dist.GradBuckets(n_buckets=8), "flat": lambda: dist.allreduce_sum_flat,
                     "abi": lambda: dist.AbiComm(E, rank, world), "abi-bf16": lambda: dist.AbiComm(E, rank, world, bf16_wire=True)}[args.exchange]()
-    tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet_W, cn_sd, lr=args.lr, allreduce=exchange)
+    tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet_W, cn_sd, lr=args.lr, allreduce=exchange,
+                           hip_graph=False if (args.no_graph or args.gemm_table) else None)
     del cn_sd
     text2_W = pack_state_dict(synth(schema.clip_text_schema(fam["text_2"]), 5), dev) if "text_2" in fam else None
     tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank,
@@ -134,7 +136,8 @@ def run(args, quiet: bool = False):
                                     if args.family == "sdxl-turbo" else
                                     "BASELINE.json configs[3]: SD-Turbo ControlNet fine-tune, 512x512 (4x256x256 tiled views)"),
                        "family": args.family,
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "gradient_exchange": args.exchange if world > 1 else None, "optimizer": "AdamW fp32 master, f16 compute, loss scale",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}", "gradient_exchange": args.exchange if world > 1 else None,
+                       "hip_graph": bool(tr._graphs), "optimizer": "AdamW fp32 master, f16 compute, loss scale",
                        "trainable_params_padded": int(tr.cn.numel), "fp8_frozen_linears": n_fp8},
             "loss_first": float(losses[0]), "loss_last": float(losses[-1]), "grad_norm_last": tr.last.get("grad_norm"),
             "loss_scale": tr.loss_scale, "applied_steps": tr.opt_step,

@@ -656,7 +656,8 @@ class ControlNetTrainer:
 
     def __init__(self, E: Engine, unet_cfg, controlnet_cfg, unet_W, controlnet_sd, *, lr: float = 1e-5, betas=(0.9, 0.999),
                  weight_decay: float = 1e-2, eps: float = 1e-8, max_grad_norm: float = 1.0, loss_scale: float = 65536.0,
-                 growth_interval: int = 2000, allreduce=None, gradient_accumulation_steps: int = 1, lr_lambda=None, gc_freeze: bool = True):
+                 growth_interval: int = 2000, allreduce=None, gradient_accumulation_steps: int = 1, lr_lambda=None, gc_freeze: bool = True,
+                 hip_graph: Optional[bool] = None):
         """``gradient_accumulation_steps``: micro-batches per optimizer step (``accelerator.accumulate`` + the 1/N loss scaling of
         ``accelerator.backward``, diffusion/train_controlnet_genima.py:1319, :1402); ``lr_lambda``: step -> multiplier of ``lr``
         (train_loop.get_scheduler = the reference's ``get_scheduler(args.lr_scheduler, ...)``, :1206-1213), advanced once per APPLIED
@@ -667,6 +668,15 @@ class ControlNetTrainer:
         # GPU sits out (rocprofv3: 3 ms of a 69 ms step).  After the second step everything alive is moved to the permanent generation
         # (gc.freeze(): never scanned again, and never collected -- call gc.unfreeze() when disposing of a trainer for good)
         self._gc_freeze, self._steps_seen = bool(gc_freeze) and os.environ.get("GN_GC_FREEZE", "1") != "0", 0
+        # ``hip_graph``: after two eager steps of a shape (autotuning, lazy weight copies of the frozen UNet) the forward + backward walk is
+        # captured ONCE into a hipGraph and replayed -- the HIP form of ``torch.compile(mode="reduce-overhead")`` for the train step: the
+        # ~2 000 launches of a step no longer wait for the Python tape (94.8 % -> ~100 % GPU-busy).  The optimizer step (host scalars: lr,
+        # Adam step, loss scale) and the front of the step (RNG draws, VAE / CLIP encode) stay eager.  Default: on, except with the
+        # bucketed gradient exchange (collectives are issued from inside the walk) -- GN_TRAIN_GRAPH=0/1 overrides.
+        env = os.environ.get("GN_TRAIN_GRAPH")
+        self._use_graph = (hip_graph if hip_graph is not None else True) if env is None else env != "0"
+        self._graphs: Dict[tuple, dict] = {}
+        self._graph_seen: Dict[tuple, int] = {}
         self.unet = FrozenParams(E, unet_W)
         self.cn = TrainParams(E, controlnet_sd)
         self.lr, self.betas, self.wd, self.eps, self.max_grad_norm = lr, betas, weight_decay, eps, max_grad_norm
@@ -755,8 +765,45 @@ class ControlNetTrainer:
     def _will_sync(self) -> bool:
         return (self._micro + 1) % self.grad_accum == 0 or self.end_of_dataloader
 
+    def _forward_backward_replayed(self, *args, added=None):
+        """forward_backward through a captured hipGraph (see ``hip_graph`` in __init__): inputs are copied into the capture's static
+        buffers, the graph is replayed on the current stream, the loss / prediction live in static outputs."""
+        if not self._use_graph or hasattr(self.allreduce, "begin"):
+            return self.forward_backward(*args, added=added)
+        flat = list(args) + (list(added) if added is not None else [])
+        key = tuple((tuple(a.shape), a.dtype) for a in flat) + (float(self.loss_scale), self.grad_accum, added is not None)
+        rec = self._graphs.get(key)
+        if rec is None:
+            seen = self._graph_seen.get(key, 0)
+            self._graph_seen[key] = seen + 1
+            if seen < 2:  # eager: tile autotuning (timed with events) and the frozen net's lazily built weight copies happen here
+                return self.forward_backward(*args, added=added)
+            E = self.E
+            static = [torch.empty_like(a) for a in flat]
+            for sbuf, a in zip(static, flat):
+                sbuf.copy_(a)
+            self.cn._wt.clear()  # derived weight copies of the trainable net are rebuilt INSIDE the graph (they change every step)
+            eager_stream = E.stream
+            graph = torch.cuda.CUDAGraph()
+            n = len(args)
+            with torch.cuda.graph(graph):
+                E.use_stream(torch.cuda.current_stream(E.device))
+                try:
+                    loss = self.forward_backward(*static[:n], added=tuple(static[n:]) if added is not None else None)
+                finally:
+                    E.use_stream(eager_stream)
+            rec = dict(graph=graph, static=static, loss=loss, pred=self.last.get("pred"))
+            self._graphs = {key: rec}  # one shape at a time: a new shape (or loss scale) drops the old capture and its memory pool
+            self.cn._wt.clear()
+        else:
+            for sbuf, a in zip(rec["static"], flat):
+                sbuf.copy_(a)
+        rec["graph"].replay()
+        self.last["pred"] = rec["pred"]
+        return rec["loss"]
+
     def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=None) -> torch.Tensor:
-        loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
+        loss = self._forward_backward_replayed(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
         self.sync_gradients = self._will_sync()
         self._micro = 0 if self.end_of_dataloader else self._micro + 1  # accelerate restarts its micro-step count with the dataloader
         if self.sync_gradients:  # gradients of the micro-batches accumulate in the flat buffer until here
