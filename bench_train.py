@@ -50,7 +50,7 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", default="buckets", choices=["buckets", "flat", "abi", "abi-bf16"],
                     help="gradient exchange: bucketed RS+AG overlapped with the backward (default), one RS+AG after it, or the C-ABI "
                          "RCCL communicator (gn_comm_*; -bf16: bf16 on the wire)")
-    ap.add_argument("--no-graph", action="store_true", help="keep the forward + backward walk eager (default: captured into one hipGraph after two steps)")
+    ap.add_argument("--graph", action="store_true", help="capture the forward + backward walk into one hipGraph after two eager steps and replay it")
     ap.add_argument("--gemm-table", default=None, help="write the per-(shape, tile) HIP-event GEMM timing table of one extra step to this CSV")
     return ap.parse_args(argv)
 
@@ -82,7 +82,7 @@ def run(args, quiet: bool = False):
         exchange = {"buckets": lambda: dist.GradBuckets(n_buckets=8), "flat": lambda: dist.allreduce_sum_flat,
                     "abi": lambda: dist.AbiComm(E, rank, world), "abi-bf16": lambda: dist.AbiComm(E, rank, world, bf16_wire=True)}[args.exchange]()
     tr = ControlNetTrainer(E, fam["unet"], fam["controlnet"], unet_W, cn_sd, lr=args.lr, allreduce=exchange,
-                           hip_graph=False if (args.no_graph or args.gemm_table) else None)
+                           hip_graph=bool(args.graph) and not args.gemm_table)
     del cn_sd
     text2_W = pack_state_dict(synth(schema.clip_text_schema(fam["text_2"]), 5), dev) if "text_2" in fam else None
     tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=1234 + rank,

@@ -671,10 +671,12 @@ class ControlNetTrainer:
         # ``hip_graph``: after two eager steps of a shape (autotuning, lazy weight copies of the frozen UNet) the forward + backward walk is
         # captured ONCE into a hipGraph and replayed -- the HIP form of ``torch.compile(mode="reduce-overhead")`` for the train step: the
         # ~2 000 launches of a step no longer wait for the Python tape (94.8 % -> ~100 % GPU-busy).  The optimizer step (host scalars: lr,
-        # Adam step, loss scale) and the front of the step (RNG draws, VAE / CLIP encode) stay eager.  Default: on, except with the
-        # bucketed gradient exchange (collectives are issued from inside the walk) -- GN_TRAIN_GRAPH=0/1 overrides.
+        # Adam step, loss scale) and the front of the step (RNG draws, VAE / CLIP encode) stay eager.  Never with the bucketed gradient
+        # exchange (collectives are issued from inside the walk).  Measured on MI355X (bench_train.py, same box, alternating): eager 66.45 /
+        # 67.9 ms, replayed 66.40 / 66.65 ms per step -- with gc_freeze the host already keeps ahead of the GPU, so the replay is
+        # insurance against a slow host, not a speed-up, and it is OPT-IN (hip_graph=True or GN_TRAIN_GRAPH=1).
         env = os.environ.get("GN_TRAIN_GRAPH")
-        self._use_graph = (hip_graph if hip_graph is not None else True) if env is None else env != "0"
+        self._use_graph = bool(hip_graph) if env is None else env != "0"
         self._graphs: Dict[tuple, dict] = {}
         self._graph_seen: Dict[tuple, int] = {}
         self.unet = FrozenParams(E, unet_W)

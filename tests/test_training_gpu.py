@@ -110,7 +110,8 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     args = (dev(nchw_to_nhwc(lat, 8).half()), dev(nchw_to_nhwc(noise, 8).half()), dev(t.float()), dev(sa), dev(s1), dev(ctx.half()),
             dev(nchw_to_nhwc(cond, 8).half()))
     unet_W = pack_state_dict(usd, "cuda")
-    a = ControlNetTrainer(Engine("cuda:0"), ucfg, ccfg, unet_W, csd, lr=1e-4, loss_scale=4096.0)
+    # trainer a replays its third step onwards from a captured hipGraph, trainer b stays eager: same kernels, same bits
+    a = ControlNetTrainer(Engine("cuda:0"), ucfg, ccfg, unet_W, csd, lr=1e-4, loss_scale=4096.0, hip_graph=True)
     a.step(*args)
     ckpt = a.save_state(str(tmp_path), 1)
     la = [float(a.step(*args).cpu()) for _ in range(2)]
@@ -118,6 +119,7 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     assert b.load_state(ckpt) == 1 and b.opt_step == 1
     lb = [float(b.step(*args).cpu()) for _ in range(2)]
     assert la == lb, (la, lb)
+    assert a._graphs and not b._graphs
     assert torch.equal(a.cn.master, b.cn.master) and torch.equal(a.cn.exp_avg_sq, b.cn.exp_avg_sq)
     # the exported diffusers ControlNet reloads into the inference host class
     from genima_amd.host import ControlNetModel
