@@ -36,7 +36,7 @@ class GemmDesc(C.Structure):
         ("out_bs", C.c_int64), ("out_bs2", C.c_int64), ("res_bs", C.c_int64), ("res_bs2", C.c_int64),
         ("accumulate", C.c_int32), ("fp8", C.c_int32), ("scale_a", C.c_void_p), ("scale_w", C.c_void_p),
         ("out2", C.c_void_p), ("ldo2", C.c_int64), ("split_n", C.c_int32),
-        ("ln_eps", C.c_float), ("ln_c1", C.c_void_p), ("chstats", C.c_void_p),
+        ("ln_eps", C.c_float), ("ln_c1", C.c_void_p),
     ]
 
 
@@ -63,7 +63,7 @@ class GroupNormDesc(C.Structure):
         ("workspace", C.c_void_p),
         ("B", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("act", C.c_int32), ("eps", C.c_float),
-        ("save_stats", C.c_void_p), ("save_scsh", C.c_void_p), ("chstats", C.c_void_p), ("chstats2", C.c_void_p),
+        ("save_stats", C.c_void_p), ("save_scsh", C.c_void_p),
     ]
 
 
@@ -87,7 +87,6 @@ SIGNATURES = {
     "gn_ctx_destroy": (_I32, [_P]),
     "gn_ctx_set_stream": (_I32, [_P, _P]),
     "gn_gemm_workspace_bytes": (_I64, [C.POINTER(GemmDesc)]),
-    "gn_gemm_chstats_band": (_I32, [C.POINTER(GemmDesc)]),
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
     "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),

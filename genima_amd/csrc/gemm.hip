@@ -718,13 +718,6 @@ extern "C" int32_t gn_set_gemm_tile_override(int32_t cfg) {
   return GN_OK;
 }
 
-extern "C" int32_t gn_gemm_chstats_band(const gn_gemm_desc* d) {
-  if (!d || d->M <= 0 || d->M % 32 != 0 || d->N % 4 != 0) return 0;
-  if (d->out_mode != GN_OUT_ROWMAJOR || d->act == GN_ACT_GEGLU || d->batch > 1 || d->fp8 || d->out2 || d->accumulate) return 0;
-  if (plan_gemm(d).splitk > 1) return 0;  // the split-K reduce kernel owns the epilogue then
-  return 32;
-}
-
 extern "C" int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d) {
   if (!d) return 0;
   Plan pl = plan_gemm(d);
@@ -763,12 +756,6 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     GN_REQUIRE(d->split_n > 0 && d->split_n < d->N && d->split_n % 32 == 0, "gn_gemm: split_n (%d) must be a multiple of 32 inside (0, N)", d->split_n);
     GN_REQUIRE(d->rows_per_batch > 0 && d->M % d->rows_per_batch == 0 && d->ldo2 >= d->rows_per_batch, "gn_gemm: out2 needs rows_per_batch | M and ldo2 >= rows_per_batch");
     GN_REQUIRE(d->N % 8 == 0 && d->ldo % 8 == 0 && ((uintptr_t)d->out & 15) == 0, "gn_gemm: out2 needs the 16-byte row-major store path for out");
-  }
-  p.chstats = d->chstats;
-  if (d->chstats) {
-    GN_REQUIRE(gn_gemm_chstats_band(d) == 32, "gn_gemm: chstats needs a plain f16 row-major problem with M %% 32 == 0 and an unsplit K "
-               "(gn_gemm_chstats_band tells)");
-    GN_REQUIRE(((uintptr_t)d->chstats & 15) == 0, "gn_gemm: chstats must be 16-byte aligned");
   }
   p.ln_c1 = d->ln_c1; p.ln_eps = d->ln_eps;
   if (d->ln_c1) {

@@ -38,7 +38,6 @@ struct GemmParams {
   int split_n;
   const float* ln_c1;                    // LayerNorm folded into the GEMM (ln_fold_apply below): per-column sums of the gamma-scaled weight
   float ln_eps;
-  float* chstats;                        // per-(32-row band, channel) sums / sums of squares of the STORED f16 values: [M / 32][2][N]
 };
 
 // batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
@@ -207,41 +206,6 @@ __device__ __forceinline__ void epilogue_tile_math(const GemmParams& p, float (&
   }
 }
 
-// Channel statistics of one stored 32 x 32 tile for the GroupNorm that reads this tensor next (gn_gemm_desc.chstats): the lane holds 16
-// channels of ONE pixel row, so a channel's sum over the tile's 32 rows is a reduction over the 32 lanes of a half-wave -- four DPP
-// steps fold each 16-lane row, row_bcast:15 adds row 0 into row 1 (row 2 into row 3): lanes 16..31 / 48..63 then hold the totals of the
-// hi = 0 / hi = 1 channel sets, and lanes 16+g / 48+g store channel group g as one float4 (sum plane, then sum-of-squares plane).
-// The values are the f16-ROUNDED ones the consumer will read; rows >= M contribute zero.  All 64 lanes must be active (wave-uniform).
-__device__ __forceinline__ float half_wave_sum(float v) {
-  v += dpp_mov<0xB1>(v);
-  v += dpp_mov<0x4E>(v);
-  v += dpp_mov<0x141>(v);
-  v += dpp_mov<0x140>(v);
-  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
-}
-// (written group by group -- 4 channels' sums and sums of squares live at a time -- so that the path costs the kernels few registers)
-__device__ __forceinline__ void epilogue_chstats(float* __restrict__ chstats, int M, int N, const float (&v)[16], int m0, int nbase32,
-                                                 int lane, bool mok) {
-  const int hi = lane >> 5, sub = lane & 15;
-  const bool writer = (lane & 16) != 0 && m0 < M;
-  float* dst = chstats + (long)(m0 >> 5) * 2 * N;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    f32x4 a, b;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float r = mok ? (float)(f16)v[4 * g + e] : 0.0f;
-      a[e] = half_wave_sum(r);
-      b[e] = half_wave_sum(r * r);
-    }
-    const int nb = nbase32 + 8 * g + 4 * hi;
-    if (writer && sub == g && nb < N) {
-      *reinterpret_cast<f32x4*>(dst + nb) = a;
-      *reinterpret_cast<f32x4*>(dst + N + nb) = b;
-    }
-  }
-}
-
 // The shift / residual vectors of one 32-column tile for this lane: channel groups g = 0..3 at columns 8 g + 4 hi + (0..3).  Row-major
 // rows whose 8-channel groups are 16-byte aligned are fetched as TWO 16-byte loads per lane instead of four 8-byte ones (the load path is
 // issue-bound like the store path): lane l takes columns 8 g .. 8 g + 7, lane l + 32 columns 8 (g + 1) .. + 7, and one
@@ -371,7 +335,6 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
         if (has_shift || has_res) load_aux1(i, j, ax[0][0]);
       }
       epilogue_tile_math(p, v, bv[RICH ? j : 0], ax[i & kOne][RICH ? j : 0], rr, a_pre, r_pre, a_post, r_post);
-      if (p.chstats) epilogue_chstats(p.chstats, p.M, p.N, v, mbase + i * 32, nbase + j * 32, l31 + 32 * hi, mok);  // wave-uniform
       if (!mok) return;
       if (p.out2 && nbase + j * 32 >= p.split_n) {  // wave-uniform: a 32-column tile never straddles split_n (split_n % 32 == 0)
         const int ml = m - bidx * p.rpb;

@@ -24,7 +24,6 @@ struct GNParams {
   int B, HW, C1, C2, C, G, cpg, chunks, rows, achunks, arows, act;
   float eps;
   int save_scsh;    // scsh is a caller buffer that has to be filled (training), not the workspace scratch of the 3-launch path
-  const float* chs1; const float* chs2;  // producer statistics [B * HW / 32][2][C1] / [..][2][C2] (gn_gemm_desc.chstats)
 };
 
 // (channel-chunk, pixel-lane) thread mapping shared by the stats and apply kernels: TX = min(C/8, 256) lanes walk the
@@ -124,52 +123,6 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const GNParams p) {
     ms[0] = (float)mean;
     ms[1] = (float)(1.0 / sqrt(var + (double)p.eps));
     if (p.stats) {  // training: keep (mean, rstd) per (batch, group) for the backward pass
-      p.stats[((long)b * p.G + g) * 2] = ms[0];
-      p.stats[((long)b * p.G + g) * 2 + 1] = ms[1];
-    }
-  }
-  __syncthreads();
-  for (int ci = tid; ci < p.cpg; ci += 256) {
-    const int c = g * p.cpg + ci;
-    const float a = ms[1] * (float)p.gamma[c];
-    float* o = p.scsh + ((long)b * p.C + c) * 2;
-    o[0] = a;
-    o[1] = (float)p.beta[c] - ms[0] * a;
-  }
-}
-
-__global__ __launch_bounds__(256) void gn_finalize_ch_kernel(const GNParams p) {
-  // statistics from the producers' epilogues: one workgroup per (group, sample) sums the (32-row band, channel) partials of the group's
-  // channels -- thread t takes items t, t + 256, ... in f64, the 256 partial sums are combined in a fixed order -> deterministic
-  __shared__ double dsum[256], dsq[256];
-  __shared__ float ms[2];
-  const int tid = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
-  const int bands = p.HW >> 5;
-  const long band0 = (long)b * bands;
-  double s = 0.0, ss = 0.0;
-  const int items = bands * p.cpg;
-  for (int it = tid; it < items; it += 256) {
-    const int band = it / p.cpg, c = g * p.cpg + (it - band * p.cpg);
-    const float* src;
-    int cs, co;
-    if (c < p.C1) { src = p.chs1; cs = p.C1; co = c; } else { src = p.chs2; cs = p.C2; co = c - p.C1; }
-    const float* row = src + (band0 + band) * 2 * cs;
-    s += (double)row[co];
-    ss += (double)row[cs + co];
-  }
-  dsum[tid] = s;
-  dsq[tid] = ss;
-  __syncthreads();
-  if (tid == 0) {
-    double ts = 0.0, tss = 0.0;
-    for (int q = 0; q < 256; ++q) { ts += dsum[q]; tss += dsq[q]; }
-    const double n = (double)p.HW * (double)p.cpg;
-    const double mean = ts / n;
-    double var = tss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    ms[0] = (float)mean;
-    ms[1] = (float)(1.0 / sqrt(var + (double)p.eps));
-    if (p.stats) {
       p.stats[((long)b * p.G + g) * 2] = ms[0];
       p.stats[((long)b * p.G + g) * 2 + 1] = ms[1];
     }
@@ -438,12 +391,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.stats = (float*)d->save_stats;
   if (d->save_scsh) p.scsh = (float*)d->save_scsh;  // training: persistent per-(b, c) scale/shift for the backward pass
   p.save_scsh = d->save_scsh != nullptr;
-  p.chs1 = d->chstats; p.chs2 = d->chstats2;
-  const bool from_producers = d->chstats != nullptr;
-  if (from_producers) {
-    GN_REQUIRE(d->HW % 32 == 0 && (d->C2 == 0) == (d->chstats2 == nullptr), "gn_groupnorm_fwd: chstats need HW %% 32 == 0 and one buffer per source");
-  }
-  if (!from_producers) {  // single-launch path when a (batch, group) slab fits in LDS
+  {  // single-launch path when a (batch, group) slab fits in LDS
     static int fused_ok = -1;
     static long fused_max = GNF_MAX_LDS;
     if (fused_ok < 0) {
@@ -473,15 +421,10 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
     p.arows = (int)cdiv64(d->HW, ac);
     p.achunks = (int)cdiv64(d->HW, p.arows);
   }
-  if (from_producers) {
-    hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
-    GN_LAUNCH_CHECK();
-  } else {
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
-    GN_LAUNCH_CHECK();
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
-    GN_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
+  GN_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
+  GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_apply_kernel, dim3(p.achunks, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;

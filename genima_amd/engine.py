@@ -93,11 +93,6 @@ class Engine:
         self.buffers: Dict[str, torch.Tensor] = {}
         self._keep = []  # tensors referenced by recorded ops
         self._scope = []
-        # GroupNorm statistics from the producing conv / Linear (gn_gemm_desc.chstats), recorded programs only (their buffers are persistent
-        # and written by ONE op site each): output data_ptr -> (stats tensor, M, N) of the launch that last wrote it
-        self._chstats = {}
-        self._chstats_bufs = {}
-        self.gn_stats_min_bytes = int(os.environ.get("GN_STATS_MIN_BYTES", str(8 << 20)))  # 0 = never; tensors below this keep the fused GN
         self.captured = False
         self.meta = []  # per recorded op: dict(kind, flops, bytes) -- algorithmic work for the roofline accounting
 
@@ -138,7 +133,6 @@ class Engine:
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self.buffers[key] = t
-        self._chstats.pop(t.data_ptr(), None)  # whoever asks for this buffer is about to overwrite it
         return t
 
     def _keepalive(self, *ts):
@@ -266,22 +260,10 @@ class Engine:
         _tune_dirty[0] = True
         return best
 
-    def _gemm(self, d: GemmDesc, keep, stats: bool = False):
+    def _gemm(self, d: GemmDesc, keep):
         if d.tile == 0 and d.splitk == 0:
             # autotuning engines measure unknown shapes; every engine uses a tile that was already measured on this architecture
             self.apply_plan(d, self._autotune(d) if self.autotune else (0 if getattr(self, "no_table", False) else _tune_table().get(self._tune_key(d), 0)))
-        if self.record:
-            self._chstats.pop(d.out, None)
-            nbytes = 2 * int(d.M) * int(d.N)
-            if stats and self.gn_stats_min_bytes > 0 and nbytes >= self.gn_stats_min_bytes and int(self.lib.gn_gemm_chstats_band(C.byref(d))) == 32:
-                # the next GroupNorm reads this tensor: its statistics come out of this launch's epilogue (no second pass over the tensor)
-                key = (d.out, int(d.M), int(d.N))
-                st = self._chstats_bufs.get(key)
-                if st is None:
-                    st = self._chstats_bufs[key] = torch.empty((int(d.M) // 32, 2, int(d.N)), dtype=torch.float32, device=self.device)
-                d.chstats = st.data_ptr()
-                self._chstats[d.out] = (st, int(d.M), int(d.N))
-                keep = tuple(keep) + (st,)
         ws_bytes = int(self.lib.gn_gemm_workspace_bytes(C.byref(d)))
         ws = None
         if ws_bytes > 0:
@@ -360,8 +342,7 @@ class Engine:
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
                transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0,
-               split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-               stats: bool = False):
+               split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5):
         """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
         transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel).
         split_n > 0: ONE launch with two destinations (the q | k | v projections of a self-attention block): columns [0, split_n)
@@ -407,7 +388,7 @@ class Engine:
         if ln_c1 is not None:
             assert bias is not None and ln_c1.dtype == torch.float32 and ln_c1.numel() == N and not transposed_out
             d.ln_c1, d.ln_eps = _ptr(ln_c1), float(ln_eps)
-        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1), stats=stats)
+        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1))
         return (out, out2) if split_n else out
 
     # ---- fp8 (OCP e4m3) Linear: SURVEY section 8 a15 / BASELINE configs[4] "fp8 MFMA" -------------------------------------------
@@ -474,8 +455,8 @@ class Engine:
                stride: int = 1, pad: Tuple[int, int, int, int] = None, x2: Optional[torch.Tensor] = None,
                shift: Optional[torch.Tensor] = None, ldshift: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
-               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False, stats: bool = False) -> torch.Tensor:
-        """NHWC conv.  ``stats``: a GroupNorm reads the output next -- let the epilogue emit its channel statistics (recorded programs).  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
+               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False) -> torch.Tensor:
+        """NHWC conv.  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
         pad = (top, left, bottom, right); default k//2 all round.  shift: [B, ldshift or Cout] per-batch channel shift."""
         B, H, W, C1 = x.shape
         C2 = x2.shape[-1] if x2 is not None else 0
@@ -500,7 +481,7 @@ class Engine:
         d.upsample2x, d.act, d.out_mode, d.rows_per_batch, d.splitk, d.out_scale = (int(upsample2x), act, OUT_ROWMAJOR,
                                                                                      Ho * Wo, splitk, out_scale)
         d.residual_before_act = int(residual_before_act)
-        self._gemm(d, (x, x2, w, bias, shift, residual, out), stats=stats)
+        self._gemm(d, (x, x2, w, bias, shift, residual, out))
         return out
 
     # ------------------------------------------------------------------------------------------------ weight repacking (gn_pack_*)
@@ -567,15 +548,6 @@ class Engine:
         d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, C1, C2, groups, act, eps
         ws = self._workspace(int(self.lib.gn_groupnorm_workspace_bytes(C.byref(d))))
         d.workspace = ws.data_ptr()
-        if self.record and HW % 32 == 0:  # statistics the producers already took (conv2d / linear with stats=True)
-            s1 = self._chstats.get(x.data_ptr())
-            s2 = self._chstats.get(x2.data_ptr()) if x2 is not None else None
-            ok1 = s1 is not None and s1[1:] == (B * HW, C1)
-            ok2 = x2 is None or (s2 is not None and s2[1:] == (B * HW, C2))
-            if ok1 and ok2:
-                d.chstats = s1[0].data_ptr()
-                d.chstats2 = s2[0].data_ptr() if x2 is not None else None
-                self._keepalive(s1[0], s2[0] if x2 is not None else None)
         if self.record:
             check(self.lib.gn_program_add_groupnorm(self._prog, C.byref(d)), "gn_program_add_groupnorm")
             self._keepalive(x, x2, gamma, beta, out, ws)

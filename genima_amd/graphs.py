@@ -87,12 +87,11 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
             sc = x
         h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, act=ACT_SILU, x2=x2, name="n1")
         sh, ld = _shift_for(W, shifts, p) if (p + ".time_emb_proj.weight") in W else (None, 0)
-        # stats=True: the GroupNorm that reads this output takes its statistics from this launch's epilogue (large tensors, recorded programs)
-        h = E.conv2d(h, W[p + ".conv1.weight"], W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1", stats=True)
+        h = E.conv2d(h, W[p + ".conv1.weight"], W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
         h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
         if side:
             E.join()
-        return E.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], residual=sc, name="c2", stats=True)
+        return E.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], residual=sc, name="c2")
 
 
 def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
@@ -170,7 +169,7 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     g = E.linear(n, W[b + ".ff.net.0.proj.weight"], W[b + ".ff.net.0.proj.bias"], act=ACT_GEGLU, name="ffg")
                 h = E.linear(g, W[b + ".ff.net.2.weight"], W[b + ".ff.net.2.bias"], residual=h, name="ffo")
             k += 1
-        out = E.linear(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"], residual=x.view(B, N, Cc), name="pout", stats=True)
+        out = E.linear(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"], residual=x.view(B, N, Cc), name="pout")
         return out.view(B, H, Wd, Cc)
 
 
@@ -186,7 +185,7 @@ def _emit_encoder(E: Engine, W, cfg, h, shifts, kv):
             skips.append(h)
         if i != nlev - 1:
             p = f"down_blocks.{i}.downsamplers.0.conv"
-            h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, name=p, stats=True)
+            h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], stride=2, name=p)
             skips.append(h)
     return h, skips
 
@@ -206,7 +205,7 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
     G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     with E.scope("unet"):
         shifts = emit_time_shifts(E, W, cfg, t_dev, added)
-        h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], name="conv_in", stats=True)
+        h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         h = _emit_mid(E, W, cfg, h, shifts, kv)
         if before_residuals is not None:
@@ -225,7 +224,7 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
                     h = emit_transformer(E, W, f"up_blocks.{i}.attentions.{j}", h, kv, _heads(cfg, nlev - 1 - i), G)
             if i != nlev - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p, stats=True)
+                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
         E.side_free = False
         h = E.groupnorm(h, W["conv_norm_out.weight"], W["conv_norm_out.bias"], G, eps, act=ACT_SILU, name="norm_out")
         return E.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], name="conv_out")
@@ -247,7 +246,7 @@ def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, co
     """-> (list of down residuals (12 for SD-2.x, 9 for SDXL), mid residual), NHWC."""
     with E.scope("cn"):
         shifts = emit_time_shifts(E, W, cfg, t_dev, added)
-        h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], residual=cond_emb, name="conv_in", stats=True)
+        h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], residual=cond_emb, name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         h = _emit_mid(E, W, cfg, h, shifts, kv)
         outs = []
@@ -283,7 +282,7 @@ def _emit_vae_attention(E: Engine, W, p: str, x, groups: int):
             E.linear(q[b], k[b], out=s[:, :N] if Np == N else s[:, :N])
             E.softmax_rows(s[:, :N], float(Cc) ** -0.5)
             E.linear(s[:, :N], vt[b][:, :N], out=a[b])
-        o = E.linear(a, W[p + ".to_out.0.weight"], W[p + ".to_out.0.bias"], residual=x.view(B, N, Cc), name="o", stats=True)
+        o = E.linear(a, W[p + ".to_out.0.weight"], W[p + ".to_out.0.bias"], residual=x.view(B, N, Cc), name="o")
         return o.view(B, H, Wd, Cc)
 
 
@@ -299,14 +298,14 @@ def emit_vae_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
     n = len(cfg["block_out_channels"])
     with E.scope("vae_dec"):
         h = E.conv2d(z8, W["post_quant_conv.weight"], W["post_quant_conv.bias"], ksize=1, name="pq")
-        h = E.conv2d(h, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"], name="conv_in", stats=True)
+        h = E.conv2d(h, W["decoder.conv_in.weight"], W["decoder.conv_in.bias"], name="conv_in")
         h = _emit_vae_mid(E, W, "decoder.mid_block", h, G)
         for i in range(n):
             for j in range(cfg["layers_per_block"] + 1):
                 h = emit_resnet(E, W, f"decoder.up_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6, eps_in=_vae_eps(W))
             if i != n - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p, stats=True)
+                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
         h = E.groupnorm(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, _vae_eps(W), act=ACT_SILU, name="norm_out")
         return E.conv2d(h, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], name="conv_out")
 

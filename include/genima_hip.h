@@ -109,14 +109,7 @@ typedef struct gn_gemm_desc {
    * GEGLU, residual, out2 ...).  Dense f16 Linears on the LDS-DMA tiles (7..14, 16..23); K is never split.  NULL = off. */
   float ln_eps;
   const float* ln_c1;
-  /* GroupNorm statistics out of the producing conv / Linear (the ResnetBlock2D convs and Transformer2DModel.proj_out whose output the
-   * next GroupNorm reads: torch native_group_norm's statistics pass in the reference): f32 [M / 32][2][N] -- for every
-   * band of 32 output rows the per-channel sum (plane 0) and sum of squares (plane 1) of the f16 values this launch STORES, written by
-   * the epilogue in a fixed order (no atomics).  gn_groupnorm_desc.chstats consumes it.  Plain row-major f16 output, M % 32 == 0,
-   * unsplit K (gn_gemm_chstats_band(d) == 32; 0 = this problem cannot produce them).  NULL = off. */
-  float* chstats;
 } gn_gemm_desc;
-int32_t gn_gemm_chstats_band(const gn_gemm_desc* d);
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
 int32_t gn_set_gemm_tile_override(int32_t cfg);
@@ -178,10 +171,6 @@ typedef struct gn_groupnorm_desc {
   float eps;
   void* save_stats;                  /* training: optional f32 [B][groups][2] (mean, rstd) kept for gn_groupnorm_bwd */
   void* save_scsh;                   /* training: optional f32 [B][C][2] per-(b, c) scale/shift kept for gn_groupnorm_bwd */
-  /* statistics already taken by the producers of x / x2 (gn_gemm_desc.chstats: f32 [B * HW / 32][2][C1] and [..][2][C2]; HW % 32 == 0):
-   * the statistics pass is skipped -- a finalize over the band sums + the coalesced apply, i.e. the tensor is read once and written
-   * once.  Both must be given when x2 is.  NULL = take the statistics here. */
-  const float* chstats; const float* chstats2;
 } gn_groupnorm_desc;
 int64_t gn_groupnorm_workspace_bytes(const gn_groupnorm_desc* d);
 int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d);
