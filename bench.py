@@ -41,6 +41,8 @@ HBM_PEAK_GBS = 8000.0
 WORKLOADS = {
     # name: (B per GPU, H, W, description)
     "tiled_b8": (8, 512, 512, "BASELINE.json configs[2]: SD-Turbo + ControlNet 4-view tiled 512x512, 5 steps, batch=8 episodes"),
+    "tiled_b4": (4, 512, 512, "SD-Turbo + ControlNet 4-view tiled 512x512, 5 steps, batch=4 episodes"),
+    "tiled_b2": (2, 512, 512, "SD-Turbo + ControlNet 4-view tiled 512x512, 5 steps, batch=2 episodes"),
     "tiled_b1": (1, 512, 512, "SD-Turbo + ControlNet 4-view tiled 512x512, 5 steps, batch=1 episode"),
     "single_b1": (1, 256, 256, "BASELINE.json configs[1]: SD-Turbo + ControlNet 256x256 single view, 5 steps, batch=1"),
 }

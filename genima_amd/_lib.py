@@ -67,17 +67,6 @@ class GroupNormDesc(C.Structure):
     ]
 
 
-class XAttnDesc(C.Structure):
-    _fields_ = [
-        ("x", C.c_void_p), ("wq", C.c_void_p), ("ln_c1", C.c_void_p), ("ln_c2", C.c_void_p),
-        ("k", C.c_void_p), ("vt", C.c_void_p), ("o", C.c_void_p),
-        ("x_rs", C.c_int64), ("w_rs", C.c_int64), ("o_rs", C.c_int64), ("k_bs", C.c_int64), ("k_rs", C.c_int64), ("vt_bs", C.c_int64),
-        ("vt_rs", C.c_int64),
-        ("B", C.c_int32), ("Nq", C.c_int32), ("C", C.c_int32), ("heads", C.c_int32), ("Nk", C.c_int32),
-        ("scale", C.c_float), ("ln_eps", C.c_float),
-    ]
-
-
 class WgradDesc(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
@@ -178,8 +167,6 @@ SIGNATURES = {
     "gn_program_destroy": (_I32, [_P]),
     "gn_program_add_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
     "gn_program_add_attention": (_I32, [_P, C.POINTER(AttnDesc)]),
-    "gn_cross_attention": (_I32, [_P, C.POINTER(XAttnDesc)]),
-    "gn_program_add_cross_attention": (_I32, [_P, C.POINTER(XAttnDesc)]),
     "gn_program_add_groupnorm": (_I32, [_P, C.POINTER(GroupNormDesc)]),
     "gn_program_add_layernorm": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F]),
     "gn_program_add_timestep_embedding": (_I32, [_P, _P, _P, _I32, _I32, _I32, _F]),

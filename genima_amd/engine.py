@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR,
-                   AttnDesc, GemmDesc, GenimaHipError, GroupNormDesc, XAttnDesc, check)
+                   AttnDesc, GemmDesc, GenimaHipError, GroupNormDesc, check)
 
 F16 = torch.float16
 
@@ -531,30 +531,6 @@ class Engine:
             self.meta.append(dict(kind="attention", flops=fl, bytes=2.0 * B * Cq * (2 * Nq + 2 * Nk), shape=(B, heads, Nq, Nk, D)))
         else:
             check(self.lib.gn_attention_fwd(self._ctx, C.byref(d)), "gn_attention_fwd")
-        return out
-
-    def cross_attention(self, x: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, Nk: int, *, wq: Optional[torch.Tensor] = None,
-                        ln_c1: Optional[torch.Tensor] = None, ln_c2: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-                        out: Optional[torch.Tensor] = None, name: Optional[str] = None) -> torch.Tensor:
-        """Cross-attention on the prompt's (<= 96) keys in ONE launch (csrc/xattn.hip), head dim 64, Nq % 128 == 0.
-        x: [B, Nq, C] -- q itself, or (with ``wq`` = the gamma-folded to_q weight + ln_c1 / ln_c2, packing.fold_layernorms) the RAW
-        residual rows: LayerNorm -> to_q -> softmax(q K^T / 8) V without q ever reaching memory.  k [B, >= Nk, C], vt [B, C, >= Nk]."""
-        B, Nq, Cc = x.shape
-        if out is None:
-            out = self.buf(name, (B, Nq, Cc))
-        d = XAttnDesc()
-        d.x, d.wq, d.ln_c1, d.ln_c2, d.k, d.vt, d.o = _ptr(x), _ptr(wq), _ptr(ln_c1), _ptr(ln_c2), _ptr(k), _ptr(vt), _ptr(out)
-        d.x_rs, d.w_rs, d.o_rs = x.stride(1), (wq.stride(0) if wq is not None else 0), out.stride(1)
-        d.k_bs, d.k_rs, d.vt_bs, d.vt_rs = k.stride(0), k.stride(1), vt.stride(0), vt.stride(1)
-        d.B, d.Nq, d.C, d.heads, d.Nk, d.scale, d.ln_eps = B, Nq, Cc, heads, Nk, 64.0 ** -0.5, ln_eps
-        assert x.stride(0) == Nq * x.stride(1) and out.stride(0) == Nq * out.stride(1), "rows of all samples must form one [B * Nq] sequence"
-        if self.record:
-            check(self.lib.gn_program_add_cross_attention(self._prog, C.byref(d)), "gn_program_add_cross_attention")
-            self._keepalive(x, wq, ln_c1, ln_c2, k, vt, out)
-            fl = 4.0 * B * heads * Nq * Nk * 64 + (2.0 * B * Nq * Cc * Cc if wq is not None else 0.0)
-            self.meta.append(dict(kind="cross_attention", flops=fl, bytes=2.0 * 2 * B * Nq * Cc, shape=(B, heads, Nq, Nk, 64)))
-        else:
-            check(self.lib.gn_cross_attention(self._ctx, C.byref(d)), "gn_cross_attention")
         return out
 
     # ------------------------------------------------------------------------------------------------ norms

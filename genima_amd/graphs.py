@@ -153,21 +153,13 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
                 h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
                 fold = _ln_fold(E, W, b + ".attn2.to_q")
-                ck, cvt = kv[b + ".attn2"]
-                # the prompt's 77 keys are ONE tile: LayerNorm -> to_q -> attention as a single launch (csrc/xattn.hip), q never stored
-                xa = getattr(E, "fused_xattn", True) and Cc // heads == 64 and N % 128 == 0 and ck.shape[1] <= 96 and h.is_contiguous()
-                if fold and xa:
-                    a = E.cross_attention(h, ck, cvt, heads, ck.shape[1], wq=fold[0], ln_c1=fold[1], ln_c2=fold[2], name="ca")
+                if fold:
+                    q = E.linear(h, fold[0], fold[2], ln_c1=fold[1], name="cq")
                 else:
-                    if fold:
-                        q = E.linear(h, fold[0], fold[2], ln_c1=fold[1], name="cq")
-                    else:
-                        n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")
-                        q = E.linear(n, W[b + ".attn2.to_q.weight"], name="cq")
-                    if xa:
-                        a = E.cross_attention(q, ck, cvt, heads, ck.shape[1], name="ca")
-                    else:
-                        a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                    n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")
+                    q = E.linear(n, W[b + ".attn2.to_q.weight"], name="cq")
+                ck, cvt = kv[b + ".attn2"]
+                a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
                 h = E.linear(a, W[b + ".attn2.to_out.0.weight"], W[b + ".attn2.to_out.0.bias"], residual=h, name="cao")
                 fold = _ln_fold(E, W, b + ".ff.net.0.proj")
                 if fold:

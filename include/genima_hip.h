@@ -157,24 +157,6 @@ typedef struct gn_attn_bwd_desc {
 } gn_attn_bwd_desc;
 int32_t gn_attention_bwd(gn_ctx* ctx, const gn_attn_bwd_desc* d);
 
-/* ---- K5x: cross-attention on the prompt's short key sequence, optionally with LayerNorm + to_q in front (one launch) ------------------
- * diffusers BasicTransformerBlock: ``attn2(norm2(h), encoder_hidden_states)`` up to (not including) ``to_out`` -- in the reference a
- * LayerNorm kernel, the ``to_q`` cuBLAS call and one SDPA launch per block (call site of the whole pipeline:
- * controller/agent/sd_controlnet_agent.py:67-76).  Head dim 64, Nk <= 96 (CLIP's 77 tokens), Nq % 128 == 0.
- *   wq == NULL: x holds q [B * Nq, x_rs] (head h at columns 64 h ..);  o = softmax(q K^T * scale) V.
- *   wq != NULL: x holds the RAW residual rows; wq [C, w_rs] the gamma-scaled to_q weight, ln_c1 f32 [C] its column sums, ln_c2 f16 [C]
- *               the folded bias (packing.fold_layernorms, as gn_gemm_desc.ln_c1): q = rstd * (x . wq^T - mean * c1) + c2 is formed in
- *               registers and never stored.
- * k [B][>= Nk rows][k_rs] (head h at columns 64 h ..), vt [B][C][vt_rs] = V transposed (vt_rs >= Nk); o [B * Nq, o_rs]. */
-typedef struct gn_xattn_desc {
-  const void* x; const void* wq; const float* ln_c1; const void* ln_c2;
-  const void* k; const void* vt; void* o;
-  int64_t x_rs, w_rs, o_rs, k_bs, k_rs, vt_bs, vt_rs;
-  int32_t B, Nq, C, heads, Nk;
-  float scale, ln_eps;
-} gn_xattn_desc;
-int32_t gn_cross_attention(gn_ctx* ctx, const gn_xattn_desc* d);
-
 /* ---- K2: GroupNorm(+SiLU), NHWC --------------------------------------------------------------------------------
  * y = act(GroupNorm_G(cat(x, x2)) * gamma + beta).  Three launches: coalesced partial statistics over pixel slabs, a finalize
  * that folds (mean, rstd, gamma, beta) into per-(b, c) scale/shift, and a coalesced apply.  Replaces torch
@@ -364,7 +346,6 @@ int32_t gn_program_destroy(gn_program* p);
 int32_t gn_program_add_gemm(gn_program* p, const gn_gemm_desc* d);
 int32_t gn_program_add_attention(gn_program* p, const gn_attn_desc* d);
 int32_t gn_program_add_groupnorm(gn_program* p, const gn_groupnorm_desc* d);
-int32_t gn_program_add_cross_attention(gn_program* p, const gn_xattn_desc* d);
 int32_t gn_program_add_layernorm(gn_program* p, const void* x, const void* gamma, const void* beta, void* y, int64_t M,
                                  int32_t C, float eps);
 int32_t gn_program_add_timestep_embedding(gn_program* p, const float* t, void* out, int32_t B, int32_t dim,
