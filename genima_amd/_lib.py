@@ -10,6 +10,8 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libgenima_hip.so")
+if os.environ.get("GN_LIB_PATH"):  # same-box A/B of library builds (tools/probes): an explicit path to another libgenima_hip.so
+    LIB_PATH = os.environ["GN_LIB_PATH"]
 
 # enums of genima_hip.h
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_QUICK_GELU, ACT_RELU, ACT_GEGLU, ACT_TANH3 = 0, 1, 2, 3, 4, 5, 6

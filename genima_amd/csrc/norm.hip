@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
 // ControlNet levels, where the three dependent launches (~6 us each of launch + ramp + tail) cost more than the data movement.
 // Deterministic: fixed thread -> element mapping and a fixed-order block reduction.
 constexpr int GNF_THREADS = 512;
+#ifndef GNF_U
+#define GNF_U 8   // independent loads in flight per thread and trip of the load phase
+#endif
 constexpr int GNF_MAX_LDS = 96 * 1024;  // measured (tools/probes/gn_bench.py): with the XCD-aware group order an 80 KB slab per CU
                                         // (320 ch @ 64x64: 22.4 vs 26.6 us; 1280 ch @ 32x32: 16.1 vs 25.6 us) beats the 3-launch path
 
@@ -219,12 +222,12 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(const GNParams p)
     // a group's channels are only 4-byte aligned inside a pixel (cpg * 2 bytes at offset g * cpg * 2), so the loads stay 4 bytes
     // wide; what the loop needs is many of them in flight: 8 independent loads per thread and trip
     int r = p0;
-    for (; r + 7 * pstep < p.HW; r += 8 * pstep) {
-      unsigned int raw[8];
+    for (; r + (GNF_U - 1) * pstep < p.HW; r += GNF_U * pstep) {
+      unsigned int raw[GNF_U];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) raw[u] = *reinterpret_cast<const unsigned int*>(src + (long)(r + u * pstep) * cs);
+      for (int u = 0; u < GNF_U; ++u) raw[u] = *reinterpret_cast<const unsigned int*>(src + (long)(r + u * pstep) * cs);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < GNF_U; ++u) {
         slab[(r + u * pstep) * hpg + j] = raw[u];
         const f16x2 v = *reinterpret_cast<const f16x2*>(&raw[u]);
         const float a = (float)v[0], bb = (float)v[1];
