@@ -222,3 +222,49 @@ def test_full_size_sdxl_train_step_with_and_without_fp8():
     e = float((g8.double() - g16.double()).norm() / g16.double().norm())
     print(f"full-size SDXL-Turbo step: loss f16 {l16:.5f} fp8 {l8:.5f}; |g| f16 {n16:.4f} fp8 {n8:.4f}; ControlNet gradient rel-L2 fp8 vs f16 {e:.3f}")
     assert abs(l8 - l16) <= 3e-2 * l16 and 1e-4 < e < 0.35
+
+
+def test_full_size_pix2pix_train_step():
+    """The InstructPix2Pix fine-tune step at full SD-Turbo width (865.9 M trainable parameters + the 8-channel conv_in, EMA on), batch 2 at
+    256x256 (diffusion/train_instruct_pix2pix_genima.py:1165-1273): finite, bit-reproducible from the seeds, every parameter reached --
+    including the decoder's concat / upsample convs whose weight gradients only this trainer needs."""
+    from genima_amd.engine import Engine
+    from genima_amd.packing import pack_state_dict
+    from genima_amd.pix2pix import InstructPix2PixTrainer, expand_conv_in
+    from genima_amd.scheduler import DDPMScheduler
+
+    dev = torch.device("cuda")
+    fam = configs.family("sd-turbo-pix2pix")
+    B, R, V = 2, 256, fam["text"]["vocab_size"]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    px = torch.zeros(B, R, R, 8, dtype=torch.float16, device="cuda")
+    px[..., :3] = (torch.rand(B, R, R, 3, generator=g, device="cuda") * 2 - 1).half()
+    orig = torch.zeros_like(px)
+    orig[..., :3] = (torch.rand(B, R, R, 3, generator=g, device="cuda") * 2 - 1).half()
+    ids = torch.zeros(B, 77, dtype=torch.int32)
+    ids[:, :14] = torch.tensor([V - 2] + [320 + i for i in range(12)] + [V - 1], dtype=torch.int32)
+    null = torch.zeros(1, 77, dtype=torch.int32)
+    null[0, :2] = torch.tensor([V - 2, V - 1], dtype=torch.int32)
+    batch = dict(edited_pixel_values=px, original_pixel_values=orig, input_ids=ids.cuda())
+    vae_W = pack_state_dict(weights.synth_state_dict(schema.vae_schema(fam["vae"]), 3, device=dev), dev)
+    text_W = pack_state_dict(weights.synth_state_dict(schema.clip_text_schema(fam["text"]), 4, device=dev), dev)
+    runs = []
+    for seed in (11, 11):
+        base = weights.synth_state_dict(schema.unet_schema(dict(fam["unet"], in_channels=4)), 1, device=dev)
+        usd = expand_conv_in(base, 8)
+        usd["conv_in.weight"][:, 4:] = 0.01  # live image-latent channels (the reference starts them at zero)
+        tr = InstructPix2PixTrainer(Engine(dev), fam["unet"], usd, lr=1e-5, use_ema=True, conditioning_dropout_prob=0.05)
+        del base, usd
+        tr.attach_frozen(fam["vae"], vae_W, fam["text"], text_W, DDPMScheduler(), seed=seed)
+        tr.set_null_prompt(null)
+        loss = float(tr.train_step(batch))
+        runs.append((loss, tr.cn.exp_avg.clone(), tr.last.get("grad_norm"), dict(tr.cn.layout), int(tr.cn.numel), tr.ema_steps))
+        del tr
+        torch.cuda.empty_cache()
+    (l0, g0, n0, layout, numel, es), (l1, g1, n1, _, _, _) = runs
+    print(f"full-size InstructPix2Pix step: loss {l0:.4f}, grad norm {n0}, {numel / 1e6:.1f} M trainable (padded) parameters")
+    assert np.isfinite(l0) and 0.1 < l0 < 10.0 and es == 1
+    assert l0 == l1 and n0 == n1 and torch.equal(g0, g1), "the step must be bit-reproducible"
+    assert 8.6e8 < numel < 8.8e8
+    dead = [name for name, (off, shape) in layout.items() if float(g0[off:off + int(np.prod(shape))].abs().max()) == 0.0]
+    assert not dead, f"parameters without gradient: {dead[:5]}"

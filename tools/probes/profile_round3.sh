@@ -1,0 +1,25 @@
+# Round-3 evidence run (one MI355X): the driver's bench line, rocprofv3 kernel stats + busy windows of the same commands, per-shape op
+# tables (tiled B = 8, tiled B = 1, single view B = 1), train steps (SD-Turbo, SDXL +- fp8), microbenches, PMC traffic (stamped with the
+# commit passed in GIT_COMMIT and the library hash).  Summaries are copied to profiles/r03_v<N>_*.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r03; rm -rf $O; mkdir -p $O
+cd $R
+python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_full.json 2> $O/bench_full.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/inf -o b8 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-train --no-single-view > $O/inf.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t8 -- python bench_train.py --steps 5 --warmup 2 > $O/train.log 2>&1
+python tools/probes/trace_window.py $O/train 360 5 > $O/train_window.txt
+python tools/probes/trace_window.py $O/inf 300 3 > $O/inf_window.txt
+python bench_train.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/train_bench.json
+python bench_train.py --steps 10 --warmup 3 --graph 2>/dev/null | tail -1 > $O/train_bench_graph.json
+python bench_train.py --family sdxl-turbo 2>/dev/null | tail -1 > $O/train_sdxl.json
+python bench_train.py --family sdxl-turbo --fp8 2>/dev/null | tail -1 > $O/train_sdxl_fp8.json
+python bench.py --dump-ops $O/ops_b8.csv --no-cpu-baseline --no-train --no-single-view > /dev/null 2>&1
+python bench.py --workload tiled_b1 --dump-ops $O/ops_tiled_b1.csv --no-cpu-baseline --no-train --no-single-view > /dev/null 2>&1
+python bench.py --workload single_b1 --dump-ops $O/ops_b1.csv --no-cpu-baseline --no-train --no-single-view > /dev/null 2>&1
+for w in tiled_b1 tiled_b2 tiled_b4 tiled_b8; do python bench.py --workload $w --steps 10 --warmup 3 --no-train --no-cpu-baseline --no-single-view --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('$w', round(d['ms_per_step'],2), 'ms per call,', round(d['value'],1), 'img/s')"; done > $O/batch_sweep.txt
+python tools/probes/split_batch.py 2 2>/dev/null | grep -v amdgpu > $O/split_batch.txt
+python tools/bench_attn.py 2>/dev/null > $O/attn.txt
+python tools/probes/gn_bench.py 2>/dev/null | grep groupnorm > $O/gn_bench.txt
+rm -f $O/inf/*kernel_trace.csv $O/train/*kernel_trace.csv $O/inf/*/*kernel_trace.csv $O/train/*/*kernel_trace.csv
+bash tools/probes/pmc_traffic.sh > $O/pmc.log 2>&1; cp gpurun_out/pmc_traffic/traffic.json $O/pmc_traffic.json
+find $O -name "*stats.csv" | head; tail -c 300 $O/bench_full.json | head -c 250; echo; cut -c1-160 $O/train_bench.json; cat $O/batch_sweep.txt; tail -3 $O/pmc.log
