@@ -7,8 +7,8 @@ cd $R
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_full.json 2> $O/bench_full.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/inf -o b8 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-train --no-single-view > $O/inf.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/train -o t8 -- python bench_train.py --steps 5 --warmup 2 > $O/train.log 2>&1
-python tools/probes/trace_window.py $O/train 360 5 > $O/train_window.txt
-python tools/probes/trace_window.py $O/inf 300 3 > $O/inf_window.txt
+python tools/probes/trace_window.py $O/train 360 4 adamw_kernel > $O/train_window.txt
+python tools/probes/trace_window.py $O/inf 300 3 image_f16_to_u8_kernel > $O/inf_window.txt
 python bench_train.py --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/train_bench.json
 python bench_train.py --steps 10 --warmup 3 --graph 2>/dev/null | tail -1 > $O/train_bench_graph.json
 python bench_train.py --family sdxl-turbo 2>/dev/null | tail -1 > $O/train_sdxl.json

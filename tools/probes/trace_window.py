@@ -1,6 +1,9 @@
 """Aggregate a rocprofv3 kernel trace over its LAST `ms` milliseconds (the timed steps of a bench run): per-kernel time, launches, and
 how busy the GPU was (sum of kernel durations / window; < 1 means launch gaps: the host could not keep the queue full).
-usage: trace_window.py <dir> <window ms> [steps]"""
+usage: trace_window.py <dir> <window ms> [steps] [marker]
+With a `marker` (a kernel that runs exactly ONCE per step: `image_f16_to_u8_kernel` closes an inference call, `adamw_kernel` a train step)
+the window is cut to EXACTLY `steps` steps -- from the end of the marker launch `steps` + 1 from the end to the end of the last one -- instead
+of a fixed number of milliseconds (round 2's windows held ~2.85 calls and were divided by 3)."""
 import csv, glob, sys, collections, re
 d, win = sys.argv[1], float(sys.argv[2]) * 1e6
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 1
@@ -10,6 +13,13 @@ for p in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 t1 = max(r[1] for r in rows); t0 = t1 - win
+marker = sys.argv[4] if len(sys.argv) > 4 else None
+if marker:
+    ends = sorted(e for s, e, n in rows if marker in n)
+    assert len(ends) > steps, f"only {len(ends)} launches of {marker}"
+    t0, t1 = ends[-steps - 1], ends[-1]
+    win = float(t1 - t0)
+    rows = [r for r in rows if r[1] <= t1]
 sel = [r for r in rows if r[0] >= t0]
 agg = collections.defaultdict(lambda: [0, 0.0])
 busy = 0.0
