@@ -757,6 +757,12 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     GN_REQUIRE(d->rows_per_batch > 0 && d->M % d->rows_per_batch == 0 && d->ldo2 >= d->rows_per_batch, "gn_gemm: out2 needs rows_per_batch | M and ldo2 >= rows_per_batch");
     GN_REQUIRE(d->N % 8 == 0 && d->ldo % 8 == 0 && ((uintptr_t)d->out & 15) == 0, "gn_gemm: out2 needs the 16-byte row-major store path for out");
   }
+  p.orw = d->out_row_width; p.ldo_hi = d->ldo_hi;
+  if (d->out_row_width) {
+    GN_REQUIRE(d->out_row_width > 0 && d->M % d->out_row_width == 0 && d->ldo_hi % 4 == 0, "gn_gemm: out_row_width must divide M, ldo_hi %% 4 == 0");
+    GN_REQUIRE(d->out_mode == GN_OUT_ROWMAJOR && d->act != GN_ACT_GEGLU && d->batch <= 1 && !d->out2,
+               "gn_gemm: the two-level output row pitch is for plain row-major f16 outputs");
+  }
   p.ln_c1 = d->ln_c1; p.ln_eps = d->ln_eps;
   if (d->ln_c1) {
     GN_REQUIRE(!d->conv && d->batch <= 1 && !d->fp8 && d->out_mode != GN_OUT_F32, "gn_gemm: ln_c1 (LayerNorm fold) is for dense f16 Linears");

@@ -38,7 +38,18 @@ struct GemmParams {
   int split_n;
   const float* ln_c1;                    // LayerNorm folded into the GEMM (ln_fold_apply below): per-column sums of the gamma-scaled weight
   float ln_eps;
+  int orw;                               // row-major f16 output with a two-level row pitch: row m lives at (m / orw) * ldo_hi + (m % orw) * ldo
+  long ldo_hi;                           // (one phase of a nearest-2x upsampling conv writes every other pixel of every other image row); 0 = m * ldo
 };
+
+// element offset of output row m (row-major f16 outputs)
+__device__ __forceinline__ long out_row_off(const GemmParams& p, int m) {
+  if (p.orw) {
+    const int hi = m / p.orw;
+    return (long)hi * p.ldo_hi + (long)(m - hi * p.orw) * p.ldo;
+  }
+  return (long)m * p.ldo;
+}
 
 // batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
 __device__ __forceinline__ GemmParams batch_offset(const GemmParams& pin) {
@@ -128,7 +139,7 @@ __device__ __forceinline__ void epilogue_store4(const GemmParams& p, int m, int 
     f16x4 o;
 #pragma unroll
     for (int i = 0; i < 4; ++i) o[i] = (f16)v[i];
-    *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + nb) = o;
+    *reinterpret_cast<f16x4*>(p.out + out_row_off(p, m) + nb) = o;
   }
 }
 
@@ -351,7 +362,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
         // lanes l and l + 32 hold the same row: one v_permlane32_swap per dword trades group g of the upper half against group
         // g + 1 of the lower half; afterwards the lower lane owns channels 8g .. 8g+7 and the upper lane 8(g+1) .. 8(g+1)+7,
         // a 16-byte store each (the write path is issue-bound on 8-byte pieces)
-        f16* orow = p.out + (long)m * p.ldo;
+        f16* orow = p.out + out_row_off(p, m);
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {
           f16x4 ha, hb;
@@ -364,7 +375,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
           if (col < p.N) *reinterpret_cast<uint4*>(orow + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
         }
       } else if (p.out_mode == GN_OUT_ROWMAJOR) {
-        f16* orow = p.out + (long)m * p.ldo;
+        f16* orow = p.out + out_row_off(p, m);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int nb = nbase + j * 32 + 8 * g + 4 * hi;

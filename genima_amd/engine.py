@@ -71,6 +71,7 @@ class Engine:
     def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None):
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
+        self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
         # launch + V^T.  Measured neutral in the call (107.59 vs 107.67 ms tiled b8, same box) although the kernel alone is 4-7 % faster at
@@ -475,6 +476,11 @@ class Engine:
         d.M, d.N, d.K = B * Ho * Wo, N, k * k * (C1 + C2)
         assert w.shape[1] == d.K, (tuple(w.shape), d.K)
         d.ldw, d.ldo, d.ldshift = w.stride(0), out.stride(-2), ldshift
+        if out.dim() == 4 and out.stride(1) != Wo * out.stride(2):
+            # a strided view of a larger image (one phase of an upsampling conv writes every other pixel of every other row):
+            # two-level row pitch, gn_gemm_desc.out_row_width / ldo_hi
+            assert out.stride(0) == Ho * out.stride(1) and residual is None, "strided output views: whole image rows, no residual"
+            d.out_row_width, d.ldo_hi = Wo, out.stride(1)
         d.ldr = residual.stride(-2) if residual is not None else 0
         d.conv, d.B, d.H, d.W, d.C1, d.C2 = 1, B, H, W, C1, C2
         d.KH, d.KW, d.stride, d.pad_t, d.pad_l, d.Ho, d.Wo = k, k, stride, pad[0], pad[1], Ho, Wo
@@ -482,6 +488,18 @@ class Engine:
                                                                                      Ho * Wo, splitk, out_scale)
         d.residual_before_act = int(residual_before_act)
         self._gemm(d, (x, x2, w, bias, shift, residual, out))
+        return out
+
+    def conv2d_up2x(self, x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor] = None, *, name: Optional[str] = None) -> torch.Tensor:
+        """conv3x3(nearest_upsample_2x(x)) as its four phase convs (packing.pack_upsample_phases): phase (dy, dx) is a 2x2 conv over the
+        source pixels (top / left padding 1 - dy / 1 - dx) whose results are written straight to pixels (2y + dy, 2x + dx) of the output --
+        4 / 9 of the multiply-adds of the fused-upsample 3x3 launch it replaces (diffusers Upsample2D)."""
+        B, H, W, _ = x.shape
+        N = w4.shape[1]
+        out = self.buf(name, (B, 2 * H, 2 * W, N))
+        for dy in (0, 1):
+            for dx in (0, 1):
+                self.conv2d(x, w4[2 * dy + dx], bias, ksize=2, pad=(1 - dy, 1 - dx, dy, dx), out=out[:, dy::2, dx::2, :])
         return out
 
     # ------------------------------------------------------------------------------------------------ weight repacking (gn_pack_*)

@@ -197,6 +197,14 @@ def _emit_mid(E: Engine, W, cfg, h, shifts, kv):
     return emit_resnet(E, W, "mid_block.resnets.1", h, None, shifts, G, eps)
 
 
+def _emit_upsample_conv(E: Engine, W, p: str, h: torch.Tensor) -> torch.Tensor:
+    """Upsample2D = nearest 2x + 3x3 conv: four 2x2 phase convs on the source pixels where the packed dict carries the phase weights
+    (packing.pack_upsample_phases: f16 inference dicts), else the 3x3 conv with the upsample fused into its gather."""
+    if getattr(E, "up_phases", True) and (p + ".up4.weight") in W:
+        return E.conv2d_up2x(h, W[p + ".up4.weight"], W[p + ".bias"], name=p)
+    return E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
+
+
 def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down_res: Optional[Sequence[torch.Tensor]] = None,
               mid_res: Optional[torch.Tensor] = None, added=None, before_residuals=None) -> torch.Tensor:
     """x8: scaled latents [B, H, W, 8] (channels >= in_channels zero).  Returns eps [B, H, W, 8] (first out_channels valid).
@@ -224,7 +232,7 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
                     h = emit_transformer(E, W, f"up_blocks.{i}.attentions.{j}", h, kv, _heads(cfg, nlev - 1 - i), G)
             if i != nlev - 1:
                 p = f"up_blocks.{i}.upsamplers.0.conv"
-                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
+                h = _emit_upsample_conv(E, W, p, h)
         E.side_free = False
         h = E.groupnorm(h, W["conv_norm_out.weight"], W["conv_norm_out.bias"], G, eps, act=ACT_SILU, name="norm_out")
         return E.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], name="conv_out")
@@ -305,7 +313,7 @@ def emit_vae_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
                 h = emit_resnet(E, W, f"decoder.up_blocks.{i}.resnets.{j}", h, None, None, G, 1e-6, eps_in=_vae_eps(W))
             if i != n - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-                h = E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
+                h = _emit_upsample_conv(E, W, p, h)
         h = E.groupnorm(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, _vae_eps(W), act=ACT_SILU, name="norm_out")
         return E.conv2d(h, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], name="conv_out")
 

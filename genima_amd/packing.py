@@ -140,6 +140,34 @@ def fold_layernorms(packed: Dict[str, torch.Tensor]) -> None:
             packed[base + lin + ".ln_c2"] = c2.to(torch.float16).contiguous()
 
 
+_UP_TAPS = (((0,), (1, 2)), ((0, 1), (2,)))  # [phase d][2x2 tap a] -> the 3x3 taps that land on source row / column (y - 1 + d + a)
+
+
+def pack_upsample_phases(w: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
+    """3x3 conv that follows a nearest-2x upsample (diffusers Upsample2D) -> its four PHASE convs on the source pixels.
+    Output pixel (2y + dy, 2x + dx) of conv3x3(upsample2x(src)) only sees the 2x2 source neighbourhood rows {y - 1 + dy, y + dy}, columns
+    {x - 1 + dx, x + dx}: the three taps of a row (column) collapse onto two source rows (columns), so the phase's 2x2 weights are sums
+    of the 3x3 ones -- 4 / 9 of the multiply-adds, exact in real arithmetic (the sums are taken in fp32 and rounded once).
+    w: OIHW [Cout, Cin, 3, 3] -> [4 (phase = 2 dy + dx), round_up(Cout, 8), 4 * round_up(Cin, 8)] in the packed tap-major K order."""
+    O, I, KH, KW = w.shape
+    assert KH == 3 and KW == 3, w.shape
+    acc_t = torch.float64 if w.dtype == torch.float64 else torch.float32
+    w = w.detach().to(acc_t)
+    Op, Ip = _rup(O, 8), _rup(I, 8)
+    out = torch.zeros((4, Op, 4 * Ip), dtype=acc_t, device=w.device)
+    for dy in range(2):
+        for dx in range(2):
+            for a in range(2):
+                for b in range(2):
+                    acc = torch.zeros((O, I), dtype=acc_t, device=w.device)
+                    for ky in _UP_TAPS[dy][a]:
+                        for kx in _UP_TAPS[dx][b]:
+                            acc = acc + w[:, :, ky, kx]
+                    t = (a * 2 + b) * Ip
+                    out[2 * dy + dx, :O, t:t + I] = acc
+    return out.to(dtype).contiguous()
+
+
 def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
     """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries).
     ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams)."""
@@ -156,6 +184,9 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
         t = t.detach().to(torch.float32)
         if t.dim() == 4:
             out[name] = hip.pack_conv_weight(t.to(hip.device)) if hip is not None else pack_conv_weight(t, dtype=dtype)
+            if dtype == torch.float16 and ".upsamplers." in name and tuple(t.shape[2:]) == (3, 3):
+                # inference graphs run the nearest-2x + 3x3 conv as four 2x2 phase convs on the source pixels (4 / 9 of the work)
+                out[name[: -len("weight")] + "up4.weight"] = pack_upsample_phases(t, dtype=dtype)
             bn = name[: -len("weight")] + "bias"
             if bn in sd:
                 out[bn] = pack_vec(sd[bn].detach().float(), out[name].shape[0], dtype=dtype)

@@ -109,6 +109,13 @@ typedef struct gn_gemm_desc {
    * GEGLU, residual, out2 ...).  Dense f16 Linears on the LDS-DMA tiles (7..14, 16..23); K is never split.  NULL = off. */
   float ln_eps;
   const float* ln_c1;
+  /* two-level output row pitch (row-major f16 outputs): row m is written at (m / out_row_width) * ldo_hi + (m % out_row_width) * ldo
+   * elements from `out`.  One PHASE of a nearest-2x upsampling conv (diffusers Upsample2D: F.interpolate(scale 2, "nearest") + a 3x3
+   * conv -- the UNet's up_blocks.*.upsamplers.0 and the VAE decoder's) is a 2x2 conv over the SOURCE pixels whose
+   * results land on every other pixel of every other row of the output: out_row_width = W, ldo = 2 * C, ldo_hi = 4 * W * C,
+   * out = base + (dy * 2 * W + dx) * C.  0 = off (row m at m * ldo). */
+  int32_t out_row_width;
+  int64_t ldo_hi;
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */

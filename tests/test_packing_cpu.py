@@ -56,3 +56,24 @@ def test_layernorm_fold_entries_reproduce_layernorm_then_linear():
             assert c1.dtype == torch.float32
             err = float((got - want).abs().max()) / float(want.abs().max())
             assert err < 2e-3, (lin, err)  # f16 rounding of W * gamma and of c2
+
+
+def test_upsample_phase_weights_are_the_collapsed_taps():
+    import torch.nn.functional as F
+
+    from genima_amd.packing import pack_upsample_phases
+
+    """CPU-side identity in fp64: the four 2x2 phase convs on the source equal the 3x3 conv on the upsampled image, borders included."""
+    g = torch.Generator().manual_seed(0)
+    x, w = torch.randn(2, 5, 6, 8, generator=g).double(), torch.randn(16, 8, 3, 3, generator=g).double()
+    ref = F.conv2d(F.interpolate(x.permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), w, padding=1)
+    w4 = pack_upsample_phases(w, dtype=torch.float64)  # [4, 16, 4 * 8], K order (a, b, c)
+    out = torch.zeros_like(ref)
+    for dy in range(2):
+        for dx in range(2):
+            wk = w4[2 * dy + dx].view(16, 2, 2, 8).permute(0, 3, 1, 2)
+            xp = F.pad(x.permute(0, 3, 1, 2), (1 - dx, dx, 1 - dy, dy))
+            out[:, :, dy::2, dx::2] = F.conv2d(xp, wk)
+    assert float((out - ref).abs().max()) < 1e-12
+
+
