@@ -125,8 +125,9 @@ def per_op_profile(pipe, io, dump=None):
         s["flops"] += m["flops"]
         s["bytes"] += m["bytes"]
         s["launches"] += 1
-        a = agg.setdefault(m["kind"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0))
+        a = agg.setdefault(m["kind"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, ref_flops=0.0))
         a["ms"] += ms
+        a["ref_flops"] += m.get("ref_flops", m["flops"])
         a["flops"] += m["flops"]
         a["bytes"] += m["bytes"]
         a["launches"] += 1
@@ -390,6 +391,10 @@ def main():
                                            "the x2 is MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction); not re-collected by this run",
                            "traffic_stamp": pmc_traffic_stamp(),
                            "frac_of_sustained_mfma_rate": ach / MFMA_SUSTAINED_TF,
+                           "achieved_reference_algorithm": sum(agg[k]["ref_flops"] for k in gemm_kinds) / (g_ms * 1e-3) / 1e12,
+                           "reference_algorithm_note": "`achieved` counts the multiply-adds the launches EXECUTE; the upsampling 3x3 convs run as four 2x2 "
+                                                       "phase convs (4/9 of the reference algorithm's MACs, SURVEY.md Appendix C) -- counted at the "
+                                                       "reference's 2*MAC figure the family does `achieved_reference_algorithm` TFLOP/s",
                            "sustained_note": f"a pure v_mfma_f32_32x32x16_f16 stream sustains {MFMA_SUSTAINED_TF:.0f} TFLOP/s on MI355X "
                                              "(19-21 ns per MFMA per SIMD at the ~1.6-1.7 GHz the chip holds under matrix load; "
                                              "tools/probes/mfma_coissue.hip); `frac` stays quoted against the nominal dense peak",

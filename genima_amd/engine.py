@@ -72,6 +72,7 @@ class Engine:
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
+        self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "4096"))  # source pixels x batch below which the 3x3 launch stays
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
         # launch + V^T.  Measured neutral in the call (107.59 vs 107.67 ms tiled b8, same box) although the kernel alone is 4-7 % faster at
@@ -275,8 +276,10 @@ class Engine:
             self._keepalive(*keep, ws)
             kind = (f"conv{d.KH}x{d.KW}" if d.conv else "linear")
             n_out = d.N // 2 if d.act == ACT_GEGLU else d.N
+            # a phase conv of an upsampling 3x3 conv (KH = 2, strided output view) does 4 / 9 of the reference algorithm's multiply-adds
+            ref_scale = 9.0 / 4.0 if (d.conv and d.KH == 2 and d.out_row_width) else 1.0
             self.meta.append(dict(kind=kind, flops=2.0 * d.M * d.N * d.K, bytes=2.0 * (d.M * d.K / max(1, d.KH * d.KW if d.conv else 1) + d.N * d.K + d.M * n_out),
-                                  shape=(int(d.M), int(d.N), int(d.K))))
+                                  shape=(int(d.M), int(d.N), int(d.K)), ref_flops=2.0 * d.M * d.N * d.K * ref_scale))
         else:
             self.run_gemm(d)
 
