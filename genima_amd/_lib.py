@@ -38,7 +38,7 @@ class GemmDesc(C.Structure):
         ("out_bs", C.c_int64), ("out_bs2", C.c_int64), ("res_bs", C.c_int64), ("res_bs2", C.c_int64),
         ("accumulate", C.c_int32), ("fp8", C.c_int32), ("scale_a", C.c_void_p), ("scale_w", C.c_void_p),
         ("out2", C.c_void_p), ("ldo2", C.c_int64), ("split_n", C.c_int32),
-        ("ln_eps", C.c_float), ("ln_c1", C.c_void_p), ("out_row_width", C.c_int32), ("ldo_hi", C.c_int64),
+        ("ln_eps", C.c_float), ("ln_c1", C.c_void_p), ("out_row_width", C.c_int32), ("ldo_hi", C.c_int64), ("up_phases", C.c_int32),
     ]
 
 

@@ -760,7 +760,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.orw = d->out_row_width; p.ldo_hi = d->ldo_hi;
   if (d->out_row_width) {
     GN_REQUIRE(d->out_row_width > 0 && d->M % d->out_row_width == 0 && d->ldo_hi % 4 == 0, "gn_gemm: out_row_width must divide M, ldo_hi %% 4 == 0");
-    GN_REQUIRE(d->out_mode == GN_OUT_ROWMAJOR && d->act != GN_ACT_GEGLU && d->batch <= 1 && !d->out2,
+    GN_REQUIRE(d->out_mode == GN_OUT_ROWMAJOR && d->act != GN_ACT_GEGLU && (d->batch <= 1 || d->up_phases) && !d->out2,
                "gn_gemm: the two-level output row pitch is for plain row-major f16 outputs");
   }
   p.ln_c1 = d->ln_c1; p.ln_eps = d->ln_eps;
@@ -771,9 +771,16 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   }
   p.nbatch = d->batch > 1 ? d->batch : 0;
   p.binner = p.nbatch ? (d->batch_inner > 0 ? d->batch_inner : 1) : 0;
+  p.up_ph = d->up_phases ? 1 : 0;
+  if (d->up_phases) {
+    GN_REQUIRE(d->conv && d->batch == 4 && d->KH == 2 && d->KW == 2 && d->stride == 1 && !d->upsample2x && d->out_row_width > 0 && !d->residual &&
+               !d->shift && d->w_bs % 8 == 0 && d->ldo % 2 == 0 && d->ldo_hi % 2 == 0,
+               "gn_gemm: up_phases is the four-phase form of an upsampling 3x3 conv (conv, batch = 4, 2x2 taps, two-level output row pitch)");
+    p.binner = 0;  // the phase offsets replace the batch strides
+  }
   p.a_bs = d->a_bs; p.a_bs2 = d->a_bs2; p.w_bs = d->w_bs; p.w_bs2 = d->w_bs2;
   p.o_bs = d->out_bs; p.o_bs2 = d->out_bs2; p.r_bs = d->res_bs; p.r_bs2 = d->res_bs2;
-  if (p.nbatch) {
+  if (p.nbatch && !d->up_phases) {
     GN_REQUIRE(!d->conv && !d->shift && d->out_mode != GN_OUT_BATCH_TRANSPOSED, "gn_gemm: batched mode is dense GEMM only (no conv/shift/transposed out)");
     GN_REQUIRE(d->a_bs % 8 == 0 && d->a_bs2 % 8 == 0 && d->w_bs % 8 == 0 && d->w_bs2 % 8 == 0 && d->out_bs % 4 == 0 && d->out_bs2 % 4 == 0 &&
                d->res_bs % 4 == 0 && d->res_bs2 % 4 == 0, "gn_gemm: batch strides must keep 16-byte (a/w) and 8-byte (out/res) alignment");

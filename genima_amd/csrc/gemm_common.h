@@ -38,6 +38,7 @@ struct GemmParams {
   int split_n;
   const float* ln_c1;                    // LayerNorm folded into the GEMM (ln_fold_apply below): per-column sums of the gamma-scaled weight
   float ln_eps;
+  int up_ph;                             // 1: blockIdx.z = output phase 2 dy + dx of an upsampling conv (batch_offset below)
   int orw;                               // row-major f16 output with a two-level row pitch: row m lives at (m / orw) * ldo_hi + (m % orw) * ldo
   long ldo_hi;                           // (one phase of a nearest-2x upsampling conv writes every other pixel of every other image row); 0 = m * ldo
 };
@@ -54,6 +55,16 @@ __device__ __forceinline__ long out_row_off(const GemmParams& p, int m) {
 // batched GEMM: offset every operand of this workgroup's problem by its (outer, inner) batch strides
 __device__ __forceinline__ GemmParams batch_offset(const GemmParams& pin) {
   GemmParams p = pin;
+  if (pin.up_ph) {
+    // the four phase convs of an Upsample2D as ONE launch: phase z = 2 dy + dx has its own 2x2 weights (w + z * w_bs), top / left padding
+    // 1 - dy / 1 - dx and writes pixels (2y + dy, 2x + dx): half an ldo_hi down, half an ldo to the right of phase (0, 0)
+    const int bz = blockIdx.z, dy = bz >> 1, dx = bz & 1;
+    p.w += (long)bz * pin.w_bs;
+    p.pad_t = 1 - dy;
+    p.pad_l = 1 - dx;
+    p.out = pin.out + (long)dy * (pin.ldo_hi >> 1) + (long)dx * (pin.ldo >> 1);
+    return p;
+  }
   if (pin.binner > 0) {
     const int bz = blockIdx.z;
     const long bo = bz / pin.binner, bi = bz - bo * pin.binner;

@@ -72,6 +72,7 @@ class Engine:
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
+        self.up_phases_one_launch = os.environ.get("GN_UP_PHASES_ONE_LAUNCH", "1") != "0"
         self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "4096"))  # source pixels x batch below which the 3x3 launch stays
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
@@ -278,8 +279,10 @@ class Engine:
             n_out = d.N // 2 if d.act == ACT_GEGLU else d.N
             # a phase conv of an upsampling 3x3 conv (KH = 2, strided output view) does 4 / 9 of the reference algorithm's multiply-adds
             ref_scale = 9.0 / 4.0 if (d.conv and d.KH == 2 and d.out_row_width) else 1.0
-            self.meta.append(dict(kind=kind, flops=2.0 * d.M * d.N * d.K, bytes=2.0 * (d.M * d.K / max(1, d.KH * d.KW if d.conv else 1) + d.N * d.K + d.M * n_out),
-                                  shape=(int(d.M), int(d.N), int(d.K)), ref_flops=2.0 * d.M * d.N * d.K * ref_scale))
+            nph = 4.0 if d.up_phases else 1.0  # the four phases of an upsampling conv in one launch
+            self.meta.append(dict(kind=kind, flops=nph * 2.0 * d.M * d.N * d.K,
+                                  bytes=2.0 * (d.M * d.K / max(1, d.KH * d.KW if d.conv else 1) + nph * d.N * d.K + nph * d.M * n_out),
+                                  shape=(int(d.M), int(d.N), int(d.K)), ref_flops=nph * 2.0 * d.M * d.N * d.K * ref_scale))
         else:
             self.run_gemm(d)
 
@@ -459,12 +462,12 @@ class Engine:
                stride: int = 1, pad: Tuple[int, int, int, int] = None, x2: Optional[torch.Tensor] = None,
                shift: Optional[torch.Tensor] = None, ldshift: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
-               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False) -> torch.Tensor:
-        """NHWC conv.  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
+               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False, up_phases: bool = False) -> torch.Tensor:
+        """NHWC conv.  ``up_phases``: w is [4][Cout][4 * Cin] -- the four phase convs of an Upsample2D as ONE launch (conv2d_up2x).  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
         pad = (top, left, bottom, right); default k//2 all round.  shift: [B, ldshift or Cout] per-batch channel shift."""
         B, H, W, C1 = x.shape
         C2 = x2.shape[-1] if x2 is not None else 0
-        N = w.shape[0]
+        N = w.shape[1] if up_phases else w.shape[0]
         k = ksize
         if pad is None:
             pad = (k // 2,) * 4
@@ -477,8 +480,10 @@ class Engine:
         d.a, d.a2, d.w, d.bias, d.shift, d.residual, d.out = (_ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(shift),
                                                               _ptr(residual), _ptr(out))
         d.M, d.N, d.K = B * Ho * Wo, N, k * k * (C1 + C2)
-        assert w.shape[1] == d.K, (tuple(w.shape), d.K)
-        d.ldw, d.ldo, d.ldshift = w.stride(0), out.stride(-2), ldshift
+        assert w.shape[-1] == d.K, (tuple(w.shape), d.K)
+        d.ldw, d.ldo, d.ldshift = w.stride(-2), out.stride(-2), ldshift
+        if up_phases:
+            d.batch, d.batch_inner, d.w_bs, d.up_phases = 4, 1, w.stride(0), 1
         if out.dim() == 4 and out.stride(1) != Wo * out.stride(2):
             # a strided view of a larger image (one phase of an upsampling conv writes every other pixel of every other row):
             # two-level row pitch, gn_gemm_desc.out_row_width / ldo_hi
@@ -500,6 +505,9 @@ class Engine:
         B, H, W, _ = x.shape
         N = w4.shape[1]
         out = self.buf(name, (B, 2 * H, 2 * W, N))
+        if getattr(self, "up_phases_one_launch", True):  # blockIdx.z = phase: one launch instead of four
+            self.conv2d(x, w4, bias, ksize=2, pad=(1, 1, 0, 0), out=out[:, 0::2, 0::2, :], up_phases=True)
+            return out
         for dy in (0, 1):
             for dx in (0, 1):
                 self.conv2d(x, w4[2 * dy + dx], bias, ksize=2, pad=(1 - dy, 1 - dx, dy, dx), out=out[:, dy::2, dx::2, :])

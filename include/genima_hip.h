@@ -116,6 +116,10 @@ typedef struct gn_gemm_desc {
    * out = base + (dy * 2 * W + dx) * C.  0 = off (row m at m * ldo). */
   int32_t out_row_width;
   int64_t ldo_hi;
+  /* 1: the FOUR phase convs of an Upsample2D as one launch (batch = 4, conv, KH = KW = 2): w = [4][N][ldw] (phase 2 dy + dx at w + z * w_bs),
+   * pad_t / pad_l / out / ldo / ldo_hi / out_row_width describe phase (0, 0); phase (dy, dx) uses padding 1 - dy / 1 - dx and writes
+   * ldo_hi / 2 * dy + ldo / 2 * dx elements further. */
+  int32_t up_phases;
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */

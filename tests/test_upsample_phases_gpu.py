@@ -23,9 +23,15 @@ def test_conv2d_up2x_matches_torch_and_the_fused_launch(engine, shape):
     w = randn_h(Cout, Cin, 3, 3, seed=2, scale=(9 * Cin) ** -0.5)
     b = randn_h(Cout, seed=3, scale=0.3)
     w4 = pack_upsample_phases(w.float().cpu()).cuda()
-    y = engine.conv2d_up2x(x, w4, b)
+    y = engine.conv2d_up2x(x, w4, b)   # one launch, blockIdx.z = phase
     assert tuple(y.shape) == (B, 2 * H, 2 * W, Cout)
     assert_close(y, _ref(x, w, b), what=f"phase upsample conv {shape}")
+    engine.up_phases_one_launch = False
+    try:
+        y4 = engine.conv2d_up2x(x, w4, b)  # four launches, one per phase
+    finally:
+        engine.up_phases_one_launch = True
+    assert torch.equal(y, y4), "the one-launch and the four-launch form run the same arithmetic"
     old = engine.conv2d(x, pack_conv_weight(w.float().cpu()).cuda(), b, upsample2x=True)
     assert rel_l2(y, old.float().cpu()) < 6e-4
 
@@ -44,7 +50,7 @@ def test_two_level_row_pitch_every_tile(engine, tile):
         b = randn_h(Cout, seed=7, scale=0.3)
         w4 = pack_upsample_phases(w.float().cpu()).cuda()
         ref = _ref(x, w, b)
-        assert_close(E.conv2d_up2x(x, w4, b), ref, what=f"tile {tile}")
+        assert_close(E.conv2d_up2x(x, w4, b), ref, what=f"tile {tile} (one launch)")
         out = torch.full((B, 2 * H, 2 * W, Cout), float("nan"), dtype=torch.float16, device="cuda")
         for dy in (0, 1):
             for dx in (0, 1):
