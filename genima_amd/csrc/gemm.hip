@@ -50,7 +50,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  // tile order inside an XCD's contiguous run: row-major (the tiles of one A row band side by side: they share the band in L2) -- or, when the
+  // WEIGHT is the big operand (few rows under a long K: the 8x8 / 16x16 latent levels), column-major, so that the row tiles of one weight
+  // column tile run on ONE XCD and the tile is fetched from HBM once instead of once per L2
+  const int tile_n = p.cm_tiles ? bid / p.tiles_m : bid % p.tiles_n, tile_m = p.cm_tiles ? bid % p.tiles_m : bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.y;
   const int kbeg = z * p.kper;
@@ -244,7 +247,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  // tile order inside an XCD's contiguous run: row-major (the tiles of one A row band side by side: they share the band in L2) -- or, when the
+  // WEIGHT is the big operand (few rows under a long K: the 8x8 / 16x16 latent levels), column-major, so that the row tiles of one weight
+  // column tile run on ONE XCD and the tile is fetched from HBM once instead of once per L2
+  const int tile_n = p.cm_tiles ? bid / p.tiles_m : bid % p.tiles_n, tile_m = p.cm_tiles ? bid % p.tiles_m : bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.y;
   const int kbeg = z * p.kper;
@@ -447,7 +453,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  // tile order inside an XCD's contiguous run: row-major (the tiles of one A row band side by side: they share the band in L2) -- or, when the
+  // WEIGHT is the big operand (few rows under a long K: the 8x8 / 16x16 latent levels), column-major, so that the row tiles of one weight
+  // column tile run on ONE XCD and the tile is fetched from HBM once instead of once per L2
+  const int tile_n = p.cm_tiles ? bid / p.tiles_m : bid % p.tiles_n, tile_m = p.cm_tiles ? bid % p.tiles_m : bid / p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int nk = (p.K + BKB - 1) / BKB;
 
@@ -811,6 +820,13 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     p.a_bytes = (unsigned)db.a; p.a2_bytes = (unsigned)(db.a2 ? db.a2 : db.a); p.w_bytes = (unsigned)db.w;
   }
   p.splitk = pl.splitk; p.kper = pl.kper;
+  {
+    // bytes each operand brings in from memory once: A = the source pixels (a conv re-reads them per tap out of cache), W = N x K
+    static const int cm_env = [] { const char* e = getenv("GN_GEMM_CM_TILES"); return e ? atoi(e) : -1; }();  // A/B switch: 0 / 1 force
+    const int64_t a_el = d->conv ? (int64_t)d->B * d->H * d->W * (d->C1 + d->C2) : d->M * d->K;
+    const int64_t w_el = d->N * d->K;
+    p.cm_tiles = cm_env >= 0 ? cm_env : (w_el > 2 * a_el && d->batch <= 1 ? 1 : 0);
+  }
   p.tiles_m = (int)cdiv64(d->M, pl.bm); p.tiles_n = (int)cdiv64(d->N, pl.bn);
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
 

@@ -38,6 +38,7 @@ struct GemmParams {
   int split_n;
   const float* ln_c1;                    // LayerNorm folded into the GEMM (ln_fold_apply below): per-column sums of the gamma-scaled weight
   float ln_eps;
+  int cm_tiles;                          // 1: column-major tile order (the weight is the big operand)
   int up_ph;                             // 1: blockIdx.z = output phase 2 dy + dx of an upsampling conv (batch_offset below)
   int orw;                               // row-major f16 output with a two-level row pitch: row m lives at (m / orw) * ldo_hi + (m % orw) * ldo
   long ldo_hi;                           // (one phase of a nearest-2x upsampling conv writes every other pixel of every other image row); 0 = m * ldo

@@ -42,7 +42,10 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+  // tile order inside an XCD's contiguous run: row-major (the tiles of one A row band side by side: they share the band in L2) -- or, when the
+  // WEIGHT is the big operand (few rows under a long K: the 8x8 / 16x16 latent levels), column-major, so that the row tiles of one weight
+  // column tile run on ONE XCD and the tile is fetched from HBM once instead of once per L2
+  const int tile_n = p.cm_tiles ? bid / p.tiles_m : bid % p.tiles_n, tile_m = p.cm_tiles ? bid % p.tiles_m : bid / p.tiles_n;
   const int m0 = tile_m * 256, n0 = tile_n * 256;
   const int z = blockIdx.y;
   const int kbeg = z * p.kper;
