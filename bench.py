@@ -262,6 +262,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test aid (tests/test_bench_gpu.py): GN_BENCH_SHARE_DEVICE=1 puts every rank on device 0 and GN_BENCH_BACKEND=gloo carries the
+    # collectives (RCCL refuses two ranks on one device) -- the N > 1 code path of this script on a one-GPU box; never the measured setup
+    share = os.environ.get("GN_BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local = 0
     if not torch.cuda.is_available() or local >= torch.cuda.device_count():
         raise SystemExit(f"bench.py: rank {rank} of {world} needs ROCm device {local}, {torch.cuda.device_count()} visible")
     if world > 1:
@@ -270,7 +275,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
 
-        dist.init_process_group("nccl", rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
+        dist.init_process_group(os.environ.get("GN_BENCH_BACKEND", "nccl"), rank=rank, world_size=world, timeout=datetime.timedelta(minutes=5))
     assert world == max(1, args.gpus), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -19,6 +19,8 @@ def init_from_env(backend: str = None) -> Tuple[int, int, int]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("GN_BENCH_SHARE_DEVICE") == "1":  # test aid: every rank on device 0 (bench.py)
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -71,7 +73,7 @@ def barrier():
 def max_over_ranks(x: float, device="cpu") -> float:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(x)
-    t = torch.tensor([x], dtype=torch.float64, device=device)
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
