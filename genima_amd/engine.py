@@ -73,7 +73,7 @@ class Engine:
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
         self.up_phases_one_launch = os.environ.get("GN_UP_PHASES_ONE_LAUNCH", "1") != "0"
-        self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "4096"))  # source pixels x batch below which the 3x3 launch stays
+        self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "1024"))  # source pixels x batch below which the 3x3 launch stays
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
         # launch + V^T.  Measured neutral in the call (107.59 vs 107.67 ms tiled b8, same box) although the kernel alone is 4-7 % faster at

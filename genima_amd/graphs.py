@@ -201,9 +201,10 @@ def _emit_upsample_conv(E: Engine, W, p: str, h: torch.Tensor) -> torch.Tensor:
     """Upsample2D = nearest 2x + 3x3 conv: four 2x2 phase convs on the source pixels where the packed dict carries the phase weights
     (packing.pack_upsample_phases: f16 inference dicts), else the 3x3 conv with the upsample fused into its gather."""
     # measured per shape (MI355X, B = 8 tiled call): 2.35 -> 1.42 ms and 2.09 -> 1.15 ms on the VAE's 256^2 -> 512^2 / 128^2 -> 256^2 upsamplers,
-    # 1.15 -> 0.96 ms on the UNet's 32^2 -> 64^2 one, a wash at 2048 source rows and a loss at 512 (four launches of a tiny-M problem)
+    # 1.15 -> 0.96 ms on the UNet's 32^2 -> 64^2 one; with the four phases as ONE launch also a gain at 2048 source rows (call 103.7 -> 103.1 ms)
+    # and at the B = 1 call's 1024 rows, still a loss at 512 (the 3x3 launch with its K split wins there)
     rows = h.shape[0] * h.shape[1] * h.shape[2]
-    if getattr(E, "up_phases", True) and (p + ".up4.weight") in W and rows >= getattr(E, "up_phases_min_rows", 4096):
+    if getattr(E, "up_phases", True) and (p + ".up4.weight") in W and rows >= getattr(E, "up_phases_min_rows", 1024):
         return E.conv2d_up2x(h, W[p + ".up4.weight"], W[p + ".bias"], name=p)
     return E.conv2d(h, W[p + ".weight"], W[p + ".bias"], upsample2x=True, name=p)
 
