@@ -71,7 +71,6 @@ class Engine:
     def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None):
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
-        self.fused_kv = os.environ.get("GN_FUSED_KV", "1") != "0"  # graphs: cross-attention K | V^T of the prompt as one launch per layer
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
         self.up_phases_one_launch = os.environ.get("GN_UP_PHASES_ONE_LAUNCH", "1") != "0"
         self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "1024"))  # source pixels x batch below which the 3x3 launch stays

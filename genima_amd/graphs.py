@@ -102,12 +102,8 @@ def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[
         if name.endswith(".attn2.to_k.weight"):
             p = name[: -len(".to_k.weight")]
             with E.scope(tag + "/" + p):
-                if (p + ".to_kv.weight") in W and not E._fp8_weights and getattr(E, "fused_kv", True):
-                    Ck = W[name].shape[0]  # K | V^T out of ONE launch (gn_gemm_desc.out2 / split_n), 23 launches fewer per call
-                    k, vt = E.linear(ctx, W[p + ".to_kv.weight"], split_n=Ck, rows_per_batch=L, pad_cols=_rup(L, 64), name="k")
-                else:
-                    k = E.linear(ctx, W[name], name="k")
-                    vt = E.linear(ctx, W[p + ".to_v.weight"], transposed_out=True, rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
+                k = E.linear(ctx, W[name], name="k")
+                vt = E.linear(ctx, W[p + ".to_v.weight"], transposed_out=True, rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
             kv[p] = (k, vt)
     return kv
 

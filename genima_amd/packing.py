@@ -235,11 +235,6 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
                     # q | k | v as ONE launch (two-destination GEMM: q, k row-major + V^T): the inference graphs' self-attention
                     out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
     if dtype == torch.float16:
-        # cross-attention K | V of the prompt as one two-destination launch (K row-major + V^T), like the self-attention q | k | v
-        for name in list(sd.keys()):
-            if name.endswith(".attn2.to_k.weight") and name[: -len("to_k.weight")] + "to_v.weight" in sd and sd[name].shape[0] % 32 == 0:
-                base = name[: -len("to_k.weight")]
-                out[base + "to_kv.weight"] = torch.cat([sd[name], sd[base + "to_v.weight"]], dim=0).to(dtype).contiguous()
         fold_layernorms(out)
     meta = {}
     if temb_w:
