@@ -71,6 +71,7 @@ class Engine:
     def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None):
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
+        self.hoist_time_shifts = os.environ.get("GN_HOIST_TIME_SHIFTS", "1") != "0"  # pipeline: all steps' time shifts in one pass (A/B switch)
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
         self.up_phases_one_launch = os.environ.get("GN_UP_PHASES_ONE_LAUNCH", "1") != "0"
         self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "1024"))  # source pixels x batch below which the 3x3 launch stays

@@ -210,13 +210,14 @@ def _emit_upsample_conv(E: Engine, W, p: str, h: torch.Tensor) -> torch.Tensor:
 
 
 def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down_res: Optional[Sequence[torch.Tensor]] = None,
-              mid_res: Optional[torch.Tensor] = None, added=None, before_residuals=None) -> torch.Tensor:
+              mid_res: Optional[torch.Tensor] = None, added=None, before_residuals=None, shifts: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x8: scaled latents [B, H, W, 8] (channels >= in_channels zero).  Returns eps [B, H, W, 8] (first out_channels valid).
     ``added`` = (text_embeds, time_ids): SDXL added conditions.  ``before_residuals``: called once the encoder and mid block are
     emitted and before the first ControlNet residual is consumed (the pipeline joins the ControlNet's stream there)."""
     G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
     with E.scope("unet"):
-        shifts = emit_time_shifts(E, W, cfg, t_dev, added)
+        if shifts is None:  # (the pipeline computes the time shifts of ALL its steps in one pass and hands each step its rows)
+            shifts = emit_time_shifts(E, W, cfg, t_dev, added)
         h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         h = _emit_mid(E, W, cfg, h, shifts, kv)
@@ -254,10 +255,12 @@ def emit_controlnet_cond(E: Engine, W, cfg, cond8: torch.Tensor) -> torch.Tensor
         return E.conv2d(h, W[p + ".conv_out.weight"], W[p + ".conv_out.bias"], name="out")
 
 
-def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, conditioning_scale: float = 1.0, added=None):
+def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, conditioning_scale: float = 1.0, added=None,
+                    shifts: Optional[torch.Tensor] = None):
     """-> (list of down residuals (12 for SD-2.x, 9 for SDXL), mid residual), NHWC."""
     with E.scope("cn"):
-        shifts = emit_time_shifts(E, W, cfg, t_dev, added)
+        if shifts is None:
+            shifts = emit_time_shifts(E, W, cfg, t_dev, added)
         h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], residual=cond_emb, name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         h = _emit_mid(E, W, cfg, h, shifts, kv)

@@ -218,11 +218,23 @@ class StableDiffusionControlNetPipeline:
             t = torch.full((B,), float(v), dtype=torch.float32, device=dev)
             E._keepalive(t)
             return t
+        # the timestep MLP + every ResNet's time_emb_proj depend on the step's timestep only: all steps' time shifts as ONE pass per network
+        # (rows [i * Bn, (i + 1) * Bn) belong to step i) instead of four small launches per network and step
+        sh_cn = sh_un = None
+        if added is None and getattr(E, "hoist_time_shifts", True):
+            t_all = torch.cat([torch.full((Bn,), float(sch.timesteps[i]), dtype=torch.float32, device=dev) for i in range(steps)])
+            E._keepalive(t_all)
+            with E.scope("cn_t"):
+                sh_cn = graphs.emit_time_shifts(E, self.controlnet.W, self.controlnet.config, t_all)
+            with E.scope("un_t"):
+                sh_un = graphs.emit_time_shifts(E, self.unet.W, self.unet.config, t_all)
         io.first_step_op = E.num_ops
         for i in range(steps):
             sigma, sigma_next = (0.0, 0.0) if linear else (float(sch.sigmas[i]), float(sch.sigmas[i + 1]))
             t_dev = torch.full((Bn,), float(sch.timesteps[i]), dtype=torch.float32, device=dev)
             E._keepalive(t_dev)
+            s_cn = None if sh_cn is None else sh_cn[i * Bn:(i + 1) * Bn]
+            s_un = None if sh_un is None else sh_un[i * Bn:(i + 1) * Bn]
             if guidance:  # latent_model_input = torch.cat([latents] * 2)
                 x8 = E.buf("x8", (Bn, h, w, 8))
                 E.scale_pad(io.latents, sch.input_scale(i), 8, out=x8[:B])
@@ -233,11 +245,11 @@ class StableDiffusionControlNetPipeline:
             # joined where the UNet consumes its residuals (fills the CUs the small-M deep-level kernels leave idle)
             if self.two_streams:
                 E.fork()
-            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0, added=added)
+            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0, added=added, shifts=s_cn)
             if self.two_streams:
                 E.main()
             eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid, added=added,
-                                   before_residuals=E.join if self.two_streams else None)
+                                   before_residuals=E.join if self.two_streams else None, shifts=s_un)
             if guidance:  # noise_pred = uncond + guidance_scale * (text - uncond)
                 eps = E.add_noise(eps[:B], eps[B:], scalar(1.0 - guidance), scalar(guidance), name="eps_cfg")
             if ancestral:
