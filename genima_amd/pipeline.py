@@ -201,13 +201,14 @@ class StableDiffusionControlNetPipeline:
         if self.two_streams:
             E.main()
         ctx, added = self._emit_prompt(E, io, Bn, L, H, W)
-        if self.two_streams:
+        kv_side = self.two_streams and os.environ.get("GN_KV_SIDE", "1") != "0"
+        if kv_side:
             # the K / V hoists of the two networks (14 + 32 small M = B x 77 Linears) only share the prompt states: the ControlNet's run on
             # the side stream (behind the conditioning embedding) beside the UNet's
             E.join()
             E.fork()
         kv_cn = graphs.emit_cross_kv(E, self.controlnet.W, ctx, "cn")
-        if self.two_streams:
+        if kv_side:
             E.main()
         kv_un = graphs.emit_cross_kv(E, self.unet.W, ctx, "unet")
         if self.two_streams:
