@@ -93,6 +93,8 @@ SIGNATURES = {
     "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
     "gn_attention_bwd": (_I32, [_P, C.POINTER(AttnBwdDesc)]),
+    "gn_attention_fp8_quantize": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _F, _P, _P, _P, _I32]),
+    "gn_attention_fp8_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
     "gn_groupnorm_workspace_bytes": (_I64, [C.POINTER(GroupNormDesc)]),
     "gn_groupnorm_fwd": (_I32, [_P, C.POINTER(GroupNormDesc)]),
     "gn_layernorm_fwd": (_I32, [_P, _P, _P, _P, _P, _I64, _I32, _F]),

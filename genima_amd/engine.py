@@ -563,6 +563,38 @@ class Engine:
             check(self.lib.gn_attention_fwd(self._ctx, C.byref(d)), "gn_attention_fwd")
         return out
 
+    def attention_fp8(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, *, out: Optional[torch.Tensor] = None,
+                      name: Optional[str] = None, lse: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Self-/cross-attention on the fp8 MFMA (D = 64; opt-in, the fp8 training forward -- csrc/attention_fp8.hip): q [B, Nq, heads*64],
+        k / v [B, Nk, heads*64] f16 views (column slices of a q | k | v projection are fine).  One launch makes the e4m3 operands
+        (scale folded into q8, V transposed into the MFMA key order), one runs the attention.  Eager only."""
+        if self.record:
+            raise GenimaHipError("attention_fp8 is an eager op (it serves the training forward, which is not recorded)")
+        B, Nq, Cq = q.shape
+        Nk = k.shape[1]
+        if Cq != heads * 64:
+            raise GenimaHipError(f"attention_fp8: head dim {Cq // heads} unsupported (64)")
+        if Nq != Nk:
+            raise GenimaHipError("attention_fp8: one row count for q and k / v (self-attention)")
+        Np = (Nk + 63) // 64 * 64
+        q8 = self.buf((name or "attn8") + ".q8", (B, Nq, Cq), dtype=torch.uint8)
+        k8 = self.buf((name or "attn8") + ".k8", (B, Nk, Cq), dtype=torch.uint8)
+        v8t = self.buf((name or "attn8") + ".v8t", (B, Cq, Np), dtype=torch.uint8)
+        check(self.lib.gn_attention_fp8_quantize(self._ctx, _ptr(q), _ptr(k), _ptr(v), q.stride(1), k.stride(1), v.stride(1), q.stride(0),
+                                                  k.stride(0), v.stride(0), B, Nq, heads, 64.0 ** -0.5, _ptr(q8), _ptr(k8), _ptr(v8t), Np),
+              "gn_attention_fp8_quantize")
+        if out is None:
+            out = self.buf(name, (B, Nq, Cq))
+        d = AttnDesc()
+        d.q, d.k, d.vt, d.o = _ptr(q8), _ptr(k8), _ptr(v8t), _ptr(out)
+        d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q8.stride(0), k8.stride(0), v8t.stride(0), out.stride(0)
+        d.q_rs, d.k_rs, d.vt_rs, d.o_rs = q8.stride(1), k8.stride(1), v8t.stride(1), out.stride(1)
+        d.B, d.heads, d.Nq, d.Nk, d.D, d.causal, d.scale = B, heads, Nq, Nk, 64, 0, 1.0
+        d.lse = _ptr(lse)
+        d.v_rowmajor = 0
+        check(self.lib.gn_attention_fp8_fwd(self._ctx, C.byref(d)), "gn_attention_fp8_fwd")
+        return out
+
     # ------------------------------------------------------------------------------------------------ norms
     def groupnorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
                   act: int = ACT_NONE, x2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,

@@ -149,6 +149,21 @@ typedef struct gn_attn_desc {
 } gn_attn_desc;
 int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d);
 
+/* fp8 (OCP e4m3) attention forward, D = 64 -- the opt-in attention of the fp8 training forward (BASELINE configs[4] "fp8 MFMA";
+ * xformers attention under diffusion/train_controlnet_sdxl_genima.py:1448-1471).  Both products run on the K = 64 fp8 MFMA; the
+ * probabilities are e4m3 too, so the result sits ~1e-2 (relative, per element) from the f16 kernel: never used by the inference path.
+ * gn_attention_fp8_quantize makes the operands from the f16 q | k | v rows ([B][N][*_rs] views, head h at column 64 h):
+ *   q8 [B][N][heads*64] = e4m3(q * scale * log2 e), k8 [B][N][heads*64] = e4m3(k)  (bytes, saturating at +-448),
+ *   v8t [B][heads*64][Npad] = e4m3(v) transposed, the keys of every 64-key tile in the MFMA operand order (csrc/attention_fp8.hip);
+ *   Npad = a multiple of 64 >= N; keys >= N are written as zeros.
+ * gn_attention_fp8_fwd takes a gn_attn_desc whose q / k / vt are those byte tensors (strides in BYTES; `scale` is ignored: it is
+ * already in q8; v_rowmajor must be 0), o f16 and the optional lse as for gn_attention_fwd (same log2-domain value, so
+ * gn_attention_bwd can run on the f16 q / k / v the operands were made from). */
+int32_t gn_attention_fp8_quantize(gn_ctx* ctx, const void* q, const void* k, const void* v, int64_t q_rs, int64_t k_rs, int64_t v_rs,
+                                  int64_t q_bs, int64_t k_bs, int64_t v_bs, int32_t B, int32_t N, int32_t heads, float scale,
+                                  void* q8, void* k8, void* v8t, int32_t Npad);
+int32_t gn_attention_fp8_fwd(gn_ctx* ctx, const gn_attn_desc* d);
+
 /* Flash-attention backward (D = 64; xformers memory-efficient attention backward under accelerator.backward,
  * diffusion/train_controlnet_genima.py:1125-1126, :1402).  P is recomputed per tile from q, k and the forward's lse; two
  * deterministic kernels (dQ over key tiles; dK, dV over query tiles), no atomics.  q / k / v / o / d_o and the gradients are

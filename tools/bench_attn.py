@@ -41,3 +41,29 @@ for heads, nq, nk, causal in [(5, 4096, 4096, False), (10, 1024, 1024, False), (
                 heads, Nk=nk, causal=causal, out=o)
     same = torch.equal(o, o2)
     print(f"          row-major V:                                    {ms2 * 1000:8.1f} us  {fl / ms2 / 1e9:7.1f} TFLOP/s  bitwise {'==' if same else '!='} V^T path", flush=True)
+
+# ---- fp8 (e4m3) attention: operands made by gn_attention_fp8_quantize, both products on the K = 64 fp8 MFMA -------------------------
+import ctypes as C  # noqa: E402
+from genima_amd._lib import AttnDesc, check  # noqa: E402
+
+for heads, n in [(5, 4096), (10, 4096), (10, 1024), (20, 1024), (20, 256)]:
+    Cc = heads * 64
+    qkv = torch.randn(B, n, 3 * Cc, device="cuda").half()
+    q, k, v = qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:]
+    o = torch.empty(B, n, Cc, device="cuda", dtype=torch.float16)
+    q8 = torch.empty(B, n, Cc, dtype=torch.uint8, device="cuda"); k8 = torch.empty_like(q8)
+    v8t = torch.empty(B, Cc, n, dtype=torch.uint8, device="cuda")
+    quant = lambda: check(E.lib.gn_attention_fp8_quantize(E._ctx, q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(1), k.stride(1), v.stride(1),
+                                                          q.stride(0), k.stride(0), v.stride(0), B, n, heads, 0.125, q8.data_ptr(), k8.data_ptr(), v8t.data_ptr(), n), "quantize")
+    d = AttnDesc()
+    d.q, d.k, d.vt, d.o = q8.data_ptr(), k8.data_ptr(), v8t.data_ptr(), o.data_ptr()
+    d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q8.stride(0), k8.stride(0), v8t.stride(0), o.stride(0)
+    d.q_rs, d.k_rs, d.vt_rs, d.o_rs = q8.stride(1), k8.stride(1), v8t.stride(1), o.stride(1)
+    d.B, d.heads, d.Nq, d.Nk, d.D, d.causal, d.scale = B, heads, n, n, 64, 0, 1.0
+    quant()
+    t_q = timeit(quant)
+    t_a = timeit(lambda: check(E.lib.gn_attention_fp8_fwd(E._ctx, C.byref(d)), "fp8 fwd"))
+    t_16 = timeit(lambda: E.attention(q, k, v, heads, out=o, v_rowmajor=True))
+    fl = 4.0 * B * heads * n * n * 64
+    print(f"fp8 attention B={B} heads={heads} N={n}: kernel {t_a * 1000:8.1f} us {fl / t_a / 1e9:7.1f} TFLOP/s | operands {t_q * 1000:6.1f} us | "
+          f"kernel + operands {fl / (t_a + t_q) / 1e9:7.1f} TFLOP/s | f16 kernel (row-major V) {t_16 * 1000:8.1f} us {fl / t_16 / 1e9:7.1f} TFLOP/s", flush=True)
