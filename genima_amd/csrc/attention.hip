@@ -24,7 +24,8 @@
 //     the f16 P that enters the PV MFMA exactly).
 // K/V tiles are double-buffered in LDS (one barrier per 64-key tile); at D = 64 tile t+1 arrives by LDS-DMA under the MFMAs of tile
 // t, at D = 32 through registers.  Block = NW waves x TQ x 32 query rows (template); 4 waves x 32 rows is the default, the other
-// shapes and the software-pipelined kernel of attention_pipe.hip stay selectable (GN_ATTN_VARIANT) for measurements.
+// shapes stay selectable (GN_ATTN_VARIANT) for measurements.  The non-causal D = 64 problems with a key count that is a multiple of 64 and V^T
+// given -- the self-attention of the U-Net / ControlNet -- go to the software-pipelined, branch-free kernel of attention_stream.hip.
 // Blocks are ordered XCD-aware: the query blocks of one (batch, head) share an L2.
 #include <stdlib.h>
 
@@ -408,10 +409,15 @@ void launch_attn(const AttnParams& p, int B, hipStream_t st) {
   hipLaunchKernelGGL((attn_fwd_kernel<D, NW, TQ, VROW>), grid, dim3(NW * 64), 0, st, p);
 }
 
+bool stream_default() {
+  static const bool on = getenv("GN_ATTN_STREAM") ? atoi(getenv("GN_ATTN_STREAM")) != 0 : true;  // attention_stream.hip for the eligible shapes (GN_ATTN_STREAM=0: this file's kernel everywhere)
+  return on;
+}
+
 int attn_variant_override() {
   static int v = -2;
   if (v == -2) {
-    // tuning aid: 0 = 4 waves x 32 rows (default), 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows, 3 = attention_pipe.hip
+    // tuning aid: 0 = this file's 4 waves x 32 rows everywhere, 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows, 4 = attention_stream.hip wherever eligible
     const char* e = getenv("GN_ATTN_VARIANT");
     v = e ? atoi(e) : -1;
   }
@@ -441,12 +447,11 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
     launch_attn<32, 4, 1>(p, d->B, ctx->stream);
   } else {
     // measured on MI355X (tools/bench_attn.py, 8 x 5 x 4096^2 / 8 x 10 x 1024^2): 4 waves x 32 rows 220 / 39 us, 4 waves x 64 rows
-    // 268 / 52 (occupancy 1), 8 waves x 32 rows 252 / 46, the software-pipelined kernel of attention_pipe.hip 227-243 / 41 (its
-    // in-wave MFMA / VALU overlap is paid back in barrier waits at 2 waves per SIMD -- DESIGN.md).  4 waves x 32 rows is the default.
+    // 268 / 52 (occupancy 1), 8 waves x 32 rows 252 / 46; attention_stream.hip 194 / 32 against 218 / 35 on one box (round 3).
     const int ov = attn_variant_override();
     if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
     else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
-    else if (ov == 3) gn_launch_attention_pipe(p, d->B, ctx->stream);
+    else if ((ov == 4 || (ov < 0 && stream_default())) && !d->causal && !d->v_rowmajor && d->Nk % 64 == 0 && d->Nk >= 128) gn_launch_attention_stream(p, d->B, ctx->stream);
     else if (d->v_rowmajor) launch_attn<64, 4, 1, true>(p, d->B, ctx->stream);
     else launch_attn<64, 4, 1>(p, d->B, ctx->stream);
   }

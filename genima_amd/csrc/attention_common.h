@@ -1,4 +1,4 @@
-// Declarations shared by the attention forward kernels (attention.hip: generic kernel, attention_pipe.hip: the D = 64 main kernel).
+// Declarations shared by the attention forward kernels (attention.hip: generic kernel, attention_stream.hip: the branch-free D = 64 self-attention kernel).
 #pragma once
 #include "common.h"
 
@@ -29,5 +29,5 @@ __device__ __forceinline__ float pair_sum(float v) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// D = 64, software-pipelined kernel (attention_pipe.hip)
-void gn_launch_attention_pipe(const AttnParams& p, int B, hipStream_t stream);
+// D = 64, non-causal, Nk a multiple of 64 (>= 128), V^T layout: the software-pipelined, branch-free kernel (attention_stream.hip)
+void gn_launch_attention_stream(const AttnParams& p, int B, hipStream_t stream);
