@@ -19,6 +19,8 @@
 //   * optional split-K over gridDim.y with an f32 workspace and a fused reduce+epilogue kernel (small-M layers);
 //   * blockIdx -> tile mapping is XCD-aware (each XCD walks a contiguous run of tiles, N fastest, so the A rows an XCD's L2
 //     holds are reused across the N tiles).
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace {
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
       const int co = first ? cc : cc - p.C1;
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
-        const unsigned voff = (kok && pix[i] >= 0) ? (unsigned)(((long)pix[i] * cs + co) * 2) : kOOB;
+        unsigned voff = (kok && pix[i] >= 0) ? (unsigned)(((long)pix[i] * cs + co) * 2) : kOOB;
+        GN_PIN(voff);
         lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
         if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
         else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
@@ -338,13 +341,15 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     } else {
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
-        const unsigned voff = (kok && aoff[i] != kOOB) ? aoff[i] + (unsigned)kcur * 2u : kOOB;
+        unsigned voff = (kok && aoff[i] != kOOB) ? aoff[i] + (unsigned)kcur * 2u : kOOB;
+        GN_PIN(voff);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const unsigned voff = (kok && woff[i] != kOOB) ? woff[i] + (unsigned)kcur * 2u : kOOB;
+      unsigned voff = (kok && woff[i] != kOOB) ? woff[i] + (unsigned)kcur * 2u : kOOB;
+      GN_PIN(voff);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
     kcur += BK;
@@ -387,8 +392,11 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   if constexpr (LNF) ln_stats_init(lnst);
 
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) dma_tile(cur ^ 1);  // lands under this tile's MFMAs; buf[cur^1] was last read before the previous barrier
+  // wsel: which of the WN column waves' share of the K steps this copy of the loop takes the LayerNorm statistics on (LNF).  The choice is
+  // made ONCE, outside the K loop (one specialised copy of the loop per column wave), because inside it every conditional branch costs the
+  // wave ~100 cycles even when it falls through (tools/probes/attn_phase_model.hip); the loop body itself has the back edge and nothing else.
+  auto k_tile = [&](auto wsel_c) __attribute__((always_inline)) {
+    constexpr int WSEL = decltype(wsel_c)::value;
     const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
     const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -407,12 +415,28 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
         for (int i = 0; i < TM; ++i)
           acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       if constexpr (LNF) {
-        if (WN == 1 || (kk % WN) == wn) ln_stats_step(lnst, fa);  // wave-uniform: this wave's share of the K steps
+        if (WN == 1 || (kk % WN) == WSEL) ln_stats_step(lnst, fa);  // compile-time: this copy's share of the K steps
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
+  };
+  // the last tile is peeled so that the loop body issues its DMA unconditionally
+  auto k_loop = [&](auto wsel_c) __attribute__((always_inline)) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      dma_tile(cur ^ 1);  // lands under this tile's MFMAs; buf[cur^1] was last read before the previous barrier
+      k_tile(wsel_c);
+    }
+    k_tile(wsel_c);
+  };
+  if constexpr (LNF && WN > 1) {
+    if (wn == 0) k_loop(std::integral_constant<int, 0>{});
+    else if (WN > 2 && wn == 2) k_loop(std::integral_constant<int, 2 % WN>{});
+    else if (WN > 2 && wn == 3) k_loop(std::integral_constant<int, 3 % WN>{});
+    else k_loop(std::integral_constant<int, 1>{});
+  } else {
+    k_loop(std::integral_constant<int, 0>{});
   }
 
   if constexpr (LNF)  // (the barrier that ended the K loop freed the LDS tiles)
@@ -482,12 +506,14 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     unsigned char* Bs = As + A_BYTES;
 #pragma unroll
     for (int i = 0; i < GA; ++i) {
-      const unsigned voff = (kok && aoff[i] != kOOB) ? aoff[i] + (unsigned)kcur : kOOB;
+      unsigned voff = (kok && aoff[i] != kOOB) ? aoff[i] + (unsigned)kcur : kOOB;
+      GN_PIN(voff);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
-      const unsigned voff = (kok && woff[i] != kOOB) ? woff[i] + (unsigned)kcur : kOOB;
+      unsigned voff = (kok && woff[i] != kOOB) ? woff[i] + (unsigned)kcur : kOOB;
+      GN_PIN(voff);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
     kcur += BKB;

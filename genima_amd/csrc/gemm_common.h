@@ -625,6 +625,10 @@ constexpr int gemm_waves_per_simd(int lds_bytes, int waves_per_block) {
   const int w = blocks * waves_per_block / 4;
   return w < 1 ? 1 : (w > 4 ? 4 : w);
 }
+// GN_PIN(x): x is ONE value in ONE register here.  Without it hipcc turns `offset = ok ? computed : kOOB` in front of an LDS-DMA builtin
+// into two exec-masked arms with a DMA instruction each (s_and_saveexec / s_cbranch_execz around every piece: sixteen branches per K
+// tile in the 128x128 kernel) -- and a branch costs a wave ~100 cycles even when it falls through (tools/probes/attn_phase_model.hip).
+#define GN_PIN(x) asm volatile("" : "+v"(x))
 constexpr unsigned kOOB = 0xFFFFFFF0u;  // out-of-range buffer offset: the hardware writes zeros to LDS for such lanes
 
 }  // namespace

@@ -3,6 +3,8 @@
 // a full L2 / MALL round trip; here two tiles are in flight and the wait is counted.  Same tiles, loaders, swizzle and epilogue as
 // gemm_dma_kernel (gemm.hip); the per-lane validity selects become OR-masks so that every path issues the same number of VMEM
 // instructions (the counted vmcnt depends on it).  Tiles 16..19 of gn_gemm_desc::tile.
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace {
@@ -193,35 +195,48 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   if constexpr (LNF) ln_stats_init(lnst);
 
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int nxt2 = cur >= 1 ? cur - 1 : 2;  // (cur + 2) % 3
-    dma_tile(nxt2);
-    const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
-    const unsigned char* Bs = As + A_BYTES;
+  // LNF: one specialised copy of the K loop per column wave, chosen ONCE outside it (wsel = whose share of the K steps the copy takes the
+  // LayerNorm statistics on): a conditional branch inside the loop costs the wave ~100 cycles even when it falls through
+  auto k_loop = [&](auto wsel_c) __attribute__((always_inline)) {
+    constexpr int WSEL = decltype(wsel_c)::value;
+    for (int kt = 0; kt < nk; ++kt) {
+      const int nxt2 = cur >= 1 ? cur - 1 : 2;  // (cur + 2) % 3
+      dma_tile(nxt2);
+      const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
+      const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      f16x8 fa[TM], fw[TN];
-      const int c = kk * 2 + hi;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const f16x8*>(As + lds_swz<128>(wm * WTM + i * 32 + l31, c));
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fw[j] = *reinterpret_cast<const f16x8*>(Bs + lds_swz<128>(wn * WTN + j * 32 + l31, c));
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int kk = 0; kk < BK / 16; ++kk) {
+        f16x8 fa[TM], fw[TN];
+        const int c = kk * 2 + hi;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
-      if constexpr (LNF) {
-        if (WN == 1 || (kk % WN) == wn) ln_stats_step(lnst, fa);  // wave-uniform: this wave's share of the K steps
+          fa[i] = *reinterpret_cast<const f16x8*>(As + lds_swz<128>(wm * WTM + i * 32 + l31, c));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          fw[j] = *reinterpret_cast<const f16x8*>(Bs + lds_swz<128>(wn * WTN + j * 32 + l31, c));
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+        if constexpr (LNF) {
+          if (WN == 1 || (kk % WN) == WSEL) ln_stats_step(lnst, fa);  // compile-time: this copy's share of the K steps
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+      wait_vmcnt<NIN>();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == 2 ? 0 : cur + 1;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    wait_vmcnt<NIN>();
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    cur = cur == 2 ? 0 : cur + 1;
+  };
+  if constexpr (LNF && WN > 1) {
+    if (wn == 0) k_loop(std::integral_constant<int, 0>{});
+    else if (WN > 2 && wn == 2) k_loop(std::integral_constant<int, 2 % WN>{});
+    else if (WN > 2 && wn == 3) k_loop(std::integral_constant<int, 3 % WN>{});
+    else k_loop(std::integral_constant<int, 1>{});
+  } else {
+    k_loop(std::integral_constant<int, 0>{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead zero fills
 
