@@ -12,6 +12,8 @@
 // next MFMA's B operand.  The second product of each kernel needs the streamed operand transposed ([d][row]): it is read out of
 // the SAME row-major LDS tile with ds_read_b64_tr_b16 (tr_frag below) -- round 1 streamed separate Q^T / K^T / dO^T copies made by
 // gn_transpose2d (96 transposes per step, twice the streamed bytes and LDS).
+#include <type_traits>
+
 #include "common.h"
 
 // waves per SIMD passed to __launch_bounds__: with the hint the dK / dV kernel comes out at 166 VGPRs (three waves per SIMD) instead of 206
@@ -184,13 +186,14 @@ __global__ __launch_bounds__(256, GN_ATTNB_DQ_WAVES) void attn_bwd_dq_kernel(con
   __syncthreads();
 
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
+  // One branch per key tile, the back edge (a conditional branch inside the loop costs the wave ~100 cycles even when it falls through --
+  // tools/probes/attn_phase_model.hip): the last tile, the only one that can be ragged, is peeled; the loop body prefetches unconditionally.
+  auto tile = [&](auto last_c, int t) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
+    if constexpr (!LAST) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
     const unsigned char* Ks = smem + cur * 2 * TILE;
     const unsigned char* Vs = Ks + TILE;
     const int j0 = t * TS;
-    const bool need_mask = j0 + TS > p.Nk;
 
     f32x16 s[2], dp[2];
 #pragma unroll
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(256, GN_ATTNB_DQ_WAVES) void attn_bwd_dq_kernel(con
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float pv = __builtin_amdgcn_exp2f(fmaf(s[u][r], c, -L));
-        if (need_mask && (j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7) >= p.Nk)) pv = 0.0f;
+        if constexpr (LAST) pv = (j0 + 32 * u + 16 * (r >> 3) + 8 * hi + (r & 7) >= p.Nk) ? 0.0f : pv;  // keys past Nk (only the last tile has any)
         dsf[u][r >> 3][r & 7] = (f16)(pv * (dp[u][r] - dl) * sc);
       }
 #pragma unroll
@@ -224,7 +227,9 @@ __global__ __launch_bounds__(256, GN_ATTNB_DQ_WAVES) void attn_bwd_dq_kernel(con
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{}, t);
+  if (ntiles > 0) tile(std::true_type{}, ntiles - 1);
 
   if (qlive) {
     f16* op = p.dq + (long)b * p.dq_bs + (long)qrow * p.dq_rs + h * D;
@@ -286,19 +291,18 @@ __global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(c
     unsigned char* Qs = smem + buf * KV_BUF;
     dma_stream(sq, rs_q, Qs, wv);
     dma_stream(sg, rs_g, Qs + TILE, wv);
-    if (tid < 64) {
-      const bool live = jn + tid < p.Nq;
-      rl = live ? lsep[jn + tid] : INFINITY;  // dead query rows: P = exp2(.. - inf) = 0
-      rd = live ? delp[jn + tid] : 0.0f;
+    {  // every wave fetches the same 64 values (one wave would do, but "if (tid < 64)" is a branch per tile): clamped index, then a select
+      const int row = jn + lane, rc = min(row, p.Nq - 1);
+      const float l = lsep[rc], dd = delp[rc];
+      rl = row < p.Nq ? l : INFINITY;  // dead query rows: P = exp2(.. - inf) = 0
+      rd = row < p.Nq ? dd : 0.0f;
     }
     jn += TS;
   };
-  auto store_stats = [&](int buf) {
-    if (tid < 64) {
-      unsigned char* Qs = smem + buf * KV_BUF;
-      reinterpret_cast<float*>(Qs + 2 * TILE)[tid] = rl;
-      reinterpret_cast<float*>(Qs + 2 * TILE + 256)[tid] = rd;
-    }
+  auto store_stats = [&](int buf) {  // (all four waves write the same values)
+    unsigned char* Qs = smem + buf * KV_BUF;
+    reinterpret_cast<float*>(Qs + 2 * TILE)[lane] = rl;
+    reinterpret_cast<float*>(Qs + 2 * TILE + 256)[lane] = rd;
   };
   if (ntiles > 0) {
     dma_tile(0);
@@ -308,9 +312,9 @@ __global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(c
   __syncthreads();
 
   int cur = 0;
-  for (int t = 0; t < ntiles; ++t) {
-    const bool more = t + 1 < ntiles;
-    if (more) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
+  auto tile = [&](auto last_c) __attribute__((always_inline)) {  // (one branch per query tile: see the dQ kernel)
+    constexpr bool LAST = decltype(last_c)::value;
+    if constexpr (!LAST) dma_tile(cur ^ 1);  // buffer cur^1 was last read before the barrier that ended the previous iteration
     const unsigned char* Qs = smem + cur * KV_BUF;
     const unsigned char* Gs = Qs + TILE;
     const float* Ls = reinterpret_cast<const float*>(Qs + 2 * TILE);
@@ -356,11 +360,13 @@ __global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(c
           accV[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gt, pf[u][g], accV[dt], 0, 0, 0);
           accK[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qt, dsf[u][g], accK[dt], 0, 0, 0);
         }
-    if (more) store_stats(cur ^ 1);
+    if constexpr (!LAST) store_stats(cur ^ 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of the next tile have landed
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{});
+  if (ntiles > 0) tile(std::true_type{});
 
   if (klive) {
     f16* okp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_rs + h * D;

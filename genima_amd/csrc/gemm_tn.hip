@@ -11,6 +11,8 @@
 // pair granularity (applied on the SOURCE side of the lane-linear LDS-DMA) so that the 16 (row, pair) pieces spread over all banks.
 // Reference op: the weight gradient autograd computes for nn.Linear / nn.Conv2d inside accelerator.backward(loss)
 // (diffusion/train_controlnet_genima.py:1391).
+#include <type_traits>
+
 #include "gemm_common.h"
 
 namespace {
@@ -99,7 +101,8 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
       const int lrow = (wave + NW * i) * RPA + arow;
       const long r = r0 + lrow;
       const int col = m0 + ((apc ^ tn_swz<CPA>(lrow)) << 3);
-      const unsigned voff = (r < rend && col < p.M) ? (unsigned)((r * p.lda + col) * 2) : kOOB;
+      unsigned voff = (r < rend && col < p.M) ? (unsigned)((r * p.lda + col) * 2) : kOOB;
+      GN_PIN(voff);  // one value in one register: no exec-masked arms with a DMA each (gemm_common.h)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
 #pragma unroll
@@ -110,15 +113,21 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
       unsigned voff = kOOB;
       if constexpr (CONV) {
         const int iy = py[i] * tp.stride - tp.pad + tdy[i], ix = px[i] * tp.stride - tp.pad + tdx[i];
-        if (r < rend && n0 + lc < p.N && (unsigned)iy < (unsigned)tp.H && (unsigned)ix < (unsigned)tp.W)
-          voff = (unsigned)(((((long)pb[i] * tp.H + iy) * tp.W + ix) * tp.C + tcc[i]) * 2);
-        // next K tile: 64 rows further
+        const bool ok = r < rend && n0 + lc < p.N && (unsigned)iy < (unsigned)tp.H && (unsigned)ix < (unsigned)tp.W;
+        voff = ok ? (unsigned)(((((long)pb[i] * tp.H + iy) * tp.W + ix) * tp.C + tcc[i]) * 2) : kOOB;
+        // next K tile: 64 rows further -- selects, not branches (64 <= Ho * Wo, so the image index steps at most once besides the carry)
         px[i] += r64; py[i] += q64;
-        if (px[i] >= tp.Wo) { px[i] -= tp.Wo; ++py[i]; }
-        while (py[i] >= tp.Ho) { py[i] -= tp.Ho; ++pb[i]; }
+        const int cx = px[i] >= tp.Wo ? 1 : 0;
+        px[i] -= cx ? tp.Wo : 0; py[i] += cx;
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const int cy = py[i] >= tp.Ho ? 1 : 0;
+          py[i] -= cy ? tp.Ho : 0; pb[i] += cy;
+        }
       } else {
-        if (r < rend && n0 + lc < p.N) voff = (unsigned)((r * p.ldw + n0 + lc) * 2);
+        voff = (r < rend && n0 + lc < p.N) ? (unsigned)((r * p.ldw + n0 + lc) * 2) : kOOB;
       }
+      GN_PIN(voff);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
   };
@@ -155,8 +164,10 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
   __syncthreads();
 
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) dma_tile(cur ^ 1, rbeg + (long)(kt + 1) * 64);
+  // one branch per K tile (the back edge): the last tile is peeled and the loop exists in two copies, with and without the column sums,
+  // chosen once outside it -- a conditional branch inside costs the wave ~100 cycles even when it falls through
+  auto k_tile = [&](auto sums_c) __attribute__((always_inline)) {
+    constexpr bool SUMS = decltype(sums_c)::value;
     const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);
     const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
         const h4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lds_h4_ptr)(q + 4 * (BM * 2)));
         fa[i] = __builtin_bit_cast(f16x8, H8{lo, hi4});
       }
-      if (do_sums) {  // wave-uniform: the first column tile's wn = 0 waves also sum the dY fragments they hold anyway
+      if constexpr (SUMS) {  // the first column tile's wn = 0 waves also sum the dY fragments they hold anyway
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -191,7 +202,16 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur ^= 1;
-  }
+  };
+  auto k_loop = [&](auto sums_c) __attribute__((always_inline)) {
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+      dma_tile(cur ^ 1, rbeg + (long)(kt + 1) * 64);
+      k_tile(sums_c);
+    }
+    k_tile(sums_c);
+  };
+  if (do_sums) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
 
   if (do_sums) {
 #pragma unroll
