@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, GN_ATTNB_DQ_WAVES) void attn_bwd_dq_kernel(con
   __syncthreads();
 
   int cur = 0;
-  // One branch per key tile, the back edge (a conditional branch inside the loop costs the wave ~100 cycles even when it falls through --
+  // One branch per key tile, the back edge (conditional branches inside the loop cost issue slots even when they fall through --
   // tools/probes/attn_phase_model.hip): the last tile, the only one that can be ragged, is peeled; the loop body prefetches unconditionally.
   auto tile = [&](auto last_c, int t) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_c)::value;

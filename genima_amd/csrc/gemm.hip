@@ -393,8 +393,8 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
 
   int cur = 0;
   // wsel: which of the WN column waves' share of the K steps this copy of the loop takes the LayerNorm statistics on (LNF).  The choice is
-  // made ONCE, outside the K loop (one specialised copy of the loop per column wave), because inside it every conditional branch costs the
-  // wave ~100 cycles even when it falls through (tools/probes/attn_phase_model.hip); the loop body itself has the back edge and nothing else.
+  // made ONCE, outside the K loop (one specialised copy of the loop per column wave): conditional branches inside it cost issue slots even when
+  // they fall through (measured on the whole call: DESIGN.md, round 3); the loop body itself has the back edge and nothing else.
   auto k_tile = [&](auto wsel_c) __attribute__((always_inline)) {
     constexpr int WSEL = decltype(wsel_c)::value;
     const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);

@@ -627,7 +627,7 @@ constexpr int gemm_waves_per_simd(int lds_bytes, int waves_per_block) {
 }
 // GN_PIN(x): x is ONE value in ONE register here.  Without it hipcc turns `offset = ok ? computed : kOOB` in front of an LDS-DMA builtin
 // into two exec-masked arms with a DMA instruction each (s_and_saveexec / s_cbranch_execz around every piece: sixteen branches per K
-// tile in the 128x128 kernel) -- and a branch costs a wave ~100 cycles even when it falls through (tools/probes/attn_phase_model.hip).
+// tile in the 128x128 kernel) -- removing them: 98.8 vs 100.3 ms per tiled call on one box.
 #define GN_PIN(x) asm volatile("" : "+v"(x))
 constexpr unsigned kOOB = 0xFFFFFFF0u;  // out-of-range buffer offset: the hardware writes zeros to LDS for such lanes
 

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
 
   int cur = 0;
   // LNF: one specialised copy of the K loop per column wave, chosen ONCE outside it (wsel = whose share of the K steps the copy takes the
-  // LayerNorm statistics on): a conditional branch inside the loop costs the wave ~100 cycles even when it falls through
+  // LayerNorm statistics on): conditional branches inside the loop cost issue slots even when they fall through (measured: DESIGN.md, round 3)
   auto k_loop = [&](auto wsel_c) __attribute__((always_inline)) {
     constexpr int WSEL = decltype(wsel_c)::value;
     for (int kt = 0; kt < nk; ++kt) {

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
 
   int cur = 0;
   // one branch per K tile (the back edge): the last tile is peeled and the loop exists in two copies, with and without the column sums,
-  // chosen once outside it -- a conditional branch inside costs the wave ~100 cycles even when it falls through
+  // chosen once outside it -- conditional branches inside the loop cost issue slots even when they fall through (measured: DESIGN.md, round 3)
   auto k_tile = [&](auto sums_c) __attribute__((always_inline)) {
     constexpr bool SUMS = decltype(sums_c)::value;
     const unsigned char* As = smem + cur * (A_BYTES + B_BYTES);

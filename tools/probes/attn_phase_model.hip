@@ -20,7 +20,16 @@ template <int MODE, int PRIO>
 __global__ void k(float* out, int iters) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[49152];
   const int lane = threadIdx.x & 63;
+  // RANDOM_DATA: f16 pairs with pseudo-random mantissas and exponents around 1 (what real K / V tiles look like to the data paths: the chip
+  // clocks to its power budget, and operand toggling is power) instead of a smooth ramp
+#ifdef RANDOM_DATA
+  for (int i = threadIdx.x; i < 49152 / 4; i += blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    reinterpret_cast<unsigned*>(smem)[i] = (h & 0x83FF83FFu) | 0x38003800u;  // sign + mantissa random, exponent 14 (0.5 .. 1)
+  }
+#else
   for (int i = threadIdx.x; i < 49152 / 4; i += blockDim.x) reinterpret_cast<float*>(smem)[i] = 0.001f * (i & 1023);
+#endif
   __syncthreads();
   const int l31 = lane & 31, hi = lane >> 5;
   int offk[4], offv[2][2];

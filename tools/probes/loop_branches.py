@@ -1,5 +1,5 @@
-"""Per kernel of a csrc/*.hip file: conditional branches inside the loops that hold its MFMAs (a branch costs a wave ~100 cycles even when it falls
-through -- tools/probes/attn_phase_model.hip).  usage: loop_branches.py genima_amd/csrc/gemm.hip [extra hipcc flags]"""
+"""Per kernel of a csrc/*.hip file: conditional branches inside the loops that hold its MFMAs (what they cost was measured on the
+whole call and on the attention loop: DESIGN.md, round 3).  usage: loop_branches.py genima_amd/csrc/gemm.hip [extra hipcc flags]"""
 import collections, re, subprocess, sys, tempfile, os
 src = sys.argv[1]; extra = sys.argv[2:]
 out = tempfile.mktemp(suffix=".s")
