@@ -5,10 +5,10 @@
 //   P = exp2(S'),   O^T[d, q] += V^T_tile . P^T
 //
 // What the measurements behind this kernel say (tools/probes/attn_phase_model.hip, profiles/r03_v5_attn_phase_model*.txt; register-only
-// model of the 64-key iteration, three waves per SIMD, ns per wave tile): phases in program order 460, software-pipelined inside the wave
-// 334 (16 MFMAs alone 296), + one ds_read_b128 per MFMA just in time 374 -- 436 with random operand bits, which is what real K / V tiles
+// model of the 64-key iteration, three waves per SIMD, ns per wave tile): phases in program order 389, software-pipelined inside the wave
+// 314 (16 MFMAs alone 296), + one ds_read_b128 per MFMA just in time 373 -- 432 with random operand bits, which is what real K / V tiles
 // look like to a chip that clocks to its power budget.  A conditional branch per 32-key stage on top of that (the optimistic softmax's "is
-// the lane sum in range?") costs +45 % with the smooth operands (550) but +4 ... 6 % with the random ones (452 - 464 against 437), whatever it
+// the lane sum in range?") costs +45 % with the smooth operands (544) but +3 ... 6 % with the random ones (450 - 465 against 437), whatever it
 // tests; a sticky flag instead costs nothing in either.  On the real kernel: this loop WITH the per-stage branch 206 - 212 us, without 194,
 // attention.hip (five branches per 64 keys, phases in program order) 218, at 8 x 5 x 4096^2 on one box.
 // So:

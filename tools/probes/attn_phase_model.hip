@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ int swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
 template <int MODE, int PRIO>
-__global__ void k(float* out, int iters) {
+__global__ __launch_bounds__(768) void k(float* out, int iters) {  // (768 threads = three waves per SIMD: 170 registers, no spills)
   __shared__ __attribute__((aligned(16))) unsigned char smem[49152];
   const int lane = threadIdx.x & 63;
   // RANDOM_DATA: f16 pairs with pseudo-random mantissas and exponents around 1 (what real K / V tiles look like to the data paths: the chip
