@@ -374,7 +374,7 @@ class Engine:
             if out is None:
                 out = self.buf(name, tuple(x.shape[:-1]) + (split_n,))
             if out2 is None:
-                out2 = self.buf(None if name is None else name + ".t", (nb, N - split_n, ld2), zero=True)
+                out2 = self.buf(None if name is None else name + ".t", (nb, N - split_n, ld2), zero=ld2 != rows_per_batch)  # only pad columns need the zeros
             d.out_mode, d.ldo, d.rows_per_batch = OUT_ROWMAJOR, out.stride(-2), rows_per_batch
             d.out2, d.ldo2, d.split_n = _ptr(out2), ld2, split_n
         elif transposed_out:
@@ -382,7 +382,7 @@ class Engine:
             nb = M // rows_per_batch
             ld = pad_cols if pad_cols else _round_up(rows_per_batch, 64)
             if out is None:
-                out = self.buf(name, (nb, N, ld), zero=True)
+                out = self.buf(name, (nb, N, ld), zero=ld != rows_per_batch)  # only pad columns need the zeros
             d.out_mode, d.ldo, d.rows_per_batch = OUT_BATCH_TRANSPOSED, ld, rows_per_batch
         else:
             if out is None:

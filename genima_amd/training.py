@@ -523,7 +523,12 @@ def t_time_shifts(g: Graph, net: TrainParams, cfg, t_dev: torch.Tensor, B: int, 
     z = g.act(emb, ACT_SILU)
     shifts = g.linear(net, z, "time_emb_proj_all.weight", "time_emb_proj_all.bias")
     # per-ResNet f32 accumulators of d(shift) = per-batch column sums of the conv1 output gradients, gathered once every ResNet ran
-    net.dshift = {p: torch.zeros((B, n), dtype=F32, device=E.device) for p, (o, n) in net.temb_slices.items()}
+    # (one zero fill for all of them: 30-odd separate torch.zeros launches sit in the step's dependent chain otherwise)
+    flat = torch.zeros(B * sum(n for (o, n) in net.temb_slices.values()), dtype=F32, device=E.device)
+    net.dshift, at = {}, 0
+    for p, (o, n) in net.temb_slices.items():
+        net.dshift[p] = flat[at:at + B * n].view(B, n)
+        at += B * n
 
     def gather():
         shifts.cell[0] = torch.cat([net.dshift[p] for p in net.temb_slices], dim=1).to(F16)
