@@ -98,6 +98,41 @@ __global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restr
   }
 }
 
+// ---- many transposes in ONE launch: the trainable net's ~140 derived weight copies (W^T for the Linears' data gradients, the rotated
+// conv weights) are rebuilt after every optimizer step -- as separate 6 us launches they sit in the step's dependent chain.  `items` is a
+// device table (fixed pointers: the f16 working copy and the persistent outputs), block_begin ascending; a block finds its item by bisection.
+__global__ __launch_bounds__(256) void transpose2d_multi_kernel(const gn_transpose_item* __restrict__ items, int n_items) {
+  __shared__ uint32_t tile[64][33];
+  int lo_i = 0, hi_i = n_items - 1;
+  const int bid = blockIdx.x;
+  while (lo_i < hi_i) {  // last item whose block_begin <= bid (block-uniform)
+    const int mid = (lo_i + hi_i + 1) >> 1;
+    if (items[mid].block_begin <= bid) lo_i = mid; else hi_i = mid - 1;
+  }
+  const gn_transpose_item it_ = items[lo_i];
+  const int local = bid - it_.block_begin;
+  const int tx = (it_.cols + 63) / 64, ty = (it_.rows + 63) / 64;
+  const int b = local / (tx * ty), rem = local - b * (tx * ty);
+  const int c0 = (rem % tx) * 64, r0 = (rem / tx) * 64;
+  const int t = threadIdx.x, lo = t & 7, hi = t >> 3;
+  const f16* in = (const f16*)it_.in + (long)b * it_.in_bs;
+  f16* out = (f16*)it_.out + (long)b * it_.out_bs;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int r = r0 + hi + 32 * k, c = c0 + lo * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < it_.rows && c < it_.cols) v = *reinterpret_cast<const uint4*>(in + (long)r * it_.ld_in + c);
+    tile_store_chunk(tile, hi + 32 * k, lo, v);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int oc = hi + 32 * k, c = c0 + oc, r = r0 + lo * 8;
+    const uint4 v = tile_load_column_chunk(tile, lo * 8, oc);
+    if (c < it_.cols && r < it_.rows) *reinterpret_cast<uint4*>(out + (long)c * it_.ld_out + r) = v;
+  }
+}
+
 // ---- im2col^T: out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c]  (0 in the padding) ---------------------
 // Same 64x64 tile / 16-byte scheme as transpose2d_vec_kernel, with the row (pixel) address computed per tap.  C % 8 == 0, M % 8 == 0.
 struct Im2colP { const f16* x; f16* out; int B, H, W, C, KH, KW, stride, pad, Ho, Wo; long M; };
@@ -752,6 +787,16 @@ int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int
   else
     hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
                        (long)in_bs, (long)out_bs);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+/* n_items gn_transpose2d problems in one launch (csrc comment at transpose2d_multi_kernel): `items` lives in DEVICE memory, every item as
+ * gn_transpose2d's 16-byte-vector form requires (cols, ld_in, ld_out, in_bs, out_bs multiples of 8, 16-byte aligned pointers, ld_out >=
+ * round_up(rows, 8)); block_begin = the running sum of batch * ceil(rows / 64) * ceil(cols / 64), total_blocks its end. */
+extern "C" int32_t gn_transpose2d_multi(gn_ctx* ctx, const gn_transpose_item* items, int32_t n_items, int32_t total_blocks) {
+  GN_REQUIRE(ctx && items && n_items > 0 && total_blocks > 0, "gn_transpose2d_multi: bad arguments");
+  hipLaunchKernelGGL(transpose2d_multi_kernel, dim3(total_blocks), dim3(256), 0, ctx->stream, items, n_items);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

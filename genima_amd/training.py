@@ -103,6 +103,50 @@ class TrainParams(FrozenParams):
         T.cast_f32_f16(self.E, self.master, self.half)
         self._wt.clear()
 
+    def refresh_derived(self):
+        """After an optimizer step: the derived weight copies (W^T of the Linears, the tap-rotated conv weights) of every weight the
+        backward pass has asked for so far, rebuilt in ONE launch (gn_transpose2d_multi) into persistent buffers -- ~140 lazily issued
+        6 us transposes sat in the step's dependent chain otherwise.  Weights first seen later join the table at the next refresh."""
+        keys = [k for k in self._wt if k not in getattr(self, "_multi_skip", ())]
+        if not keys:
+            self._wt.clear()
+            return
+        if getattr(self, "_multi_keys", None) != keys:
+            rows_, blocks, outs, skip = [], 0, {}, set(getattr(self, "_multi_skip", ()))
+            for key in keys:
+                name, taps = key
+                w = self.W[name]
+                if taps > 1:
+                    Cout, K = w.shape
+                    Cin = K // taps
+                    out = self._wt[key]  # [Cin, taps * Cout], allocated by the lazy path: kept as the persistent buffer
+                    it = (w.data_ptr(), out.data_ptr() + 2 * (taps - 1) * Cout, taps * Cin, taps * Cout, Cin, -Cout, Cout, Cin, taps)
+                else:
+                    N, K = w.shape
+                    out = self._wt[key]  # [K, ld_out]
+                    it = (w.data_ptr(), out.data_ptr(), K, out.stride(0), 0, 0, N, K, 1)
+                src, dst, ld_in, ld_out, in_bs, out_bs, r, c, batch = it
+                ok = (c % 8 == 0 and ld_in % 8 == 0 and ld_out % 8 == 0 and in_bs % 8 == 0 and out_bs % 8 == 0 and ld_out >= _rup(r, 8)
+                      and src % 16 == 0 and dst % 16 == 0)
+                if not ok:
+                    skip.add(key)
+                    continue
+                rows_.append([src, dst, ld_in, ld_out, in_bs, out_bs, (r & 0xFFFFFFFF) | (c << 32), (batch & 0xFFFFFFFF) | (blocks << 32)])
+                blocks += batch * (-(-r // 64)) * (-(-c // 64))
+                outs[key] = out
+            self._multi_skip = skip
+            keys = [k for k in keys if k not in skip]
+            self._multi_keys = keys
+            self._multi_outs = outs
+            self._multi_blocks = blocks
+            self._multi_table = torch.tensor(rows_, dtype=torch.int64).to(self.E.device) if rows_ else None
+        self._wt.clear()
+        if self._multi_table is not None:
+            from ._lib import check
+            check(self.E.lib.gn_transpose2d_multi(self.E._ctx, self._multi_table.data_ptr(), len(self._multi_keys), self._multi_blocks),
+                  "gn_transpose2d_multi")
+            self._wt.update(self._multi_outs)
+
     def zero_grad(self):
         T.fill_f32(self.E, self.grad, 0.0)
 
@@ -748,7 +792,10 @@ class ControlNetTrainer:
         # one pass: AdamW on the fp32 master, the f16 working copy refreshed from the new values, the gradient cleared
         T.adamw(E, cn.master, cn.grad, cn.exp_avg, cn.exp_avg_sq, self.current_lr(), self.betas[0], self.betas[1], self.eps, self.wd,
                 self.opt_step, self._clip, inv, half_out=cn.half, zero_grad=True)
-        cn._wt.clear()  # derived (transposed / rotated) weight copies are stale
+        if self._use_graph or os.environ.get("GN_MULTI_WT") == "0":
+            cn._wt.clear()  # derived (transposed / rotated) weight copies are stale: rebuilt inside the captured graph
+        else:
+            cn.refresh_derived()  # ... and rebuilt here, in one launch
 
     def current_lr(self) -> float:
         return self.lr * (float(self.lr_lambda(self.sched_step)) if self.lr_lambda is not None else 1.0)

@@ -302,6 +302,17 @@ typedef struct gn_wgrad_desc {
 int64_t gn_wgrad_workspace_bytes(const gn_wgrad_desc* d);
 int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d);
 
+/* Many gn_transpose2d problems in ONE launch (the trainable network's derived weight copies -- W^T for the Linears' data gradients,
+ * the tap-rotated conv weights -- are rebuilt after every optimizer step; accelerate / autograd get them for free from cuBLAS's
+ * transposed operand forms, diffusion/train_controlnet_genima.py:1391).  `items`: DEVICE memory, each as the 16-byte-vector form of
+ * gn_transpose2d requires; block_begin = running sum of batch * ceil(rows/64) * ceil(cols/64), total_blocks = its end. */
+typedef struct gn_transpose_item {
+  const void* in; void* out;
+  int64_t ld_in, ld_out, in_bs, out_bs;
+  int32_t rows, cols, batch, block_begin;
+} gn_transpose_item;
+int32_t gn_transpose2d_multi(gn_ctx* ctx, const gn_transpose_item* items, int32_t n_items, int32_t total_blocks);
+
 /* gn_transpose2d of one matrix that also yields sums[g][cols] += the column sums of row block g (groups = 1: bias gradient;
  * groups = batch: per-sample time-shift gradient; sums2 / groups2: an optional second grouping from the same pass) -- the
  * weight-gradient path transposes dY anyway.  (rows / groups) % 64 == 0; workspace: ceil(rows / 64) * cols floats.  Replaces the

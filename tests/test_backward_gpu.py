@@ -5,7 +5,7 @@ import torch.nn.functional as F
 
 from genima_amd import train_ops as T
 from genima_amd.packing import pack_conv_weight
-from util import assert_close, q16, rel_l2
+from util import assert_close, q16, randn_h, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -349,3 +349,34 @@ def test_wgrad_conv_natural_layout(engine, B, H, C, N, ks, stride):
     dw = torch.zeros(N, ks * ks * C, device="cuda")
     T.wgrad(engine, h(nhwc(dy)), h(nhwc(x)), dw, ksize=ks, stride=stride, pad=ks // 2)
     assert_close(dw, ref, rel=5e-4, what=f"conv wgrad {C}->{N} k{ks} s{stride}")
+
+
+def test_transpose2d_multi_matches_single_launches(engine):
+    """gn_transpose2d_multi: a table of Linear weights (W^T) and packed 3x3 conv weights (tap-rotated data-gradient form) in one launch,
+    bit for bit what the separate gn_transpose2d launches write."""
+    import ctypes as C
+    from genima_amd import train_ops as T
+    from genima_amd._lib import check
+    ws = [(randn_h(320, 1280, seed=1), 0), (randn_h(640, 9 * 320, seed=2), 9), (randn_h(72, 200, seed=3), 0), (randn_h(128, 4 * 64, seed=4), 4)]
+    refs, outs, rows, blocks = [], [], [], 0
+    for w, taps in ws:
+        if taps:
+            Cout, K = w.shape
+            Cin = K // taps
+            refs.append(T.conv_weight_dgrad(engine, w, taps))
+            out = torch.zeros_like(refs[-1])
+            it = (w.data_ptr(), out.data_ptr() + 2 * (taps - 1) * Cout, taps * Cin, taps * Cout, Cin, -Cout, Cout, Cin, taps)
+        else:
+            N, K = w.shape
+            refs.append(T.transpose2d(engine, w, N, K))
+            out = torch.zeros_like(refs[-1])
+            it = (w.data_ptr(), out.data_ptr(), K, out.stride(0), 0, 0, N, K, 1)
+        src, dst, ld_in, ld_out, in_bs, out_bs, r, c, batch = it
+        rows.append([src, dst, ld_in, ld_out, in_bs, out_bs, (r & 0xFFFFFFFF) | (c << 32), (batch & 0xFFFFFFFF) | (blocks << 32)])
+        blocks += batch * (-(-r // 64)) * (-(-c // 64))
+        outs.append(out)
+    table = torch.tensor(rows, dtype=torch.int64).cuda()
+    check(engine.lib.gn_transpose2d_multi(engine._ctx, table.data_ptr(), len(rows), blocks), "gn_transpose2d_multi")
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
