@@ -167,6 +167,7 @@ class GradBuckets:
                 if off < e and off + numel > a:
                     ready[b] = min(ready[b], fu)
         self.ready, self.works, self.fired = ready, [], []
+        self.fire_indices = set(ready)  # tape indices after which some bucket's exchange is launched (Graph.backward joins its side stream there)
 
     def entry_done(self, index: int):
         for b, r in enumerate(self.ready):

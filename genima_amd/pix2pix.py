@@ -274,6 +274,8 @@ class InstructPix2PixTrainer(ControlNetTrainer):
         if buckets is not None and self._will_sync():
             buckets.begin(self.cn.grad, self.cn.layout, g.first_use, len(g.tape))
             g.on_entry_done = buckets.entry_done
+            g.fire_indices = getattr(buckets, "fire_indices", None)
+        self._side_wgrad(g)
         g.backward()
         self.last["pred"] = pred.t
         return loss
