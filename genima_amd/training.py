@@ -671,12 +671,10 @@ def t_controlnet(g: Graph, net: TrainParams, cfg, x8: torch.Tensor, t_dev: torch
     return outs, mid
 
 
-def t_unet(g: Graph, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx: torch.Tensor, ctx_pad: torch.Tensor,
-           nk_valid: int, down_res: Sequence[Var], mid_res: Var, added=None) -> Var:
-    """Frozen UNet: encoder + mid through the fused inference lowering (no gradient flows there), decoder with activations kept
-    so that d(loss)/d(residuals) reaches the ControlNet (diffusion/train_controlnet_genima.py:1377-1388)."""
-    E, W = g.E, net.W
-    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+def unet_frozen_front(E: Engine, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx: torch.Tensor, added=None):
+    """The part of the frozen UNet that no gradient and no ControlNet output reaches -- time shifts, conv_in, encoder, mid block -- through
+    the fused inference lowering: -> (shifts, h, skips).  The trainer runs it on a second stream beside the ControlNet's forward."""
+    W = net.W
     shifts = graphs.emit_time_shifts(E, W, cfg, t_dev, added)
     kv_inf = graphs.emit_cross_kv(E, W, ctx, "unet_train")
     h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"])
@@ -686,7 +684,16 @@ def t_unet(g: Graph, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tens
         h = graphs._emit_mid(E, W, cfg, h, shifts, kv_inf)
     finally:
         E.ln_fold = fold
-    del kv_inf
+    return shifts, h, skips
+
+
+def t_unet(g: Graph, net: FrozenParams, cfg, x8: torch.Tensor, t_dev: torch.Tensor, ctx: torch.Tensor, ctx_pad: torch.Tensor,
+           nk_valid: int, down_res: Sequence[Var], mid_res: Var, added=None, pre=None) -> Var:
+    """Frozen UNet: encoder + mid through the fused inference lowering (no gradient flows there), decoder with activations kept
+    so that d(loss)/d(residuals) reaches the ControlNet (diffusion/train_controlnet_genima.py:1377-1388)."""
+    E, W = g.E, net.W
+    G, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    shifts, h, skips = pre if pre is not None else unet_frozen_front(E, net, cfg, x8, t_dev, ctx, added)
     skips = [g.add(Var(s, needs=False), r) for s, r in zip(skips, down_res)]
     hv = g.add(Var(h, needs=False), mid_res)
     kv = t_cross_kv(g, net, Var(ctx_pad, needs=False), _attn2_prefixes(W, ("up_blocks.",)))
@@ -813,8 +820,28 @@ class ControlNetTrainer:
         g = Graph(E)
         noisy = E.add_noise(latents8, noise8, sqrt_ac, sqrt_1mac)
         ctx_pad, L = pad_context(ctx), ctx.shape[1]
+        # the frozen UNet's encoder + mid need neither the ControlNet nor a tape: on a second stream beside the ControlNet's forward
+        pre, side = None, None
+        if not torch.cuda.is_current_stream_capturing() and os.environ.get("GN_FWD_SIDE", "1") != "0":
+            if getattr(self, "_fwd_stream", None) is None:
+                self._fwd_stream = torch.cuda.Stream(E.device)
+            side, main = self._fwd_stream, E.stream
+            side.wait_stream(main)
+            E.use_stream(side)
+            E._on_side = True
+            try:
+                with torch.cuda.stream(side):
+                    pre = unet_frozen_front(E, self.unet, self.unet_cfg, noisy, t_dev, ctx, added)
+            finally:
+                E.use_stream(main)
+                E._on_side = False
         down, mid = t_controlnet(g, self.cn, self.cn_cfg, noisy, t_dev, ctx_pad, L, cond8, added)
-        pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid, added)
+        if side is not None:
+            E.stream.wait_stream(side)
+            for t in (pre[0], pre[1], *pre[2]):  # allocated in the side stream's pool, consumed on the main stream
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(E.stream)
+        pred = t_unet(g, self.unet, self.unet_cfg, noisy, t_dev, ctx, ctx_pad, L, down, mid, added, pre=pre)
         loss, dpred = T.mse_loss(E, pred.t, noise8, c_valid, grad_scale=self.loss_scale / self.grad_accum)
         pred.cell[0] = dpred
         buckets = self.allreduce if hasattr(self.allreduce, "begin") else None
