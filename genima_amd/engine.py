@@ -317,7 +317,10 @@ class Engine:
     def _workspace(self, nbytes: int) -> torch.Tensor:
         """f32 split-K / GroupNorm scratch: one shared grow-only buffer per stream (ops on one stream run in order)."""
         n = _round_up(nbytes, 256) // 4
-        key = "__workspace_side__" if getattr(self, "_on_side", False) else "__workspace__"
+        # one buffer per stream: `_on_side` is False (the main stream), True (a recorded program's side stream) or a tag naming one of the
+        # trainer's extra streams -- they run CONCURRENTLY with each other (the next step's front starts under the previous step's backward)
+        side = getattr(self, "_on_side", False)
+        key = "__workspace__" if not side else ("__workspace_side__" if side is True else f"__workspace_{side}__")
         cur = self.buffers.get(key)
         if cur is None or cur.numel() < n:
             if self.record and cur is not None:

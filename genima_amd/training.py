@@ -225,7 +225,7 @@ class Graph:
         self._side_keep.extend(keep)
         self._side_dirty = True
         E.use_stream(self._side)
-        E._on_side = True  # its own split-K workspace
+        E._on_side = "wgrad"  # its own split-K workspace
         try:
             with torch.cuda.stream(self._side):  # temporaries belong to the side stream's allocator pool
                 yield
@@ -800,6 +800,40 @@ class ControlNetTrainer:
         self._clip = torch.zeros(3, dtype=F32, device=E.device)
         self.last = {}
 
+    # ---- GradScaler bookkeeping read back LATE: the found-inf flag of step k is needed on the host only when step k + 1 scales its loss
+    # (or anyone looks at loss_scale / opt_step / sched_step / last), so step() leaves an asynchronous copy + event behind instead of
+    # blocking on it -- the host goes on to issue step k + 1's front (VAE / CLIP encode, on their own stream) under step k's optimizer.
+    def _scaler_state(name):  # noqa: N805 -- a property factory evaluated in the class body
+        def get(self):
+            self._flush_scale()
+            return self.__dict__["_st_" + name]
+
+        def put(self, value):
+            if "_st_" + name in self.__dict__:
+                self._flush_scale()
+            self.__dict__["_st_" + name] = value
+        return property(get, put)
+
+    loss_scale = _scaler_state("loss_scale")
+    _clean = _scaler_state("_clean")
+    opt_step = _scaler_state("opt_step")
+    sched_step = _scaler_state("sched_step")
+    last = _scaler_state("last")
+    del _scaler_state
+
+    def _flush_scale(self):
+        pend = self.__dict__.get("_scale_pending")
+        if pend is None:
+            return
+        self.__dict__["_scale_pending"] = None
+        host, ev = pend
+        ev.synchronize()
+        self._apply_scale(*host.tolist())
+
+    def flush(self):
+        """Apply whatever bookkeeping of the last optimizer step is still in flight (a host wait for that step's clip kernel)."""
+        self._flush_scale()
+
     def enable_fp8_frozen(self) -> int:
         """BASELINE configs[4] ("fp8 MFMA"): run the frozen UNet's transformer Linears (attention projections, GEGLU and FF-out:
         68 % of the SDXL UNet's FLOPs) on the fp8 MFMA in the FORWARD pass -- weights quantised once with
@@ -828,7 +862,7 @@ class ControlNetTrainer:
             side, main = self._fwd_stream, E.stream
             side.wait_stream(main)
             E.use_stream(side)
-            E._on_side = True
+            E._on_side = "fwd"
             try:
                 with torch.cuda.stream(side):
                     pre = unet_frozen_front(E, self.unet, self.unet_cfg, noisy, t_dev, ctx, added)
@@ -884,7 +918,22 @@ class ControlNetTrainer:
 
     def update_scale(self) -> bool:
         """GradScaler.update(): one host read of the found-inf flag.  Returns True when the step was applied."""
-        coef, norm, bad = self._clip.tolist()
+        self._flush_scale()
+        return self._apply_scale(*self._clip.tolist())
+
+    def update_scale_async(self):
+        """The same, without waiting: the three scalars go to pinned host memory behind the optimizer's kernels; any later look at the
+        scaler's state (the next step's loss scaling at the latest) applies them."""
+        self._flush_scale()
+        if self.__dict__.get("_clip_host") is None:
+            self.__dict__["_clip_host"] = torch.empty(3, dtype=F32, pin_memory=True)
+        host = self.__dict__["_clip_host"]
+        host.copy_(self._clip, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(self.E.stream)
+        self.__dict__["_scale_pending"] = (host, ev)
+
+    def _apply_scale(self, coef, norm, bad) -> bool:
         self.last["grad_norm"] = norm
         if bad:
             self.loss_scale *= 0.5
@@ -944,7 +993,10 @@ class ControlNetTrainer:
         self._micro = 0 if self.end_of_dataloader else self._micro + 1  # accelerate restarts its micro-step count with the dataloader
         if self.sync_gradients:  # gradients of the micro-batches accumulate in the flat buffer until here
             self.optimizer_step()
-            self.update_scale()
+            if os.environ.get("GN_DEFER_SCALE", "1") != "0":
+                self.update_scale_async()
+            else:
+                self.update_scale()
         return loss
 
     # ---- checkpoints: diffusers ControlNet directory + optimizer state (diffusion/train_controlnet_genima.py:1077-1105, 1416-1457, 1486)
@@ -1020,6 +1072,39 @@ class ControlNetTrainer:
         ``input_ids`` [b, 77] -- the collate_fn output of diffusion/train_controlnet_genima.py:934-964 -- or the uint8 batch of
         data.collate_u8 (``pixel_values_u8`` / ``conditioning_pixel_values_u8``).  Returns the device loss."""
         E, dev = self.E, self.E.device
+        # The front of the step -- upload, augmentation, VAE encode, noise draws, text tower(s): frozen networks and fresh inputs only -- runs
+        # on its own stream: with the scaler's read-back deferred (update_scale_async) the host gets here while the previous step's
+        # optimizer is still executing, and the compute-bound encode overlaps the memory-bound AdamW pass.  GN_FRONT_SIDE=0: main stream.
+        side = None
+        if os.environ.get("GN_FRONT_SIDE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
+            if getattr(self, "_front_stream", None) is None:
+                self._front_stream = torch.cuda.Stream(dev)
+            side, main = self._front_stream, E.stream
+            E.use_stream(side)
+            E._on_side = "front"
+        try:
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                lat8, noise8, t, sa, s1, ctx, cond8, added = self._front(batch)
+                t_dev, sa, s1 = t.to(dev, F32), sa.to(dev), s1.to(dev)
+        finally:
+            if side is not None:
+                E.use_stream(main)
+                E._on_side = False
+        if side is not None:
+            main.wait_stream(side)
+            for x in (lat8, noise8, t_dev, sa, s1, ctx, cond8) + (tuple(added) if added is not None else ()):
+                x.record_stream(main)  # allocated in the front stream's pool, consumed on the main stream
+        loss = self.step(lat8, noise8, t_dev, sa, s1, ctx, cond8, added)
+        self._steps_seen += 1
+        if self._gc_freeze and self._steps_seen == 2:
+            import gc
+
+            gc.collect()
+            gc.freeze()
+        return loss
+
+    def _front(self, batch):
+        E, dev = self.E, self.E.device
         if "pixel_values_u8" in batch:  # the uint8 NHWC host batch of genima_amd/data.py: ToTensor + Normalize happen on the device
             from .data import to_device
             batch = to_device(E, batch)
@@ -1054,11 +1139,4 @@ class ControlNetTrainer:
             E.copy4d(pen_g, ctx[:, :, dl:], (1, 1, B, L), (0, 0, L * dg, dg), (0, 0, L * (dl + dg), dl + dg), dg)
             R = float(x8.shape[1])
             added = (pooled, torch.tensor([[R, R, 0.0, 0.0, R, R]] * B, dtype=F32, device=dev))
-        loss = self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8, added)
-        self._steps_seen += 1
-        if self._gc_freeze and self._steps_seen == 2:
-            import gc
-
-            gc.collect()
-            gc.freeze()
-        return loss
+        return lat8, noise8, t, sa, s1, ctx, cond8, added
