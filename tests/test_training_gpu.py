@@ -127,3 +127,33 @@ def test_checkpoint_resume_is_bit_exact(tmp_path):
     m = ControlNetModel.from_pretrained(str(tmp_path / "cn"))
     sd = a.controlnet_state_dict()
     assert all(torch.equal(m.state_dict()[k], sd[k].cpu()) for k in sd)
+
+
+def test_overlapped_step_equals_the_serial_step(monkeypatch):
+    """The default step -- weight gradients, the frozen UNet's encoder on their own streams, derived weights rebuilt in one launch, the
+    GradScaler's flag read back late (an overflow at step 2 included) -- against the serial step (every switch off): the same losses,
+    loss scales and master weights, bit for bit."""
+    ucfg, ccfg, usd, csd, lat, noise, ctx, cond, t, sa, s1 = _setup()
+    dev = lambda x: x.cuda()  # noqa: E731
+    args = (dev(nchw_to_nhwc(lat, 8).half()), dev(nchw_to_nhwc(noise, 8).half()), dev(t.float()), dev(sa), dev(s1), dev(ctx.half()),
+            dev(nchw_to_nhwc(cond, 8).half()))
+    unet_W = pack_state_dict(usd, "cuda")
+
+    def run(serial: bool):
+        for k in ("GN_WGRAD_SIDE", "GN_FWD_SIDE", "GN_MULTI_WT", "GN_DEFER_SCALE", "GN_FRONT_SIDE"):
+            if serial:
+                monkeypatch.setenv(k, "0")
+            else:
+                monkeypatch.delenv(k, raising=False)
+        tr = ControlNetTrainer(Engine("cuda:0"), ucfg, ccfg, unet_W, csd, lr=1e-4, loss_scale=2.0 ** 30)  # overflows: the scale backs off first
+        losses, scales = [], []
+        for _ in range(12):
+            losses.append(float(tr.step(*args).cpu()))
+            scales.append(tr.loss_scale)  # (a flushing property under the deferred read-back)
+        return losses, scales, tr.opt_step, tr.cn.master.clone()
+
+    l0, s0, o0, m0 = run(serial=True)
+    l1, s1_, o1, m1 = run(serial=False)
+    assert s0[0] < 2.0 ** 30 and o0 >= 1, f"the test wants skipped (overflowed) AND applied steps: scales {s0}, applied {o0}"
+    assert l0 == l1 and s0 == s1_ and o0 == o1
+    assert torch.equal(m0, m1)
