@@ -123,8 +123,12 @@ def _worker_rccl_order(rank, world, port, q):
     grad = base * (rank + 1)
     bk = gd.GradBuckets(n_buckets=4, align=8)
     bk.begin(grad, layout, first_use, 10)
+    # the trainer joins its weight-gradient stream exactly where an exchange is launched: fire_indices must name those entries
+    assert bk.fire_indices == set(bk.ready) and len(bk.fire_indices) >= 2
     for i in range(10, -1, -1):
+        before = len(log)
         bk.entry_done(i)
+        assert (len(log) > before) == (i in bk.fire_indices), (i, bk.fire_indices)
     issued = [e for e in log if e[0] != "wait"]
     assert not any(e[0] == "wait" for e in log), "no collective may be waited on inside the backward walk"
     assert all(e[3] for e in issued), "the RCCL path must issue asynchronously"
