@@ -336,6 +336,13 @@ class InstructPix2PixTrainer(ControlNetTrainer):
         E, dev = self.E, self.E.device
         if self.vae_W is None:
             raise GenimaHipError("attach_frozen(...) first")
+        args = self._on_front_stream(lambda: self._front_p2p(batch))  # (ControlNetTrainer: the front of the step on its own stream)
+        loss = self.step(*args)
+        self._steps_seen += 1
+        return loss
+
+    def _front_p2p(self, batch):
+        E, dev = self.E, self.E.device
         edited8 = self._nhwc8(batch["edited_pixel_values"])
         orig8 = self._nhwc8(batch["original_pixel_values"])
         ids = batch["input_ids"].to(dev, torch.int32).contiguous()
@@ -353,9 +360,7 @@ class InstructPix2PixTrainer(ControlNetTrainer):
         if self.cdp is not None:
             random_p = torch.rand(B, generator=self._gen_cpu)
             ctx, img_mom = self.apply_conditioning_dropout(ctx, img_mom, random_p)
-        loss = self.step(lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, img_mom)
-        self._steps_seen += 1
-        return loss
+        return lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, img_mom
 
     def apply_conditioning_dropout(self, ctx, img_mom, random_p: torch.Tensor):
         """:1204-1233 -- prompt rows with random_p < 2p become the encoding of ``""``; image latents are zeroed where p <= random_p < 3p

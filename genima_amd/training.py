@@ -1075,25 +1075,10 @@ class ControlNetTrainer:
         # The front of the step -- upload, augmentation, VAE encode, noise draws, text tower(s): frozen networks and fresh inputs only -- runs
         # on its own stream: with the scaler's read-back deferred (update_scale_async) the host gets here while the previous step's
         # optimizer is still executing, and the compute-bound encode overlaps the memory-bound AdamW pass.  GN_FRONT_SIDE=0: main stream.
-        side = None
-        if os.environ.get("GN_FRONT_SIDE", "1") != "0" and not torch.cuda.is_current_stream_capturing():
-            if getattr(self, "_front_stream", None) is None:
-                self._front_stream = torch.cuda.Stream(dev)
-            side, main = self._front_stream, E.stream
-            E.use_stream(side)
-            E._on_side = "front"
-        try:
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                lat8, noise8, t, sa, s1, ctx, cond8, added = self._front(batch)
-                t_dev, sa, s1 = t.to(dev, F32), sa.to(dev), s1.to(dev)
-        finally:
-            if side is not None:
-                E.use_stream(main)
-                E._on_side = False
-        if side is not None:
-            main.wait_stream(side)
-            for x in (lat8, noise8, t_dev, sa, s1, ctx, cond8) + (tuple(added) if added is not None else ()):
-                x.record_stream(main)  # allocated in the front stream's pool, consumed on the main stream
+        def front():
+            lat8, noise8, t, sa, s1, ctx, cond8, added = self._front(batch)
+            return lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8, added
+        lat8, noise8, t_dev, sa, s1, ctx, cond8, added = self._on_front_stream(front)
         loss = self.step(lat8, noise8, t_dev, sa, s1, ctx, cond8, added)
         self._steps_seen += 1
         if self._gc_freeze and self._steps_seen == 2:
@@ -1102,6 +1087,30 @@ class ControlNetTrainer:
             gc.collect()
             gc.freeze()
         return loss
+
+    def _on_front_stream(self, fn):
+        """Run ``fn`` (the step's front: frozen networks and fresh inputs only) on the front stream; its tensor outputs (tuples one level
+        deep) are handed to the main stream.  GN_FRONT_SIDE=0: on the main stream."""
+        E = self.E
+        if os.environ.get("GN_FRONT_SIDE", "1") == "0" or torch.cuda.is_current_stream_capturing():
+            return fn()
+        if getattr(self, "_front_stream", None) is None:
+            self._front_stream = torch.cuda.Stream(E.device)
+        side, main = self._front_stream, E.stream
+        E.use_stream(side)
+        E._on_side = "front"
+        try:
+            with torch.cuda.stream(side):
+                out = fn()
+        finally:
+            E.use_stream(main)
+            E._on_side = False
+        main.wait_stream(side)
+        for x in out:
+            for y in (x if isinstance(x, (tuple, list)) else (x,)):
+                if isinstance(y, torch.Tensor) and y.is_cuda:
+                    y.record_stream(main)  # allocated in the front stream's pool, consumed on the main stream
+        return out
 
     def _front(self, batch):
         E, dev = self.E, self.E.device
