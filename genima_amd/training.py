@@ -846,17 +846,18 @@ class ControlNetTrainer:
         return len(ws)
 
     # ---- forward + backward: fills self.cn.grad (loss-scaled) and returns the device loss scalar
-    def forward_backward(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, c_valid: int = 4, added=None):
+    def forward_backward(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, c_valid: int = 4, added=None, early=None):
         """latents8 / noise8: f16 [B, h, w, 8] (channels >= c_valid zero); t_dev f32 [B] timesteps; sqrt_ac / sqrt_1mac f32 [B]
         (DDPMScheduler.add_noise coefficients); ctx f16 [B, L, D] prompt states; cond8 f16 [B, H, W, 8] conditioning image in [0, 1];
         added = (text_embeds f16 [B, P], time_ids f32 [B, 6]) for the SDXL family (train_controlnet_sdxl_genima.py:1448-1471)."""
         E = self.E
         g = Graph(E)
-        noisy = E.add_noise(latents8, noise8, sqrt_ac, sqrt_1mac)
+        # ``early`` = (noisy latents, unet_frozen_front's result) already produced on the front stream (train_step)
+        noisy = early[0] if early is not None else E.add_noise(latents8, noise8, sqrt_ac, sqrt_1mac)
         ctx_pad, L = pad_context(ctx), ctx.shape[1]
         # the frozen UNet's encoder + mid need neither the ControlNet nor a tape: on a second stream beside the ControlNet's forward
-        pre, side = None, None
-        if not torch.cuda.is_current_stream_capturing() and os.environ.get("GN_FWD_SIDE", "1") != "0":
+        pre, side = (early[1] if early is not None else None), None
+        if pre is None and not torch.cuda.is_current_stream_capturing() and os.environ.get("GN_FWD_SIDE", "1") != "0":
             if getattr(self, "_fwd_stream", None) is None:
                 self._fwd_stream = torch.cuda.Stream(E.device)
             side, main = self._fwd_stream, E.stream
@@ -987,8 +988,11 @@ class ControlNetTrainer:
         self.last["pred"] = rec["pred"]
         return rec["loss"]
 
-    def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=None) -> torch.Tensor:
-        loss = self._forward_backward_replayed(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
+    def step(self, latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=None, early=None) -> torch.Tensor:
+        if early is not None and not self._use_graph:
+            loss = self.forward_backward(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added, early=early)
+        else:
+            loss = self._forward_backward_replayed(latents8, noise8, t_dev, sqrt_ac, sqrt_1mac, ctx, cond8, added=added)
         self.sync_gradients = self._will_sync()
         self._micro = 0 if self.end_of_dataloader else self._micro + 1  # accelerate restarts its micro-step count with the dataloader
         if self.sync_gradients:  # gradients of the micro-batches accumulate in the flat buffer until here
@@ -1075,11 +1079,21 @@ class ControlNetTrainer:
         # The front of the step -- upload, augmentation, VAE encode, noise draws, text tower(s): frozen networks and fresh inputs only -- runs
         # on its own stream: with the scaler's read-back deferred (update_scale_async) the host gets here while the previous step's
         # optimizer is still executing, and the compute-bound encode overlaps the memory-bound AdamW pass.  GN_FRONT_SIDE=0: main stream.
+        early_ok = os.environ.get("GN_FRONT_UNET", "1") != "0" and os.environ.get("GN_FRONT_SIDE", "1") != "0" and not self._use_graph
+
         def front():
             lat8, noise8, t, sa, s1, ctx, cond8, added = self._front(batch)
-            return lat8, noise8, t.to(dev, F32), sa.to(dev), s1.to(dev), ctx, cond8, added
-        lat8, noise8, t_dev, sa, s1, ctx, cond8, added = self._on_front_stream(front)
-        loss = self.step(lat8, noise8, t_dev, sa, s1, ctx, cond8, added)
+            t_dev, sa, s1 = t.to(dev, F32), sa.to(dev), s1.to(dev)
+            early = None
+            if early_ok:  # the frozen UNet's encoder + mid as well: they need the noisy latents, the timesteps and the prompt states only
+                noisy = E.add_noise(lat8, noise8, sa, s1)
+                sh, h, skips = unet_frozen_front(E, self.unet, self.unet_cfg, noisy, t_dev, ctx, added)
+                early = (noisy, sh, h, tuple(skips))
+            return lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early
+        lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early = self._on_front_stream(front)
+        if early is not None:
+            early = (early[0], (early[1], early[2], list(early[3])))
+        loss = self.step(lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early=early)
         self._steps_seen += 1
         if self._gc_freeze and self._steps_seen == 2:
             import gc
@@ -1106,10 +1120,14 @@ class ControlNetTrainer:
             E.use_stream(main)
             E._on_side = False
         main.wait_stream(side)
-        for x in out:
-            for y in (x if isinstance(x, (tuple, list)) else (x,)):
-                if isinstance(y, torch.Tensor) and y.is_cuda:
-                    y.record_stream(main)  # allocated in the front stream's pool, consumed on the main stream
+        def hand_over(x):  # allocated in the front stream's pool, consumed on the main stream
+            if isinstance(x, torch.Tensor):
+                if x.is_cuda:
+                    x.record_stream(main)
+            elif isinstance(x, (tuple, list)):
+                for y in x:
+                    hand_over(y)
+        hand_over(out)
         return out
 
     def _front(self, batch):
