@@ -288,7 +288,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the `train` extra (BASELINE.json's second metric: ControlNet train steps/s)")
     ap.add_argument("--no-single-view", action="store_true", help="skip the `single_view_b1` extra (configs[1] latency, hipGraph)")
-    ap.add_argument("--train-steps", type=int, default=5)
+    ap.add_argument("--train-steps", type=int, default=10)
     ap.add_argument("--no-act", action="store_true", help="skip the ACT controller forward after each pipeline call")
     ap.add_argument("--dump-ops", default=None, help="write the per-(kernel, shape) HIP-event timing table of one call to this CSV")
     args = ap.parse_args()
@@ -481,7 +481,8 @@ def main():
         try:
             import bench_train
 
-            targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "2"])
+            targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "3"])  # (as `bench_train.py --steps 10 --warmup 3`: the trainer builds its lazily
+            # derived state -- weight copies, their one-launch table, gc.freeze -- in its first steps, and consecutive steps overlap)
             line = bench_train.run(targs)
             if rank == 0 and line is not None:
                 out["train"] = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "samples_per_sec",
