@@ -73,7 +73,7 @@ def run(args, quiet: bool = False):
     def synth(sch, seed):
         return weights.synth_state_dict(sch, seed, device=dev)
 
-    unet_W = pack_state_dict(synth(schema.unet_schema(fam["unet"]), 1), dev)
+    unet_W = pack_state_dict(synth(schema.unet_schema(fam["unet"]), 1), dev, up_phases=False)  # the tape runs the fused-upsample 3x3 launch
     vae_W = pack_state_dict(synth(schema.vae_schema(fam["vae"]), 3), dev)
     text_W = pack_state_dict(synth(schema.clip_text_schema(fam["text"]), 4), dev)
     cn_sd = synth(schema.controlnet_schema(fam["controlnet"]), 2)

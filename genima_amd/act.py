@@ -425,6 +425,14 @@ class GenimaACT:
         """``agent.load_state_dict(ckpt["agent"], strict=False)`` (controller/eval_genima.py:91-103): RoboBase key families are mapped
         by ``robobase_key_map``; with ``strict=False`` unknown keys are reported, not fatal -- but a checkpoint that fills NONE of the
         forward's weights is an error (a silently random-initialised controller would act plausibly and wrongly)."""
+        if getattr(self, "_trainer", None) is not None:
+            # update() calls trained on the device: pull those weights to the host copy first, so that keys a partial checkpoint does not
+            # carry keep their TRAINED values (ADVICE r3), and say that the optimizer state goes with the trainer
+            import warnings
+
+            self._own_state()
+            warnings.warn("GenimaACT.load_state_dict: discarding the live ACT trainer (Adam moments, step count); keys missing from the "
+                          "checkpoint keep their trained values")
         inv = {v: k for k, v in self.key_aliases.items()}
         new = {}
         for k, v in sd.items():

@@ -82,7 +82,11 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
   }
   // conv: (b, oy, ox) of the row each B piece loads, advanced by 64 rows per K tile without divisions
   int pb[GB], py[GB], px[GB];
-  const int q64 = CONV ? 64 / tp.Wo : 0, r64 = CONV ? 64 % tp.Wo : 0;
+  // 64 rows = qb64 whole images + qy64 image rows + qx64 pixels (mixed radix Ho * Wo, Wo): exact for ANY feature-map size -- a 4 x 4 map
+  // (Ho * Wo = 16) wraps the image index four times per K tile
+  const int hw64 = CONV ? tp.Ho * tp.Wo : 1;
+  const int qb64 = CONV ? 64 / hw64 : 0, rem64 = CONV ? 64 % hw64 : 0;
+  const int qy64 = CONV ? rem64 / tp.Wo : 0, qx64 = CONV ? rem64 % tp.Wo : 0;
   if constexpr (CONV) {
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
@@ -115,15 +119,14 @@ __global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) v
         const int iy = py[i] * tp.stride - tp.pad + tdy[i], ix = px[i] * tp.stride - tp.pad + tdx[i];
         const bool ok = r < rend && n0 + lc < p.N && (unsigned)iy < (unsigned)tp.H && (unsigned)ix < (unsigned)tp.W;
         voff = ok ? (unsigned)(((((long)pb[i] * tp.H + iy) * tp.W + ix) * tp.C + tcc[i]) * 2) : kOOB;
-        // next K tile: 64 rows further -- selects, not branches (64 <= Ho * Wo, so the image index steps at most once besides the carry)
-        px[i] += r64; py[i] += q64;
+        // next K tile: 64 rows further -- selects, not branches: each digit carries at most once (qx64 < Wo, qy64 < Ho)
+        px[i] += qx64;
         const int cx = px[i] >= tp.Wo ? 1 : 0;
-        px[i] -= cx ? tp.Wo : 0; py[i] += cx;
-#pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-          const int cy = py[i] >= tp.Ho ? 1 : 0;
-          py[i] -= cy ? tp.Ho : 0; pb[i] += cy;
-        }
+        px[i] -= cx ? tp.Wo : 0;
+        py[i] += qy64 + cx;
+        const int cy = py[i] >= tp.Ho ? 1 : 0;
+        py[i] -= cy ? tp.Ho : 0;
+        pb[i] += qb64 + cy;
       } else {
         voff = (r < rend && n0 + lc < p.N) ? (unsigned)((r * p.ldw + n0 + lc) * 2) : kOOB;
       }

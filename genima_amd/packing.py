@@ -168,9 +168,12 @@ def pack_upsample_phases(w: torch.Tensor, dtype=torch.float16) -> torch.Tensor:
     return out.to(dtype).contiguous()
 
 
-def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) -> "OrderedDict[str, torch.Tensor]":
+def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16, up_phases: bool = True) -> "OrderedDict[str, torch.Tensor]":
     """Generic packer for UNet / ControlNet / VAE / CLIP-text state dicts (see module docstring for the derived entries).
-    ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams)."""
+    ``dtype=torch.float32`` gives the same layout for the fp32 master copy of a trainable network (training.TrainParams).
+    ``up_phases=False`` skips the four-phase copies of the upsampler convs (``*.up4.weight``, 16 / 9 of the 3x3 weight's bytes): dicts
+    handed to the trainers, whose tape only runs the fused-upsample 3x3 launch, do not need them.  The phase path sums taps in fp32 and
+    rounds once, so it differs from the 3x3 launch by f16 rounding of the summed weights (6e-4 rel-L2, tests/test_upsample_phases_gpu.py)."""
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     temb_w, temb_b, temb_slices, off = [], [], OrderedDict(), 0
     # f16 copies for a ROCm device: the two layout shuffles run as the library's own gn_pack_* kernels on the uploaded tensors (the same
@@ -184,7 +187,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16) ->
         t = t.detach().to(torch.float32)
         if t.dim() == 4:
             out[name] = hip.pack_conv_weight(t.to(hip.device)) if hip is not None else pack_conv_weight(t, dtype=dtype)
-            if dtype == torch.float16 and ".upsamplers." in name and tuple(t.shape[2:]) == (3, 3):
+            if up_phases and dtype == torch.float16 and ".upsamplers." in name and tuple(t.shape[2:]) == (3, 3):
                 # inference graphs run the nearest-2x + 3x3 conv as four 2x2 phase convs on the source pixels (4 / 9 of the work)
                 out[name[: -len("weight")] + "up4.weight"] = pack_upsample_phases(t, dtype=dtype)
             bn = name[: -len("weight")] + "bias"

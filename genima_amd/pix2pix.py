@@ -336,7 +336,7 @@ class InstructPix2PixTrainer(ControlNetTrainer):
         E, dev = self.E, self.E.device
         if self.vae_W is None:
             raise GenimaHipError("attach_frozen(...) first")
-        args = self._on_front_stream(lambda: self._front_p2p(batch))  # (ControlNetTrainer: the front of the step on its own stream)
+        args = self._on_front_stream(lambda: self._front_p2p(batch), batch)  # (ControlNetTrainer: the front of the step on its own stream)
         loss = self.step(*args)
         self._steps_seen += 1
         return loss

@@ -935,7 +935,8 @@ class ControlNetTrainer:
         if self.__dict__.get("_clip_host") is None:
             self.__dict__["_clip_host"] = torch.empty(3, dtype=F32, pin_memory=True)
         host = self.__dict__["_clip_host"]
-        host.copy_(self._clip, non_blocking=True)
+        with torch.cuda.stream(self.E.stream):  # the copy must sit behind the optimizer's kernels on the ENGINE's stream, whatever the caller's is
+            host.copy_(self._clip, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(self.E.stream)
         self.__dict__["_scale_pending"] = (host, ev)
@@ -1096,7 +1097,7 @@ class ControlNetTrainer:
                 sh, h, skips = unet_frozen_front(E, self.unet, self.unet_cfg, noisy, t_dev, ctx, added)
                 early = (noisy, sh, h, tuple(skips))
             return lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early
-        lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early = self._on_front_stream(front)
+        lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early = self._on_front_stream(front, batch)
         if early is not None:
             early = (early[0], (early[1], early[2], list(early[3])))
         loss = self.step(lat8, noise8, t_dev, sa, s1, ctx, cond8, added, early=early)
@@ -1108,15 +1109,22 @@ class ControlNetTrainer:
             gc.freeze()
         return loss
 
-    def _on_front_stream(self, fn):
+    def _on_front_stream(self, fn, inputs=None):
         """Run ``fn`` (the step's front: frozen networks and fresh inputs only) on the front stream; its tensor outputs (tuples one level
-        deep) are handed to the main stream.  GN_FRONT_SIDE=0: on the main stream."""
+        deep) are handed to the main stream.  GN_FRONT_SIDE=0: on the main stream.  ``inputs``: the caller's batch -- DEVICE tensors in it may
+        still be in flight on the caller's current stream (a pinned ``.to(dev, non_blocking=True)``, on-device augmentation), so the front
+        stream waits for that stream first; host batches (the DataLoader's uint8 path, uploaded on the front stream itself) keep the full overlap."""
         E = self.E
         if os.environ.get("GN_FRONT_SIDE", "1") == "0" or torch.cuda.is_current_stream_capturing():
             return fn()
         if getattr(self, "_front_stream", None) is None:
             self._front_stream = torch.cuda.Stream(E.device)
         side, main = self._front_stream, E.stream
+        dev_in = [v for v in (inputs.values() if isinstance(inputs, dict) else (inputs or ())) if isinstance(v, torch.Tensor) and v.is_cuda]
+        if dev_in:
+            side.wait_stream(torch.cuda.current_stream(E.device))
+            for v in dev_in:
+                v.record_stream(side)
         E.use_stream(side)
         E._on_side = "front"
         try:

@@ -335,7 +335,9 @@ def test_wgrad_linear_natural_layout(engine, R, N, K, tile):
 
 
 @pytest.mark.parametrize("B,H,C,N,ks,stride", [(2, 16, 64, 72, 3, 1), (2, 32, 128, 128, 3, 1), (3, 16, 320, 320, 3, 2), (2, 12, 64, 64, 1, 1),
-                                               (8, 32, 640, 640, 3, 1), (2, 64, 16, 32, 3, 2), (2, 32, 96, 256, 3, 2), (1, 48, 8, 16, 3, 1)])
+                                               (8, 32, 640, 640, 3, 1), (2, 64, 16, 32, 3, 2), (2, 32, 96, 256, 3, 2), (1, 48, 8, 16, 3, 1),
+                                               # feature maps smaller than one 64-row K tile: 4 x 4 and 2 x 2 outputs, several tiles per slice
+                                               (8, 4, 64, 64, 3, 1), (8, 4, 128, 64, 1, 1), (12, 8, 64, 96, 3, 2), (40, 2, 32, 32, 3, 1), (9, 6, 64, 64, 3, 1)])
 def test_wgrad_conv_natural_layout(engine, B, H, C, N, ks, stride):
     """Conv weight gradient straight from NHWC x and dY (no im2col^T): against autograd's conv2d weight gradient (fp32 on the f16 inputs),
     in the packed [Cout, tap * C + c] layout of the forward weights."""
