@@ -420,12 +420,12 @@ def main():
         if args.graph:
             io.engine.use_stream(io.stream)
         agg = per_op_profile(pipe, io, args.dump_ops)
-        gemm_kinds = [k for k in agg if k.startswith("conv") or k == "linear"]
+        gemm_kinds = [k for k in agg if k.startswith("conv") or k in ("linear", "tblock")]  # tblock: fused chains of Linears (csrc/tblock.hip)
         g_ms = sum(agg[k]["ms"] for k in gemm_kinds)
         g_fl = sum(agg[k]["flops"] for k in gemm_kinds)
         n_l = sum(agg[k]["launches"] for k in gemm_kinds)
         ach = g_fl / (g_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_kernel<BM,BN,WM,WN,CONV> (MFMA implicit-GEMM conv3x3/1x1 + Linear)",
+        out["roofline"] = {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_kernel<BM,BN,WM,WN,CONV> (MFMA implicit-GEMM conv3x3/1x1 + Linear) + tblock_kernel (fused Linear chains)",
                            "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
                            "traffic": pmc_traffic_per_launch("gemm") if args.workload == "tiled_b8" else None,
                            "traffic_note": "HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes of this "

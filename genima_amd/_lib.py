@@ -69,6 +69,19 @@ class GroupNormDesc(C.Structure):
     ]
 
 
+class TBlockDesc(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("C", C.c_int32), ("M", C.c_int64),
+        ("a", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
+        ("tape", C.c_void_p), ("tape_bytes", C.c_int64),
+        ("lda", C.c_int64), ("ldr1", C.c_int64), ("ldr2", C.c_int64), ("ldo", C.c_int64), ("ldo2", C.c_int64),
+        ("ln_eps", C.c_float),
+    ]
+
+
+TBLOCK_MID, TBLOCK_TAIL = 1, 2
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
@@ -92,6 +105,10 @@ SIGNATURES = {
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
     "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
+    "gn_tblock_tape_bytes": (_I64, [_I32, _I32]),
+    "gn_tblock_supported": (_I32, [_I32, _I64, _I32]),
+    "gn_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),
+    "gn_program_add_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),
     "gn_attention_bwd": (_I32, [_P, C.POINTER(AttnBwdDesc)]),
     "gn_attention_fp8_quantize": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _F, _P, _P, _P, _I32]),
     "gn_attention_fp8_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),

@@ -108,3 +108,4 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) {
 int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d);
 int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d);
 int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d);
+int32_t gn_launch_tblock(gn_ctx* ctx, const gn_tblock_desc* d);

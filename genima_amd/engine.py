@@ -21,8 +21,8 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR,
-                   AttnDesc, GemmDesc, GenimaHipError, GroupNormDesc, check)
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_MID,
+                   TBLOCK_TAIL, AttnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, check)
 
 F16 = torch.float16
 
@@ -75,6 +75,10 @@ class Engine:
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
         self.up_phases_one_launch = os.environ.get("GN_UP_PHASES_ONE_LAUNCH", "1") != "0"
         self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "1024"))  # source pixels x batch below which the 3x3 launch stays
+        self.tblock = os.environ.get("GN_TBLOCK", "1") != "0"  # graphs: fused transformer-block chains at C = 320 (csrc/tblock.hip; A/B switch)
+        # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:
+        # tail 147 vs 201 us at 32768 rows, 121 vs 113 at 16384, 114 vs 64 at 8192)
+        self.tblock_min_rows = int(os.environ.get("GN_TBLOCK_MIN_ROWS", "24576"))
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
         # launch + V^T.  Measured neutral in the call (107.59 vs 107.67 ms tiled b8, same box) although the kernel alone is 4-7 % faster at
@@ -401,6 +405,46 @@ class Engine:
             d.ln_c1, d.ln_eps = _ptr(ln_c1), float(ln_eps)
         self._gemm(d, (x, w, bias, residual, out, out2, ln_c1))
         return (out, out2) if split_n else out
+
+    # ---- fused chains of a transformer block's Linears (csrc/tblock.hip): one launch keeps 128 rows of the residual stream in LDS ----------
+    def tblock_supported(self, M: int, C: int) -> bool:
+        return bool(self.lib.gn_tblock_supported(TBLOCK_TAIL, int(M), int(C)))
+
+    def _tblock(self, d: TBlockDesc, keep, flops: float, nbytes: float):
+        if self.record:
+            check(self.lib.gn_program_add_tblock(self._prog, C.byref(d)), "gn_program_add_tblock")
+            self._keepalive(*keep)
+            self.meta.append(dict(kind="tblock", flops=flops, bytes=nbytes, shape=(int(d.M), int(d.C), int(d.kind)), ref_flops=flops))
+        else:
+            check(self.lib.gn_tblock(self._ctx, C.byref(d)), "gn_tblock")
+
+    def tblock_mid(self, a: torch.Tensor, res: torch.Tensor, tape: torch.Tensor, *, ln_eps: float = 1e-5, name: Optional[str] = None):
+        """(h1, q): h1 = a @ Wo.T + bo + res (attn1.to_out.0 + residual), q = LayerNorm2(h1) @ Wq.T (attn2.to_q) -- one launch
+        (gn_tblock_desc GN_TBLOCK_MID; ``tape`` = packing.pack_tblock_mid_tape).  a, res: [..., 320] f16 contiguous rows."""
+        Cc = a.shape[-1]
+        M = a.numel() // Cc
+        h1 = self.buf(name, a.shape)
+        q = self.buf(None if name is None else name + ".q", a.shape)
+        d = TBlockDesc()
+        d.kind, d.C, d.M = TBLOCK_MID, Cc, M
+        d.a, d.res1, d.out, d.out2, d.tape, d.tape_bytes = _ptr(a), _ptr(res), _ptr(h1), _ptr(q), _ptr(tape), tape.numel() * tape.element_size()
+        d.lda, d.ldr1, d.ldo, d.ldo2, d.ln_eps = a.stride(-2), res.stride(-2), h1.stride(-2), q.stride(-2), float(ln_eps)
+        self._tblock(d, (a, res, h1, q, tape), 2.0 * M * Cc * Cc * 2, 2.0 * M * Cc * 4 + tape.numel())
+        return h1, q
+
+    def tblock_tail(self, a: torch.Tensor, res: torch.Tensor, res_out: torch.Tensor, tape: torch.Tensor, *, ln_eps: float = 1e-5,
+                    name: Optional[str] = None) -> torch.Tensor:
+        """out = proj_out(ff(h2) + h2) + res_out with h2 = a @ Wo.T + bo + res (attn2.to_out.0 + residual; norm3 + GEGLU feed-forward +
+        residual; proj_out + the transformer's input) -- one launch (GN_TBLOCK_TAIL; ``tape`` = packing.pack_tblock_tail_tape)."""
+        Cc = a.shape[-1]
+        M = a.numel() // Cc
+        out = self.buf(name, a.shape)
+        d = TBlockDesc()
+        d.kind, d.C, d.M = TBLOCK_TAIL, Cc, M
+        d.a, d.res1, d.res2, d.out, d.tape, d.tape_bytes = _ptr(a), _ptr(res), _ptr(res_out), _ptr(out), _ptr(tape), tape.numel() * tape.element_size()
+        d.lda, d.ldr1, d.ldr2, d.ldo, d.ln_eps = a.stride(-2), res.stride(-2), res_out.stride(-2), out.stride(-2), float(ln_eps)
+        self._tblock(d, (a, res, res_out, out, tape), 2.0 * M * Cc * Cc * (2 + 8 + 4), 2.0 * M * Cc * 4 + tape.numel())
+        return out
 
     # ---- fp8 (OCP e4m3) Linear: SURVEY section 8 a15 / BASELINE configs[4] "fp8 MFMA" -------------------------------------------
     _fp8_weights = None   # {weight data_ptr: (bytes, scales, weight)} of the Linears that run on the fp8 MFMA (enable_fp8)

@@ -151,6 +151,15 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     a = E.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads, v_rowmajor=True, name="sa")
                 else:
                     a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
+                if (getattr(E, "tblock", True) and k == 0 and b + ".tblock_tail.tape" in W and not E._fp8_weights and getattr(E, "ln_fold", True)
+                        and B * N >= getattr(E, "tblock_min_rows", 0) and E.tblock_supported(B * N, Cc)):
+                    # attn1.to_out .. attn2.to_q and attn2.to_out .. proj_out as TWO launches that keep their rows of the residual stream in
+                    # LDS and stream the weights from a tape (csrc/tblock.hip) instead of six gn_gemm launches
+                    h1, q = E.tblock_mid(a, h, W[b + ".tblock_mid.tape"], name="mid")
+                    ck, cvt = kv[b + ".attn2"]
+                    a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                    out = E.tblock_tail(a, h1, x.view(B, N, Cc), W[b + ".tblock_tail.tape"], name="tail")
+                    return out.view(B, H, Wd, Cc)
                 h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
                 fold = _ln_fold(E, W, b + ".attn2.to_q")
                 if fold:

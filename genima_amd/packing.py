@@ -140,6 +140,91 @@ def fold_layernorms(packed: Dict[str, torch.Tensor]) -> None:
             packed[base + lin + ".ln_c2"] = c2.to(torch.float16).contiguous()
 
 
+# ---- weight tapes of the fused transformer-block chains (csrc/tblock.hip; include/genima_hip.h gn_tblock_desc) ------------------------------
+TBLOCK_C, TBLOCK_SLOT, TBLOCK_VEC = 320, 20480, 3072
+
+
+def _lds_image64(t: torch.Tensor) -> torch.Tensor:
+    """[rows, 32] f16 -> the same bytes as the kernel's LDS sub-tile image: 64-byte rows whose four 16-byte chunks are XOR-swizzled by
+    (row >> 2) & 3 (csrc/common.h lds_swz<64>): physical chunk pc of a row holds logical chunk pc ^ ((row >> 2) & 3)."""
+    rows = t.shape[0]
+    r = torch.arange(rows, device=t.device)
+    idx = torch.arange(4, device=t.device)[None, :] ^ ((r >> 2) & 3)[:, None]
+    return torch.gather(t.reshape(rows, 4, 8), 1, idx[:, :, None].expand(-1, -1, 8)).reshape(-1)
+
+
+def _slot_bytes(*pieces: torch.Tensor) -> torch.Tensor:
+    """pieces (any dtype, laid end to end) padded with zeros to one 20 KB slot, as bytes."""
+    b = torch.cat([x.contiguous().reshape(-1).view(torch.uint8) for x in pieces])
+    assert b.numel() <= TBLOCK_SLOT, b.numel()
+    return torch.cat([b, torch.zeros(TBLOCK_SLOT - b.numel(), dtype=torch.uint8, device=b.device)])
+
+
+def _nc_slots(w: torch.Tensor):
+    """N = C Linear weight [320, 320] f16 -> ten slots, slot j = image of w[:, 32 j : 32 j + 32] (320 rows x 64 bytes)."""
+    assert tuple(w.shape) == (TBLOCK_C, TBLOCK_C) and w.dtype == torch.float16, (w.shape, w.dtype)
+    return [_slot_bytes(_lds_image64(w[:, 32 * j:32 * j + 32])) for j in range(TBLOCK_C // 32)]
+
+
+def _vec_bytes(*pieces: torch.Tensor) -> torch.Tensor:
+    b = torch.cat([x.contiguous().reshape(-1).view(torch.uint8) for x in pieces])
+    assert b.numel() <= TBLOCK_VEC
+    return torch.cat([b, torch.zeros(TBLOCK_VEC - b.numel(), dtype=torch.uint8, device=b.device)])
+
+
+def pack_tblock_mid_tape(wo, bo, wq_ln, c1q, c2q) -> torch.Tensor:
+    """Tape of GN_TBLOCK_MID: attn1.to_out.0 (weight, bias) then attn2.to_q with norm2 folded (``.ln_weight``, ``.ln_c1`` f32, ``.ln_c2``).
+    Layout: 10 + 10 slots of 20 KB, then the 3 KB vector block  bo f16 [320] | c1 f32 [320] | c2 f16 [320]."""
+    return torch.cat(_nc_slots(wo) + _nc_slots(wq_ln) + [_vec_bytes(bo.half(), c1q.float(), c2q.half())]).contiguous()
+
+
+def pack_tblock_tail_tape(wo, bo, w1_ln, c1, c2, w2, b2, wp, bp) -> torch.Tensor:
+    """Tape of GN_TBLOCK_TAIL: attn2.to_out.0; ff.net.0.proj with norm3 folded, in the packed GEGLU row order (32-row [hidden | gate]
+    blocks) + its c1 (f32) / c2; ff.net.2; proj_out.  Layout: 10 slots (to_out); per 64-column chunk ch of the hidden dimension 5 slots of the
+    projection -- slot js = images of w1_ln[128 ch : 128 ch + 128, 64 js + 32 sub : + 32], sub = 0, 1, the LAST one followed at byte 16384 by
+    c1[128 ch : + 128] f32 and c2[128 ch : + 128] f16 -- and 2 slots of ff.net.2 (w2[:, 64 ch + 32 j : + 32]); 10 slots (proj_out); then the
+    vector block  bo f16 [320] | b2 f16 [320] | bp f16 [320]."""
+    C = TBLOCK_C
+    assert tuple(w1_ln.shape) == (8 * C, C) and tuple(w2.shape) == (C, 4 * C), (w1_ln.shape, w2.shape)
+    parts = _nc_slots(wo)
+    for ch in range(4 * C // 64):
+        rows = w1_ln[128 * ch:128 * ch + 128]
+        for js in range(5):
+            pieces = [_lds_image64(rows[:, 64 * js + 32 * sub:64 * js + 32 * sub + 32]) for sub in range(2)]
+            if js == 4:
+                pieces += [c1[128 * ch:128 * ch + 128].float(), c2[128 * ch:128 * ch + 128].half()]
+            parts.append(_slot_bytes(*pieces))
+        for j in range(2):
+            parts.append(_slot_bytes(_lds_image64(w2[:, 64 * ch + 32 * j:64 * ch + 32 * j + 32])))
+    parts += _nc_slots(wp)
+    parts.append(_vec_bytes(bo.half(), b2.half(), bp.half()))
+    return torch.cat(parts).contiguous()
+
+
+def add_tblock_tapes(packed: Dict[str, torch.Tensor]) -> None:
+    """For every single-block Transformer2DModel of width 320 in a PACKED f16 dict (after fold_layernorms) add ``<block>.tblock_mid.tape`` and
+    ``<block>.tblock_tail.tape`` (uint8): graphs.emit_transformer then runs attn1.to_out .. attn2.to_q and attn2.to_out .. proj_out as two
+    gn_tblock launches instead of six gn_gemm launches."""
+    for name in list(packed.keys()):
+        if not name.endswith(".transformer_blocks.0.ff.net.0.proj.ln_weight"):
+            continue
+        b = name[: -len(".ff.net.0.proj.ln_weight")]
+        p = b[: -len(".transformer_blocks.0")]
+        if p + ".transformer_blocks.1.norm1.weight" in packed or packed[name].shape[1] != TBLOCK_C:
+            continue
+        need = [b + ".attn1.to_out.0.weight", b + ".attn1.to_out.0.bias", b + ".attn2.to_q.ln_weight", b + ".attn2.to_out.0.weight",
+                b + ".attn2.to_out.0.bias", b + ".ff.net.2.weight", b + ".ff.net.2.bias", p + ".proj_out.weight", p + ".proj_out.bias"]
+        if any(k not in packed for k in need) or packed[p + ".proj_out.weight"].dim() != 2:
+            continue
+        dev = packed[name].device  # (a dict packed for a ROCm device holds its GEGLU tensors there already, the rest still on the host)
+        g = lambda k: packed[k].to(dev)
+        packed[b + ".tblock_mid.tape"] = pack_tblock_mid_tape(g(b + ".attn1.to_out.0.weight"), g(b + ".attn1.to_out.0.bias"), g(b + ".attn2.to_q.ln_weight"),
+                                                              g(b + ".attn2.to_q.ln_c1"), g(b + ".attn2.to_q.ln_c2"))
+        packed[b + ".tblock_tail.tape"] = pack_tblock_tail_tape(g(b + ".attn2.to_out.0.weight"), g(b + ".attn2.to_out.0.bias"), g(name),
+                                                                g(b + ".ff.net.0.proj.ln_c1"), g(b + ".ff.net.0.proj.ln_c2"), g(b + ".ff.net.2.weight"),
+                                                                g(b + ".ff.net.2.bias"), g(p + ".proj_out.weight"), g(p + ".proj_out.bias"))
+
+
 _UP_TAPS = (((0,), (1, 2)), ((0, 1), (2,)))  # [phase d][2x2 tap a] -> the 3x3 taps that land on source row / column (y - 1 + d + a)
 
 
@@ -239,6 +324,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16, up
                     out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
     if dtype == torch.float16:
         fold_layernorms(out)
+        add_tblock_tapes(out)
     meta = {}
     if temb_w:
         out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(dtype).contiguous()

@@ -130,6 +130,38 @@ int32_t gn_gemm(gn_ctx* ctx, const gn_gemm_desc* d);
  * zeros), scales f32 [rows].  Activations: rows = tokens; weights [N, K]: rows = output channels (done once per weight). */
 int32_t gn_quantize_fp8_rows(gn_ctx* ctx, const void* x, int64_t ldx, int64_t rows, int32_t K, void* q, int64_t ldq, void* scales);
 
+/* ---- fused chains of a BasicTransformerBlock's Linears (csrc/tblock.hip) --------------------------------------------------------
+ * One workgroup keeps 128 rows of the [M, C] residual stream in LDS for a whole chain of GEMMs and streams the chain's weights through an
+ * LDS ring from a "weight tape" (one contiguous buffer holding the LDS image of every 20 KB weight slot in consumption order,
+ * genima_amd/packing.py pack_tblock_tape; gn_tblock_tape_bytes() long).  Replaces, inside the diffusers transformer blocks that
+ * `self.pipe(...)` runs (controller/agent/sd_controlnet_agent.py:67-76; graphs.emit_transformer), the gn_gemm launches
+ *   GN_TBLOCK_MID : out  = a Wo^T + bo + res1            (attn1.to_out.0 + residual)
+ *                   out2 = LayerNorm2(out) Wq^T           (norm2 folded into attn2.to_q, as gn_gemm_desc.ln_c1)
+ *   GN_TBLOCK_TAIL: h2   = a Wo^T + bo + res1            (attn2.to_out.0 + residual)
+ *                   h3   = GEGLU(LayerNorm3(h2) W1^T + b1) W2^T + b2 + h2   (norm3 folded into ff.net.0.proj; ff.net.2 + residual)
+ *                   out  = h3 Wp^T + bp + res2            (proj_out + the transformer's input)
+ * h2 / h3 and the [M, 4C] GEGLU intermediate never leave the chip; every intermediate is rounded to f16 where the separate launches round
+ * it.  Built for C = 320 (the 64x64-latent level), M % 128 == 0; gn_tblock_supported() says whether a problem qualifies.
+ * All tensors f16 row-major, rows 16-byte aligned. */
+enum { GN_TBLOCK_MID = 1, GN_TBLOCK_TAIL = 2 };
+typedef struct gn_tblock_desc {
+  int32_t kind;           /* GN_TBLOCK_* */
+  int32_t C;              /* channels (320) */
+  int64_t M;              /* rows (tokens) */
+  const void* a;          /* [M, lda]: the attention output the first Linear consumes */
+  const void* res1;       /* [M, ldr1]: residual of the first Linear */
+  const void* res2;       /* TAIL: [M, ldr2] residual of proj_out (the transformer's input); MID: NULL */
+  void* out;              /* [M, ldo]: MID: the residual stream after attn1; TAIL: the transformer's output */
+  void* out2;             /* MID: [M, ldo2] cross-attention queries; TAIL: NULL */
+  const void* tape;       /* the chain's weight tape */
+  int64_t tape_bytes;
+  int64_t lda, ldr1, ldr2, ldo, ldo2;
+  float ln_eps;
+} gn_tblock_desc;
+int64_t gn_tblock_tape_bytes(int32_t kind, int32_t C);          /* 0 = not built for this kind / width */
+int32_t gn_tblock_supported(int32_t kind, int64_t M, int32_t C); /* 1 / 0 */
+int32_t gn_tblock(gn_ctx* ctx, const gn_tblock_desc* d);
+
 /* ---- K4/K5/K11: flash-style attention forward --------------------------------------------------------------------
  * o[b, i, h*D + :] = softmax_j(scale * q[b,i,h] . k[b,j,h]) v[b,j,h]; V is consumed TRANSPOSED (vt[b][h*D + d][j], produced
  * for free by the V projection's GN_OUT_BATCH_TRANSPOSED epilogue).  Replaces xformers memory_efficient_attention / torch SDPA
@@ -382,6 +414,7 @@ int32_t gn_program_create(gn_ctx* ctx, gn_program** out);
 int32_t gn_program_destroy(gn_program* p);
 int32_t gn_program_add_gemm(gn_program* p, const gn_gemm_desc* d);
 int32_t gn_program_add_attention(gn_program* p, const gn_attn_desc* d);
+int32_t gn_program_add_tblock(gn_program* p, const gn_tblock_desc* d);
 int32_t gn_program_add_groupnorm(gn_program* p, const gn_groupnorm_desc* d);
 int32_t gn_program_add_layernorm(gn_program* p, const void* x, const void* gamma, const void* beta, void* y, int64_t M,
                                  int32_t C, float eps);

@@ -1,0 +1,130 @@
+"""-m gpu: the fused transformer-block chains (csrc/tblock.hip, gn_tblock) against (a) an fp32 torch restatement of the diffusers
+BasicTransformerBlock ops they replace -- attn1.to_out.0 + residual, norm2 -> attn2.to_q, attn2.to_out.0 + residual, norm3 -> GEGLU
+feed-forward + residual, proj_out + residual (the transformer blocks inside `self.pipe(...)`, controller/agent/sd_controlnet_agent.py:67-76)
+-- on the same f16-rounded inputs at the 1e-3 bar, stage by stage, and (b) the gn_gemm launches they replace (same f16 rounding points,
+same K order: agreement far inside the bar).  Every 128-row workgroup, both column halves and all 20 hidden chunks carry distinct data."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from genima_amd import packing
+from genima_amd._lib import ACT_GEGLU
+from util import assert_close, q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+C = 320
+
+
+def _weights(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: torch.randn(*s, generator=g) * sc
+    sd = {}
+    b = "t.transformer_blocks.0"
+    for n in ("attn1.to_out.0", "attn2.to_out.0"):
+        sd[f"{b}.{n}.weight"], sd[f"{b}.{n}.bias"] = r(C, C, sc=C ** -0.5), r(C, sc=0.2)
+    for n in ("attn1.to_q", "attn1.to_k", "attn1.to_v", "attn2.to_q"):
+        sd[f"{b}.{n}.weight"] = r(C, C, sc=C ** -0.5)
+    sd[f"{b}.attn2.to_k.weight"], sd[f"{b}.attn2.to_v.weight"] = r(C, 1024, sc=1024 ** -0.5), r(C, 1024, sc=1024 ** -0.5)
+    for n in ("norm1", "norm2", "norm3"):
+        sd[f"{b}.{n}.weight"], sd[f"{b}.{n}.bias"] = 1.0 + r(C, sc=0.2), r(C, sc=0.2)
+    sd[f"{b}.ff.net.0.proj.weight"], sd[f"{b}.ff.net.0.proj.bias"] = r(8 * C, C, sc=C ** -0.5), r(8 * C, sc=0.2)
+    sd[f"{b}.ff.net.2.weight"], sd[f"{b}.ff.net.2.bias"] = r(C, 4 * C, sc=(4 * C) ** -0.5), r(C, sc=0.2)
+    sd["t.proj_out.weight"], sd["t.proj_out.bias"] = r(C, C, sc=C ** -0.5), r(C, sc=0.2)
+    return {k: q16(v) for k, v in sd.items()}
+
+
+def _ref_mid(sd, a, res):
+    b = "t.transformer_blocks.0"
+    h1 = q16(a @ sd[f"{b}.attn1.to_out.0.weight"].T + sd[f"{b}.attn1.to_out.0.bias"] + res)
+    q = F.layer_norm(h1, (C,), sd[f"{b}.norm2.weight"], sd[f"{b}.norm2.bias"], 1e-5) @ sd[f"{b}.attn2.to_q.weight"].T
+    return h1, q
+
+
+def _ref_tail(sd, a, res, x):
+    b = "t.transformer_blocks.0"
+    h2 = q16(a @ sd[f"{b}.attn2.to_out.0.weight"].T + sd[f"{b}.attn2.to_out.0.bias"] + res)
+    pr = F.layer_norm(h2, (C,), sd[f"{b}.norm3.weight"], sd[f"{b}.norm3.bias"], 1e-5) @ sd[f"{b}.ff.net.0.proj.weight"].T + sd[f"{b}.ff.net.0.proj.bias"]
+    hid = q16(pr[:, : 4 * C] * F.gelu(pr[:, 4 * C:]))
+    h3 = q16(hid @ sd[f"{b}.ff.net.2.weight"].T + sd[f"{b}.ff.net.2.bias"] + h2)
+    return h3 @ sd["t.proj_out.weight"].T + sd["t.proj_out.bias"] + x
+
+
+@pytest.fixture(scope="module")
+def packed():
+    sd = _weights()
+    W = packing.pack_state_dict(sd, "cuda")
+    assert "t.transformer_blocks.0.tblock_tail.tape" in W and "t.transformer_blocks.0.tblock_mid.tape" in W
+    return sd, W
+
+
+@pytest.mark.parametrize("M", [128, 640, 4096])
+def test_tblock_mid_vs_reference_and_unfused(engine, packed, M):
+    sd, W = packed
+    b = "t.transformer_blocks.0"
+    g = torch.Generator().manual_seed(M)
+    a, res = q16(torch.randn(M, C, generator=g)), q16(torch.randn(M, C, generator=g) * 2.0 + 0.3)
+    ad, rd = a.half().cuda(), res.half().cuda()
+    h1, q = engine.tblock_mid(ad, rd, W[b + ".tblock_mid.tape"])
+    rh1, rq = _ref_mid(sd, a, res)
+    assert_close(h1, rh1, what="mid: attn1.to_out + residual")
+    assert_close(q, rq, what="mid: norm2 -> attn2.to_q")
+    # the launches it replaces
+    uh1 = engine.linear(ad, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=rd)
+    uq = engine.linear(uh1, W[b + ".attn2.to_q.ln_weight"], W[b + ".attn2.to_q.ln_c2"], ln_c1=W[b + ".attn2.to_q.ln_c1"])
+    assert torch.equal(h1, uh1), "h1 differs from the gn_gemm launch (same K order, same rounding point)"
+    assert rel_l2(q, uq.float()) < 2e-4
+
+
+@pytest.mark.parametrize("M", [128, 640, 4096])
+def test_tblock_tail_vs_reference_and_unfused(engine, packed, M):
+    sd, W = packed
+    b = "t.transformer_blocks.0"
+    g = torch.Generator().manual_seed(M + 1)
+    a, res, x = q16(torch.randn(M, C, generator=g)), q16(torch.randn(M, C, generator=g) * 2.0 - 0.2), q16(torch.randn(M, C, generator=g) * 3.0)
+    ad, rd, xd = a.half().cuda(), res.half().cuda(), x.half().cuda()
+    out = engine.tblock_tail(ad, rd, xd, W[b + ".tblock_tail.tape"])
+    assert_close(out, _ref_tail(sd, a, res, x), what="tail: attn2.to_out .. proj_out")
+    h2 = engine.linear(ad, W[b + ".attn2.to_out.0.weight"], W[b + ".attn2.to_out.0.bias"], residual=rd)
+    hid = engine.linear(h2, W[b + ".ff.net.0.proj.ln_weight"], W[b + ".ff.net.0.proj.ln_c2"], ln_c1=W[b + ".ff.net.0.proj.ln_c1"], act=ACT_GEGLU)
+    h3 = engine.linear(hid, W[b + ".ff.net.2.weight"], W[b + ".ff.net.2.bias"], residual=h2)
+    un = engine.linear(h3, W["t.proj_out.weight"], W["t.proj_out.bias"], residual=xd)
+    assert rel_l2(out, un.float()) < 3e-4, rel_l2(out, un.float())
+
+
+def test_tblock_rejects_what_it_is_not_built_for(engine, packed):
+    from genima_amd._lib import GenimaHipError
+
+    _, W = packed
+    tape = W["t.transformer_blocks.0.tblock_mid.tape"]
+    assert not engine.tblock_supported(100, C) and not engine.tblock_supported(256, 640) and engine.tblock_supported(256, C)
+    with pytest.raises(GenimaHipError):
+        engine.tblock_mid(torch.zeros(100, C, dtype=torch.float16, device="cuda"), torch.zeros(100, C, dtype=torch.float16, device="cuda"), tape)
+    with pytest.raises(GenimaHipError):  # the tail's tape is not the mid's
+        engine.tblock_mid(torch.zeros(128, C, dtype=torch.float16, device="cuda"), torch.zeros(128, C, dtype=torch.float16, device="cuda"),
+                          W["t.transformer_blocks.0.tblock_tail.tape"])
+
+
+def test_transformer_graph_with_and_without_the_fused_chains(engine, packed):
+    """graphs.emit_transformer end to end (GroupNorm, proj_in, q | k | v, both attentions): the two-launch route against the six-launch one."""
+    from genima_amd import graphs
+
+    sd, W = packed
+    W = dict(W)
+    g = torch.Generator().manual_seed(5)
+    W["t.norm.weight"], W["t.norm.bias"] = (1.0 + 0.1 * torch.randn(C, generator=g)).half().cuda(), (0.1 * torch.randn(C, generator=g)).half().cuda()
+    W["t.proj_in.weight"], W["t.proj_in.bias"] = (torch.randn(C, C, generator=g) * C ** -0.5).half().cuda(), torch.zeros(C).half().cuda()
+    B, Hh = 2, 16
+    x = torch.randn(B, Hh, Hh, C, generator=g).half().cuda()
+    ctx = torch.randn(B, 77, 1024, generator=g).half().cuda()
+    kv = graphs.emit_cross_kv(engine, W, ctx, "t")
+    kv = {k[len("t/"):] if k.startswith("t/") else k: v for k, v in kv.items()}
+    old, old_min = engine.tblock, engine.tblock_min_rows
+    try:
+        engine.tblock, engine.tblock_min_rows = True, 0
+        y1 = graphs.emit_transformer(engine, W, "t", x, kv, 5, 32).float()
+        engine.tblock = False
+        y0 = graphs.emit_transformer(engine, W, "t", x, kv, 5, 32).float()
+    finally:
+        engine.tblock, engine.tblock_min_rows = old, old_min
+    assert rel_l2(y1, y0) < 5e-4, rel_l2(y1, y0)
