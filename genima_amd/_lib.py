@@ -82,6 +82,14 @@ class TBlockDesc(C.Structure):
 TBLOCK_MID, TBLOCK_TAIL = 1, 2
 
 
+class ConvGnDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("scsh", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
+        ("ldr", C.c_int64), ("ldo", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("act", C.c_int32),
+    ]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("dy", C.c_void_p), ("x", C.c_void_p), ("dw", C.c_void_p), ("workspace", C.c_void_p),
@@ -109,6 +117,9 @@ SIGNATURES = {
     "gn_tblock_supported": (_I32, [_I32, _I64, _I32]),
     "gn_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),
     "gn_program_add_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),
+    "gn_conv3x3_gn_supported": (_I32, [_I32, _I32, _I32, _I32, _I32]),
+    "gn_conv3x3_gn": (_I32, [_P, C.POINTER(ConvGnDesc)]),
+    "gn_program_add_conv3x3_gn": (_I32, [_P, C.POINTER(ConvGnDesc)]),
     "gn_attention_bwd": (_I32, [_P, C.POINTER(AttnBwdDesc)]),
     "gn_attention_fp8_quantize": (_I32, [_P, _P, _P, _P, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _F, _P, _P, _P, _I32]),
     "gn_attention_fp8_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgenima_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_s3.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_bwd.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip", "act_train.hip", "pack.hip", "tblock.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_s3.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_bwd.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip", "act_train.hip", "pack.hip", "tblock.hip", "conv_gn.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950's register file is unified, so keep MFMA accumulators in VGPRs -- the softmax / epilogue VALU
 # then works on them in place instead of through v_accvgpr_read/write copies (400 of them per attention tile otherwise).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]

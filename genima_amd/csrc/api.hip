@@ -20,7 +20,7 @@ namespace {
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
   OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE, OP_FILM, OP_SCALE_CAT_PAD,
-  OP_TBLOCK,
+  OP_TBLOCK, OP_CONV_GN,
   OP_FORK, OP_MAIN, OP_JOIN  // stream control: ops after FORK go to the program's side stream until MAIN; JOIN makes main wait for it
 };
 
@@ -40,6 +40,7 @@ struct Op {
     gn_attn_desc attn;
     gn_groupnorm_desc gnorm;
     gn_tblock_desc tblock;
+    gn_conv3x3_gn_desc convgn;
     GenericArgs g;
   };
 };
@@ -62,6 +63,7 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_ATTN: return gn_launch_attention(ctx, &op.attn);
     case OP_GROUPNORM: return gn_launch_groupnorm(ctx, &op.gnorm);
     case OP_TBLOCK: return gn_launch_tblock(ctx, &op.tblock);
+    case OP_CONV_GN: return gn_conv3x3_gn(ctx, &op.convgn);
     case OP_LAYERNORM: return gn_layernorm_fwd(ctx, g.p0, g.p1, g.p2, g.p3, g.n0, g.i0, g.f0);
     case OP_TEMB: return gn_timestep_embedding(ctx, (const float*)g.p0, g.p3, g.i0, g.i1, g.i2, g.f0);
     case OP_SCALE_PAD: return gn_scale_pad(ctx, g.p0, g.p3, g.n0, g.i0, g.i1, g.f0);
@@ -185,6 +187,15 @@ int32_t gn_program_add_tblock(gn_program* p, const gn_tblock_desc* d) {
   memset(&op, 0, sizeof(op));
   op.type = OP_TBLOCK;
   op.tblock = *d;
+  p->ops.push_back(op);
+  return GN_OK;
+}
+int32_t gn_program_add_conv3x3_gn(gn_program* p, const gn_conv3x3_gn_desc* d) {
+  GN_REQUIRE(p && d, "gn_program_add_conv3x3_gn: null argument");
+  Op op;
+  memset(&op, 0, sizeof(op));
+  op.type = OP_CONV_GN;
+  op.convgn = *d;
   p->ops.push_back(op);
   return GN_OK;
 }

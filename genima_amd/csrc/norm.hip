@@ -373,7 +373,9 @@ extern "C" int64_t gn_groupnorm_workspace_bytes(const gn_groupnorm_desc* d) {
 }
 
 int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
-  GN_REQUIRE(d && d->x && d->gamma && d->beta && d->y && d->workspace, "gn_groupnorm_fwd: null pointer");
+  GN_REQUIRE(d && d->x && d->gamma && d->beta && d->workspace, "gn_groupnorm_fwd: null pointer");
+  const bool stats_only = d->y == nullptr;  // scale / shift pairs for a consumer that applies them itself (gn_conv3x3_gn)
+  GN_REQUIRE(!stats_only || d->save_scsh, "gn_groupnorm_fwd: y == NULL (statistics only) needs save_scsh");
   const int C = d->C1 + d->C2;
   GN_REQUIRE(d->B > 0 && d->HW > 0 && d->C1 > 0, "gn_groupnorm_fwd: empty problem");
   GN_REQUIRE(d->C1 % 8 == 0 && d->C2 % 8 == 0, "gn_groupnorm_fwd: C1/C2 (%d/%d) must be multiples of 8", d->C1, d->C2);
@@ -408,7 +410,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
     // few (batch, group) slabs leave most CUs idle -- unless the whole tensor is so small that the call is latency-bound anyway
     // (batch 1: 32 slabs; one launch of ~6 us instead of three)
     const bool small = (long)d->B * d->HW * C * 2 <= (4l << 20);
-    if (fused_ok && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= fused_max &&
+    if (!stats_only && fused_ok && p.cpg % 2 == 0 && (p.cpg >> 1) <= GNF_THREADS && d->C1 % 2 == 0 && slab <= fused_max &&
         ((long)d->B * d->groups >= 64 || small)) {
       hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups, d->B), dim3(GNF_THREADS), (size_t)slab, ctx->stream, p);
       GN_LAUNCH_CHECK();
@@ -428,6 +430,7 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
+  if (stats_only) return GN_OK;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(p.achunks, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_MID,
-                   TBLOCK_TAIL, AttnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, check)
+                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, check)
 
 F16 = torch.float16
 
@@ -75,6 +75,11 @@ class Engine:
         self.up_phases = os.environ.get("GN_UP_PHASES", "1") != "0"  # graphs: upsample + 3x3 conv as four 2x2 phase convs (A/B switch)
         self.up_phases_one_launch = os.environ.get("GN_UP_PHASES_ONE_LAUNCH", "1") != "0"
         self.up_phases_min_rows = int(os.environ.get("GN_UP_PHASES_MIN_ROWS", "1024"))  # source pixels x batch below which the 3x3 launch stays
+        self.conv_gn = os.environ.get("GN_CONV_GN", "1") != "0"  # graphs: GroupNorm-apply + SiLU inside the consuming 3x3 conv (csrc/conv_gn.hip; A/B switch)
+        # it pays where the GroupNorm launch is HBM-expensive against its conv (tools/bench_conv_gn.py, MI355X, B = 8): 512^2 x 128 -> 128
+        # 1251 -> 915 us, 512^2 x 256 -> 128 2066 -> 1657 us; a wash at 256^2 x 256 (789 -> 774), a loss below (the SiLU of the 1.4x halo patch is
+        # VALU time beside the MFMAs of a 128-wide output tile)
+        self.conv_gn_min_hw = int(os.environ.get("GN_CONV_GN_MIN_HW", str(512 * 512)))
         self.tblock = os.environ.get("GN_TBLOCK", "1") != "0"  # graphs: fused transformer-block chains at C = 320 (csrc/tblock.hip; A/B switch)
         # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:
         # tail 147 vs 201 us at 32768 rows, 121 vs 113 at 16384, 114 vs 64 at 8192)
@@ -663,6 +668,53 @@ class Engine:
             self.meta.append(dict(kind="groupnorm", flops=0.0, bytes=2.0 * 2 * B * HW * (C1 + C2), shape=(B, HW, C1 + C2)))
         else:
             check(self.lib.gn_groupnorm_fwd(self._ctx, C.byref(d)), "gn_groupnorm_fwd")
+        return out
+
+    def groupnorm_stats(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
+                        name: Optional[str] = None) -> torch.Tensor:
+        """Statistics-only GroupNorm (gn_groupnorm_fwd with y == NULL): -> f32 [B, C, 2] per-(sample, channel) (scale, shift) such that
+        GN(x)[b, .., c] = x * scale + shift; conv2d_gn applies them (and the SiLU) to its input patch in LDS.  One read of x, no write."""
+        B, Cc = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * Cc)
+        scsh = self.buf(name, (B, Cc, 2), dtype=torch.float32)
+        d = GroupNormDesc()
+        d.x, d.gamma, d.beta, d.y, d.save_scsh = _ptr(x), _ptr(gamma), _ptr(beta), None, _ptr(scsh)
+        d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, Cc, 0, groups, ACT_NONE, eps
+        ws = self._workspace(int(self.lib.gn_groupnorm_workspace_bytes(C.byref(d))))
+        d.workspace = ws.data_ptr()
+        if self.record:
+            check(self.lib.gn_program_add_groupnorm(self._prog, C.byref(d)), "gn_program_add_groupnorm")
+            self._keepalive(x, gamma, beta, scsh, ws)
+            self.meta.append(dict(kind="groupnorm", flops=0.0, bytes=2.0 * B * HW * Cc, shape=(B, HW, Cc, 0)))
+        else:
+            check(self.lib.gn_groupnorm_fwd(self._ctx, C.byref(d)), "gn_groupnorm_fwd")
+        return scsh
+
+    def conv2d_gn_supported(self, x: torch.Tensor, cout: int) -> bool:
+        B, H, W, Cin = x.shape
+        return bool(self.lib.gn_conv3x3_gn_supported(B, H, W, Cin, cout))
+
+    def conv2d_gn(self, x: torch.Tensor, scsh: Optional[torch.Tensor], w: torch.Tensor, bias: Optional[torch.Tensor] = None, *,
+                  act: int = ACT_SILU, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                  name: Optional[str] = None) -> torch.Tensor:
+        """conv3x3(act(x * scale + shift)) + bias (+ residual) with the GroupNorm-apply and the SiLU done on the conv's LDS patch
+        (gn_conv3x3_gn, csrc/conv_gn.hip).  x: RAW NHWC [B, H, W, Cin]; scsh from groupnorm_stats (None: plain conv); w packed [Cout, 9 Cin]."""
+        B, H, W, Cin = x.shape
+        N = w.shape[0]
+        assert w.shape[1] == 9 * Cin, (tuple(w.shape), Cin)
+        if out is None:
+            out = self.buf(name, (B, H, W, N))
+        d = ConvGnDesc()
+        d.x, d.scsh, d.w, d.bias, d.residual, d.out = _ptr(x), _ptr(scsh), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out)
+        d.ldr, d.ldo = (residual.stride(-2) if residual is not None else 0), out.stride(-2)
+        d.B, d.H, d.W, d.Cin, d.Cout, d.act = B, H, W, Cin, N, act
+        if self.record:
+            check(self.lib.gn_program_add_conv3x3_gn(self._prog, C.byref(d)), "gn_program_add_conv3x3_gn")
+            self._keepalive(x, scsh, w, bias, residual, out)
+            M, K = B * H * W, 9 * Cin
+            self.meta.append(dict(kind="conv3x3", flops=2.0 * M * N * K, bytes=2.0 * (M * Cin + N * K + M * N), shape=(M, N, K), ref_flops=2.0 * M * N * K))
+        else:
+            check(self.lib.gn_conv3x3_gn(self._ctx, C.byref(d)), "gn_conv3x3_gn")
         return out
 
     def layernorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, *,

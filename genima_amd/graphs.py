@@ -85,13 +85,28 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
         else:
             assert x2 is None
             sc = x
-        h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, act=ACT_SILU, x2=x2, name="n1")
         sh, ld = _shift_for(W, shifts, p) if (p + ".time_emb_proj.weight") in W else (None, 0)
-        h = E.conv2d(h, W[p + ".conv1.weight"], W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
+
+        def fuse(t, cout):  # GroupNorm-apply + SiLU inside the consuming conv's LDS patch (csrc/conv_gn.hip): the large, unconditioned convs
+            return (getattr(E, "conv_gn", True) and t.dim() == 4 and t.shape[1] * t.shape[2] >= getattr(E, "conv_gn_min_hw", 0)
+                    and E.conv2d_gn_supported(t, cout))
+
+        c1w, c2w = W[p + ".conv1.weight"], W[p + ".conv2.weight"]
+        if x2 is None and sh is None and fuse(x, c1w.shape[0]):
+            st = E.groupnorm_stats(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, name="n1s")
+            h = E.conv2d_gn(x, st, c1w, W[p + ".conv1.bias"], name="c1")
+        else:
+            h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, act=ACT_SILU, x2=x2, name="n1")
+            h = E.conv2d(h, c1w, W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
+        if fuse(h, c2w.shape[0]):
+            st = E.groupnorm_stats(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, name="n2s")
+            if side:
+                E.join()
+            return E.conv2d_gn(h, st, c2w, W[p + ".conv2.bias"], residual=sc, name="c2")
         h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
         if side:
             E.join()
-        return E.conv2d(h, W[p + ".conv2.weight"], W[p + ".conv2.bias"], residual=sc, name="c2")
+        return E.conv2d(h, c2w, W[p + ".conv2.bias"], residual=sc, name="c2")
 
 
 def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:

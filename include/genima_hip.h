@@ -233,6 +233,29 @@ typedef struct gn_groupnorm_desc {
 int64_t gn_groupnorm_workspace_bytes(const gn_groupnorm_desc* d);
 int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d);
 
+/* gn_groupnorm_fwd with y == NULL and save_scsh set: STATISTICS ONLY -- the per-(sample, channel) scale / shift pairs are written and
+ * nothing is normalised; gn_conv3x3_gn applies them (and the SiLU) to its input patch in LDS.
+ *
+ * ---- 3x3 convolution (stride 1, padding 1) with GroupNorm-apply + SiLU fused into its prologue (csrc/conv_gn.hip) ------------------------
+ * out = conv3x3(act(x * scale[b, c] + shift[b, c])) + bias (+ residual): diffusers ResnetBlock2D's norm1 -> SiLU -> conv1 and
+ * norm2 -> SiLU -> conv2 (+ shortcut) without the normalised tensor's round trip through HBM (the VAE decoder inside `self.pipe(...)`,
+ * controller/agent/sd_controlnet_agent.py:67-76).  A workgroup keeps the 10 x 18 input patch of an 8 x 16 output tile in LDS, normalises it
+ * there (the arithmetic of gn_groupnorm_fwd's apply pass: the MFMA sees the same f16 values) and reads all nine taps from it.
+ * Needs H % 8 == 0, W % 16 == 0, Cin % 128 == 0, Cout % 128 == 0 (gn_conv3x3_gn_supported). */
+typedef struct gn_conv3x3_gn_desc {
+  const void* x;          /* NHWC f16 [B, H, W, Cin]: the RAW tensor the GroupNorm reads */
+  const void* scsh;       /* f32 [B][Cin][2] (scale, shift) from the statistics-only GroupNorm call, or NULL: plain convolution */
+  const void* w;          /* packed conv weight [Cout][9 * Cin] f16 (gn_pack_conv_weight) */
+  const void* bias;       /* [Cout] f16 or NULL */
+  const void* residual;   /* [B * H * W, ldr] f16 or NULL: added after the bias */
+  void* out;              /* [B * H * W, ldo] f16 */
+  int64_t ldr, ldo;
+  int32_t B, H, W, Cin, Cout;
+  int32_t act;            /* GN_ACT_NONE / GN_ACT_SILU on the normalised input (with scsh) */
+} gn_conv3x3_gn_desc;
+int32_t gn_conv3x3_gn_supported(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout);
+int32_t gn_conv3x3_gn(gn_ctx* ctx, const gn_conv3x3_gn_desc* d);
+
 /* ---- K7: LayerNorm over the last dim of [M, C] (C % 8 == 0, C <= 4096) --------------------------------------------- */
 int32_t gn_layernorm_fwd(gn_ctx* ctx, const void* x, const void* gamma, const void* beta, void* y,
                          int64_t M, int32_t C, float eps);
@@ -415,6 +438,7 @@ int32_t gn_program_destroy(gn_program* p);
 int32_t gn_program_add_gemm(gn_program* p, const gn_gemm_desc* d);
 int32_t gn_program_add_attention(gn_program* p, const gn_attn_desc* d);
 int32_t gn_program_add_tblock(gn_program* p, const gn_tblock_desc* d);
+int32_t gn_program_add_conv3x3_gn(gn_program* p, const gn_conv3x3_gn_desc* d);
 int32_t gn_program_add_groupnorm(gn_program* p, const gn_groupnorm_desc* d);
 int32_t gn_program_add_layernorm(gn_program* p, const void* x, const void* gamma, const void* beta, void* y, int64_t M,
                                  int32_t C, float eps);

@@ -1,0 +1,107 @@
+"""-m gpu: 3x3 conv with GroupNorm-apply + SiLU in its LDS prologue (csrc/conv_gn.hip, gn_conv3x3_gn) against (a) torch fp32
+`conv2d(silu(group_norm(x)))` on the same f16-rounded inputs -- the ResnetBlock2D ops it replaces (diffusers VAE decoder inside
+`self.pipe(...)`, controller/agent/sd_controlnet_agent.py:67-76) -- at the 1e-3 bar, and (b) the gn_groupnorm_fwd + gn_gemm launches it
+replaces (the MFMA sees the same f16 values; only the K order differs).  Tiles at every image border, several channel groups, several output
+channel tiles, with and without the residual, and the statistics-only GroupNorm call on its own."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from genima_amd import packing
+from genima_amd._lib import ACT_NONE, ACT_SILU
+from util import assert_close, q16, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _case(B, H, W, Cin, Cout, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = q16(torch.randn(B, Cin, H, W, generator=g) * 1.5 + 0.3 * torch.randn(B, Cin, 1, 1, generator=g))
+    w = q16(torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5)
+    bias = q16(torch.randn(Cout, generator=g) * 0.2)
+    gamma, beta = q16(1.0 + 0.2 * torch.randn(Cin, generator=g)), q16(0.2 * torch.randn(Cin, generator=g))
+    res = q16(torch.randn(B, Cout, H, W, generator=g))
+    return x, w, bias, gamma, beta, res
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,residual", [(1, 8, 16, 128, 128, False), (2, 16, 32, 128, 128, True), (1, 24, 48, 256, 128, True),
+                                                     (2, 16, 16, 128, 256, False), (1, 8, 32, 384, 256, True)])
+def test_conv3x3_gn_vs_torch_and_unfused(engine, B, H, W, Cin, Cout, residual):
+    x, w, bias, gamma, beta, res = _case(B, H, W, Cin, Cout, seed=H + Cin)
+    G, eps = 32, 1e-6
+    ref = F.conv2d(q16(F.silu(F.group_norm(x, G, gamma, beta, eps))), w, bias, padding=1) + (res if residual else 0.0)
+    xd, rd = _nhwc(x).half().cuda(), _nhwc(res).half().cuda()
+    wd, bd = packing.pack_conv_weight(w).cuda(), bias.half().cuda()
+    gd, bed = gamma.half().cuda(), beta.half().cuda()
+    assert engine.conv2d_gn_supported(xd, Cout)
+    st = engine.groupnorm_stats(xd, gd, bed, G, eps)
+    y = engine.conv2d_gn(xd, st, wd, bd, act=ACT_SILU, residual=rd if residual else None)
+    assert_close(_nhwc_to_nchw(y), ref, what=f"conv3x3_gn {Cin}->{Cout} {H}x{W}")
+    # the launches it replaces
+    n = engine.groupnorm(xd, gd, bed, G, eps, act=ACT_SILU)
+    y0 = engine.conv2d(n, wd, bd, residual=rd if residual else None)
+    assert rel_l2(y, y0.float()) < 2e-4, rel_l2(y, y0.float())
+
+
+def _nhwc_to_nchw(t):
+    return t.float().permute(0, 3, 1, 2)
+
+
+def test_groupnorm_statistics_only(engine):
+    B, H, W, C, G, eps = 3, 32, 32, 256, 32, 1e-5
+    g = torch.Generator().manual_seed(3)
+    x = q16(torch.randn(B, C, H, W, generator=g) * 2.0 + 1.0)
+    gamma, beta = q16(1.0 + 0.3 * torch.randn(C, generator=g)), q16(0.3 * torch.randn(C, generator=g))
+    st = engine.groupnorm_stats(_nhwc(x).half().cuda(), gamma.half().cuda(), beta.half().cuda(), G, eps).cpu()
+    xg = x.double().view(B, G, -1)
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd = (var + eps).rsqrt()
+    scale = (rstd[:, :, None] * gamma.double().view(1, G, -1)).reshape(B, C)
+    shift = beta.double()[None, :] - (mean[:, :, None] * rstd[:, :, None] * gamma.double().view(1, G, -1)).reshape(B, C)
+    assert_close(st[:, :, 0], scale.float(), rel=1e-5, what="scale")
+    assert_close(st[:, :, 1], shift.float(), rel=1e-5, what="shift")
+
+
+def test_conv3x3_patch_kernel_without_groupnorm(engine):
+    """scsh == NULL: the plain conv through the patch kernel (zero padding from the out-of-range DMA lanes)."""
+    x, w, bias, _, _, res = _case(2, 16, 32, 128, 128, seed=9)
+    xd = _nhwc(x).half().cuda()
+    y = engine.conv2d_gn(xd, None, packing.pack_conv_weight(w).cuda(), bias.half().cuda(), act=ACT_NONE, residual=_nhwc(res).half().cuda())
+    assert_close(_nhwc_to_nchw(y), F.conv2d(x, w, bias, padding=1) + res, what="patch conv, no GroupNorm")
+
+
+def test_conv3x3_gn_rejects_unsupported_shapes(engine):
+    from genima_amd._lib import GenimaHipError
+
+    x = torch.zeros(1, 12, 16, 128, dtype=torch.float16, device="cuda")  # H % 8 != 0
+    assert not engine.conv2d_gn_supported(x, 128)
+    assert not engine.conv2d_gn_supported(torch.zeros(1, 8, 16, 64, dtype=torch.float16, device="cuda"), 128)
+    with pytest.raises(GenimaHipError):
+        engine.conv2d_gn(x, None, torch.zeros(128, 9 * 128, dtype=torch.float16, device="cuda"))
+
+
+def test_vae_resnet_graph_with_and_without_the_fusion(engine):
+    """graphs.emit_resnet on a VAE-style block (no time shift): the fused route against the four-launch one."""
+    from genima_amd import graphs
+
+    g = torch.Generator().manual_seed(11)
+    C = 128
+    sd = {"r.norm1.weight": 1.0 + 0.1 * torch.randn(C, generator=g), "r.norm1.bias": 0.1 * torch.randn(C, generator=g),
+          "r.conv1.weight": torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5, "r.conv1.bias": 0.1 * torch.randn(C, generator=g),
+          "r.norm2.weight": 1.0 + 0.1 * torch.randn(C, generator=g), "r.norm2.bias": 0.1 * torch.randn(C, generator=g),
+          "r.conv2.weight": torch.randn(C, C, 3, 3, generator=g) * (9 * C) ** -0.5, "r.conv2.bias": 0.1 * torch.randn(C, generator=g)}
+    W = packing.pack_state_dict(sd, "cuda")
+    x = torch.randn(2, 32, 32, C, generator=g).half().cuda()
+    old = engine.conv_gn, engine.conv_gn_min_hw
+    try:
+        engine.conv_gn, engine.conv_gn_min_hw = True, 0
+        y1 = graphs.emit_resnet(engine, W, "r", x, None, None, 32, 1e-6).float()
+        engine.conv_gn = False
+        y0 = graphs.emit_resnet(engine, W, "r", x, None, None, 32, 1e-6).float()
+    finally:
+        engine.conv_gn, engine.conv_gn_min_hw = old
+    assert rel_l2(y1, y0) < 3e-4, rel_l2(y1, y0)

@@ -4,11 +4,11 @@
 steps=${1:-10}
 mkdir -p gpurun_out
 for v in 1 0 1 0; do
-  GN_TBLOCK=$v python bench.py --steps $steps --warmup 3 --no-train --no-single-view 2>/dev/null | tail -1 > gpurun_out/ab_tblock_$v.json
+  GN_TBLOCK=$v GN_CONV_GN=$v python bench.py --steps $steps --warmup 3 --no-train --no-single-view 2>/dev/null | tail -1 > gpurun_out/ab_tblock_$v.json
   python - <<PY
 import json
 d = json.load(open("gpurun_out/ab_tblock_$v.json"))
 rows = [(r["kernel"], round(r["ms_per_call"], 2), r["launches"], round(r.get("achieved", 0), 1)) for r in d.get("roofline_extra", [])[:9]]
-print("GN_TBLOCK=$v", round(d["value"], 1), "img/s", round(d["ms_per_step"], 2), "ms  gemm family", round(d["roofline"]["achieved"], 1), "TF/s", rows, flush=True)
+print("GN_TBLOCK=GN_CONV_GN=$v", round(d["value"], 1), "img/s", round(d["ms_per_step"], 2), "ms  gemm family", round(d["roofline"]["achieved"], 1), "TF/s", rows, flush=True)
 PY
 done
