@@ -40,6 +40,7 @@ constexpr int TB_VEC_OFF = TB_STATS_OFF + TB_BM * 8;       // 160768: bias / c1 
 constexpr int TB_VEC_BYTES = 3072;
 constexpr int TB_LDS = TB_VEC_OFF + TB_VEC_BYTES;          // 163840 = the CU's 160 KB
 constexpr int TB_FF_CHUNKS = 4 * TB_C / 64;                // 20 chunks of 64 hidden columns
+constexpr int TB_FRONT_VEC_BYTES = 9216;                   // FRONT: b_in f16 [320] | c1 f32 [960] | c2 f16 [960] | GroupNorm scale / shift f32 [320][2], in the H region
 constexpr int TB_C1C2_OFF = 2 * TB_SUB;                    // inside the LAST GEGLU-projection slot of a chunk: c1 f32 [128], then c2 f16 [128]
 static_assert(TB_LDS <= 160 * 1024, "LDS budget");
 
@@ -50,9 +51,11 @@ struct TbParams {
   f16* out;
   f16* out2;
   const unsigned char* tape;
-  long lda, ldr1, ldr2, ldo, ldo2;
+  const float* scsh;   // FRONT: GroupNorm (scale, shift) pairs [B][C][2]
+  f16* out3;           // FRONT: V^T [B][C][ldo3]
+  long lda, ldr1, ldr2, ldo, ldo2, ldo3;
   unsigned a_bytes, tape_bytes;
-  int M, nslots;
+  int M, nslots, rpb;  // rpb: rows (tokens) per sample
   float eps;
 };
 
@@ -90,6 +93,8 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   const int l31 = lane & 31, hi = lane >> 5;
   const int m0 = blockIdx.x * TB_BM;
   const int arow = wm * 32 + l31;  // this lane's row of the workgroup's 128 (A operand and accumulator rows alike)
+  constexpr int VEC = KIND == GN_TBLOCK_FRONT ? TB_H_OFF : TB_VEC_OFF;  // the chain's bias / c1 / c2 vectors (FRONT has no GEGLU chunk: it takes that region)
+  constexpr int VEC_BYTES = KIND == GN_TBLOCK_FRONT ? TB_FRONT_VEC_BYTES : TB_VEC_BYTES;
 
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_t = __builtin_amdgcn_make_buffer_rsrc((void*)p.tape, 0, (int)p.tape_bytes, 0x00020000);
@@ -105,9 +110,13 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(smem + kt * TB_SUB + wave * 1024), 16, base + kt * 64, 0, 0, 0);
   }
   // the chain's bias / c1 / c2 vectors sit behind the last slot of the tape
-  if (wave < TB_VEC_BYTES / 1024)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(smem + TB_VEC_OFF + wave * 1024), 16,
-                                             (unsigned)p.nslots * TB_SLOT + wave * 1024 + lane * 16, 0, 0, 0);
+  for (int i = wave; i < VEC_BYTES / 1024; i += 8)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(smem + VEC + i * 1024), 16, (unsigned)p.nslots * TB_SLOT + i * 1024 + lane * 16, 0, 0, 0);
+  if constexpr (KIND == GN_TBLOCK_FRONT) {
+    // the sample's GroupNorm (scale, shift) pairs behind the vectors: 320 x 8 bytes (all rows of a workgroup belong to one sample)
+    if (tid < TB_C / 2)
+      *reinterpret_cast<f32x4*>(smem + VEC + 6400 + tid * 16) = *reinterpret_cast<const f32x4*>(p.scsh + ((long)(m0 / p.rpb) * TB_C + 2 * tid) * 2);
+  }
 
   // ---- the weight ring: slot s of the tape -> ring buffer s % 3; every wave moves two or three of its twenty 1 KB pieces
   // (the workgroups of an XCD walk the tape in step: each starts a slot at a different one of its 20 pieces, so that they do not all ask the
@@ -127,14 +136,13 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
     ibuf = ibuf == 2 ? 0 : ibuf + 1;
   };
   int cbuf = 0;
-  bool drain = false;  // the next wait retires EVERYTHING (set after global stores: their order against loads in vmcnt is not relied on)
   // consume one slot: its pieces have landed (the younger slot's stay in flight), every wave is past the previous slot (its buffer is free
   // for slot + 2) and past whatever it wrote to LDS before this call
   auto consume = [&](auto&& f) __attribute__((always_inline)) {
-    if (drain) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+    // (global stores of an epilogue in between do not disturb the count: LOADS retire in order among themselves, so whichever nd of the
+    // younger operations are still outstanding, this slot's pieces -- older than the next slot's nd -- are not among them)
+    if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-    drain = false;
     if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     issue();
@@ -193,7 +201,8 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   // epilogue of an N = C GEMM: (LayerNorm fold) + bias + residual -> f16 -> the A image (in place) and / or global memory.
   //   bias_off: byte offset of the f16 bias (or c2) vector in the VEC region; c1_off: f32 c1 vector (LNF); RES: 0 none, 1 registers, 2 the A image
   auto epilogue_nc = [&](f32x16 (&acc)[5], int bias_off, auto lnf_c, int c1_off, auto res_c, const uint4 (&rpre)[5][2], auto lds_c, f16* gout,
-                         long ldo) __attribute__((always_inline)) {
+                         long ldo, auto vt_c) __attribute__((always_inline)) {
+    constexpr bool TO_VT = decltype(vt_c)::value;  // f16 values -> [n][m] in the (free) A image, for the transposed V^T store
     constexpr bool LNF = decltype(lnf_c)::value;
     constexpr int RES = decltype(res_c)::value;
     constexpr bool TO_LDS = decltype(lds_c)::value;
@@ -211,14 +220,14 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
       if constexpr (LNF) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f32x4 c1 = *reinterpret_cast<const f32x4*>(smem + TB_VEC_OFF + c1_off + (n0 + 8 * g + 4 * hi) * 4);
+          const f32x4 c1 = *reinterpret_cast<const f32x4*>(smem + VEC + c1_off + (n0 + 8 * g + 4 * hi) * 4);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[4 * g + e] = rstd * v[4 * g + e] + nrm * c1[e];
         }
       }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f16x4 b = *reinterpret_cast<const f16x4*>(smem + TB_VEC_OFF + bias_off + (n0 + 8 * g + 4 * hi) * 2);
+        const f16x4 b = *reinterpret_cast<const f16x4*>(smem + VEC + bias_off + (n0 + 8 * g + 4 * hi) * 2);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[4 * g + e] += (float)b[e];
       }
@@ -235,6 +244,11 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[4 * g + e] += (float)r[e];
         }
+      }
+      if constexpr (TO_VT) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) *reinterpret_cast<f16*>(smem + ((n0 + 8 * (e >> 2) + 4 * hi + (e & 3)) * TB_BM + arow) * 2) = (f16)v[e];
+        return;
       }
       u32x4 q[2];
       pack_tile(v, q);
@@ -283,31 +297,78 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
 
   // ---- the chain -------------------------------------------------------------------------------------------------------------------
   uint4 rpre[5][2];
-  prefetch_res(p.res1, p.ldr1, rpre);  // older than every ring DMA: retired by the first counted wait
+  if constexpr (KIND != GN_TBLOCK_FRONT) prefetch_res(p.res1, p.ldr1, rpre);  // older than every ring DMA: retired by the first counted wait
   issue();
   issue();
+  if constexpr (KIND == GN_TBLOCK_FRONT) {
+    // GroupNorm-apply on the rows in place (no activation: Transformer2DModel.norm): thread (row, quarter) walks its chunks of the ten sub-tiles
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const int row = tid >> 2, lc = tid & 3;
+#pragma unroll 2
+    for (int kt = 0; kt < TB_KT; ++kt) {
+      unsigned char* q = smem + kt * TB_SUB + swz64(row, lc);
+      const f16x8 v = *reinterpret_cast<const f16x8*>(q);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + VEC + 6400 + (kt * 32 + lc * 8 + e) * 8);
+        o[e] = (f16)((float)v[e] * sc[0] + sc[1]);
+        o[e + 1] = (f16)((float)v[e + 1] * sc[2] + sc[3]);
+      }
+      *reinterpret_cast<f16x8*>(q) = o;
+    }
+  }
 
   f32x16 acc[5];
   zero5(acc);
-  // GEMM 1 (both kinds): a Wo^T + bo + res1 -> the A image (in place)
+  // GEMM 1: a Wo^T + bo (+ res1) -> the A image (in place)
   for (int kt = 0; kt < TB_KT; ++kt)
     consume([&](const unsigned char* Ws) __attribute__((always_inline)) { mma_nc(acc, smem + kt * TB_SUB, Ws); });
   block_barrier();  // every wave is done reading `a` out of the image
-  if constexpr (KIND == GN_TBLOCK_MID) {
-    epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::true_type{}, p.out, p.ldo);
-    drain = true;
-  } else {
-    epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::true_type{}, (f16*)nullptr, 0);
-  }
+  if constexpr (KIND == GN_TBLOCK_FRONT)
+    epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 0>{}, rpre, std::true_type{}, p.out, p.ldo, std::false_type{});
+  else if constexpr (KIND == GN_TBLOCK_MID)
+    epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::true_type{}, p.out, p.ldo, std::false_type{});
+  else
+    epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::true_type{}, (f16*)nullptr, 0, std::false_type{});
   block_barrier();
   row_stats();  // (visible to the epilogues that read them: at least one slot barrier lies between)
 
-  if constexpr (KIND == GN_TBLOCK_MID) {
+  if constexpr (KIND == GN_TBLOCK_FRONT) {
+    // q, k, v = LN1(h) W'^T with the same raw rows (VEC: b_in f16 [320] | c1 f32 [960] | c2 f16 [960]); q | k row-major into out2 [M, 2C],
+    // V transposed per sample (the attention kernels' V^T operand) through the A image once every wave is done with it
+    for (int g3 = 0; g3 < 3; ++g3) {
+      zero5(acc);
+      for (int kt = 0; kt < TB_KT; ++kt)
+        consume([&](const unsigned char* Ws) __attribute__((always_inline)) { mma_nc(acc, smem + kt * TB_SUB, Ws); });
+      if (g3 < 2) {
+        epilogue_nc(acc, 4480 + g3 * 640, std::true_type{}, 640 + g3 * 1280, std::integral_constant<int, 0>{}, rpre, std::false_type{},
+                    p.out2 + g3 * TB_C, p.ldo2, std::false_type{});
+      } else {
+        block_barrier();
+        epilogue_nc(acc, 4480 + 2 * 640, std::true_type{}, 640 + 2 * 1280, std::integral_constant<int, 0>{}, rpre, std::false_type{}, (f16*)nullptr, 0,
+                    std::true_type{});
+        block_barrier();
+        // [320 n][128 m] f16 in LDS -> V^T[b][n][m_local ..]: 16 lanes cover the 256 contiguous bytes of one n
+        const int b = m0 / p.rpb, ml = m0 - b * p.rpb;
+        f16* vt = p.out3 + (long)b * TB_C * p.ldo3 + ml;
+#pragma unroll
+        for (int i = 0; i < TB_C * 16 / TB_NT; ++i) {
+          const int c = tid + TB_NT * i, n = c >> 4, pc = c & 15;
+          *reinterpret_cast<u32x4*>(vt + (long)n * p.ldo3 + pc * 8) = *reinterpret_cast<const u32x4*>(smem + n * (TB_BM * 2) + pc * 16);
+        }
+      }
+    }
+  }
+  if constexpr (KIND == GN_TBLOCK_FRONT) {
+  } else if constexpr (KIND == GN_TBLOCK_MID) {
     // GEMM 2: LN2(h1) Wq^T -> out2 (VEC: bo f16 [320] | c1 f32 [320] | c2 f16 [320])
     zero5(acc);
     for (int kt = 0; kt < TB_KT; ++kt)
       consume([&](const unsigned char* Ws) __attribute__((always_inline)) { mma_nc(acc, smem + kt * TB_SUB, Ws); });
-    epilogue_nc(acc, 640 + 1280, std::true_type{}, 640, std::integral_constant<int, 0>{}, rpre, std::false_type{}, p.out2, p.ldo2);
+    epilogue_nc(acc, 640 + 1280, std::true_type{}, 640, std::integral_constant<int, 0>{}, rpre, std::false_type{}, p.out2, p.ldo2, std::false_type{});
   } else {
     // feed-forward: per 64-column chunk of the hidden dimension, hid = GEGLU(LN3(h2) W1'^T) -> LDS, acc += hid W2[:, chunk]^T
     zero5(acc);
@@ -363,13 +424,13 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
     }
     // + b2 + h2 (read back from the image) -> h3, in place (no other wave reads the image any more: the last A-operand reads were five
     // slot barriers ago, and the waves' residual tiles are disjoint)
-    epilogue_nc(acc, 640, std::false_type{}, 0, std::integral_constant<int, 2>{}, rpre, std::true_type{}, (f16*)nullptr, 0);
+    epilogue_nc(acc, 640, std::false_type{}, 0, std::integral_constant<int, 2>{}, rpre, std::true_type{}, (f16*)nullptr, 0, std::false_type{});
     // proj_out: h3 Wp^T + bp + res2 -> out
     prefetch_res(p.res2, p.ldr2, rpre);
     zero5(acc);
     for (int kt = 0; kt < TB_KT; ++kt)
       consume([&](const unsigned char* Ws) __attribute__((always_inline)) { mma_nc(acc, smem + kt * TB_SUB, Ws); });
-    epilogue_nc(acc, 1280, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::false_type{}, p.out, p.ldo);
+    epilogue_nc(acc, 1280, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::false_type{}, p.out, p.ldo, std::false_type{});
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the run-ahead zero fills must not outlive the workgroup's LDS allocation
 }

@@ -158,7 +158,8 @@ def test_geglu_block_layout_masked_softmax_weight_rotation(engine):
     assert xt.shape == (40, 8) and torch.equal(xt[:, :3].cpu(), x.t().half()) and float(xt[:, 3:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("N,Nk,fused", [(256, 256, True), (200, 77, False), (1024, 1024, True), (64, 77, False)])
+# (4096, 4096): the self-attention shape of the 64x64-latent level, the one the fine-tune step runs at 512^2
+@pytest.mark.parametrize("N,Nk,fused", [(256, 256, True), (200, 77, False), (1024, 1024, True), (64, 77, False), (4096, 4096, True)])
 def test_flash_attention_backward(engine, N, Nk, fused):
     """gn_attention_bwd (flash, P recomputed from lse) vs torch autograd of softmax attention; fused = q|k share one buffer."""
     B, heads, D = 2, 3, 64
