@@ -75,11 +75,11 @@ class TBlockDesc(C.Structure):
         ("a", C.c_void_p), ("res1", C.c_void_p), ("res2", C.c_void_p), ("out", C.c_void_p), ("out2", C.c_void_p),
         ("tape", C.c_void_p), ("tape_bytes", C.c_int64),
         ("lda", C.c_int64), ("ldr1", C.c_int64), ("ldr2", C.c_int64), ("ldo", C.c_int64), ("ldo2", C.c_int64),
-        ("ln_eps", C.c_float),
+        ("ln_eps", C.c_float), ("scsh", C.c_void_p), ("out3", C.c_void_p), ("ldo3", C.c_int64), ("rows_per_batch", C.c_int32),
     ]
 
 
-TBLOCK_MID, TBLOCK_TAIL = 1, 2
+TBLOCK_MID, TBLOCK_TAIL, TBLOCK_FRONT = 1, 2, 3
 
 
 class ConvGnDesc(C.Structure):

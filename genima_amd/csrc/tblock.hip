@@ -40,7 +40,8 @@ constexpr int TB_VEC_OFF = TB_STATS_OFF + TB_BM * 8;       // 160768: bias / c1 
 constexpr int TB_VEC_BYTES = 3072;
 constexpr int TB_LDS = TB_VEC_OFF + TB_VEC_BYTES;          // 163840 = the CU's 160 KB
 constexpr int TB_FF_CHUNKS = 4 * TB_C / 64;                // 20 chunks of 64 hidden columns
-constexpr int TB_FRONT_VEC_BYTES = 9216;                   // FRONT: b_in f16 [320] | c1 f32 [960] | c2 f16 [960] | GroupNorm scale / shift f32 [320][2], in the H region
+constexpr int TB_FRONT_VEC_BYTES = 7168;                   // FRONT's vector block (in the H region): b_in f16 [320] | c1 f32 [960] | c2 f16 [960], padded to 7 KB;
+constexpr int TB_FRONT_SCSH_OFF = TB_FRONT_VEC_BYTES;      // behind it the sample's GroupNorm (scale, shift) pairs f32 [320][2]
 constexpr int TB_C1C2_OFF = 2 * TB_SUB;                    // inside the LAST GEGLU-projection slot of a chunk: c1 f32 [128], then c2 f16 [128]
 static_assert(TB_LDS <= 160 * 1024, "LDS budget");
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   if constexpr (KIND == GN_TBLOCK_FRONT) {
     // the sample's GroupNorm (scale, shift) pairs behind the vectors: 320 x 8 bytes (all rows of a workgroup belong to one sample)
     if (tid < TB_C / 2)
-      *reinterpret_cast<f32x4*>(smem + VEC + 6400 + tid * 16) = *reinterpret_cast<const f32x4*>(p.scsh + ((long)(m0 / p.rpb) * TB_C + 2 * tid) * 2);
+      *reinterpret_cast<f32x4*>(smem + VEC + TB_FRONT_SCSH_OFF + tid * 16) = *reinterpret_cast<const f32x4*>(p.scsh + ((long)(m0 / p.rpb) * TB_C + 2 * tid) * 2);
   }
 
   // ---- the weight ring: slot s of the tape -> ring buffer s % 3; every wave moves two or three of its twenty 1 KB pieces
@@ -136,13 +137,21 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
     ibuf = ibuf == 2 ? 0 : ibuf + 1;
   };
   int cbuf = 0;
+  int stores_in_flight = 0;  // consumes for which an epilogue's 10 global stores per wave may still be outstanding (see consume)
   // consume one slot: its pieces have landed (the younger slot's stay in flight), every wave is past the previous slot (its buffer is free
   // for slot + 2) and past whatever it wrote to LDS before this call
   auto consume = [&](auto&& f) __attribute__((always_inline)) {
-    // (global stores of an epilogue in between do not disturb the count: LOADS retire in order among themselves, so whichever nd of the
-    // younger operations are still outstanding, this slot's pieces -- older than the next slot's nd -- are not among them)
-    if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    // gfx9's single vmcnt retires loads and stores in issue order.  The ten global stores of an epilogue (`stores_in_flight` consumes ago)
+    // are YOUNGER than this slot's pieces for two consumes: allowing them to stay outstanding lets them drain under the next GEMM's first
+    // slots instead of stalling the ring behind the HBM write latency.
+    if (stores_in_flight > 0) {
+      if (wave < 4) asm volatile("s_waitcnt vmcnt(13) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+      --stores_in_flight;
+    } else {
+      if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    }
     if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     issue();
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
       f16x8 o;
 #pragma unroll
       for (int e = 0; e < 8; e += 2) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + VEC + 6400 + (kt * 32 + lc * 8 + e) * 8);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(smem + VEC + TB_FRONT_SCSH_OFF + (kt * 32 + lc * 8 + e) * 8);
         o[e] = (f16)((float)v[e] * sc[0] + sc[1]);
         o[e + 1] = (f16)((float)v[e + 1] * sc[2] + sc[3]);
       }
@@ -327,10 +336,13 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   for (int kt = 0; kt < TB_KT; ++kt)
     consume([&](const unsigned char* Ws) __attribute__((always_inline)) { mma_nc(acc, smem + kt * TB_SUB, Ws); });
   block_barrier();  // every wave is done reading `a` out of the image
-  if constexpr (KIND == GN_TBLOCK_FRONT)
+  if constexpr (KIND == GN_TBLOCK_FRONT) {
     epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 0>{}, rpre, std::true_type{}, p.out, p.ldo, std::false_type{});
-  else if constexpr (KIND == GN_TBLOCK_MID)
+    stores_in_flight = 2;
+  } else if constexpr (KIND == GN_TBLOCK_MID) {
     epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::true_type{}, p.out, p.ldo, std::false_type{});
+    stores_in_flight = 2;
+  }
   else
     epilogue_nc(acc, 0, std::false_type{}, 0, std::integral_constant<int, 1>{}, rpre, std::true_type{}, (f16*)nullptr, 0, std::false_type{});
   block_barrier();
@@ -346,6 +358,7 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
       if (g3 < 2) {
         epilogue_nc(acc, 4480 + g3 * 640, std::true_type{}, 640 + g3 * 1280, std::integral_constant<int, 0>{}, rpre, std::false_type{},
                     p.out2 + g3 * TB_C, p.ldo2, std::false_type{});
+        stores_in_flight = 2;
       } else {
         block_barrier();
         epilogue_nc(acc, 4480 + 2 * 640, std::true_type{}, 640 + 2 * 1280, std::integral_constant<int, 0>{}, rpre, std::false_type{}, (f16*)nullptr, 0,
@@ -439,17 +452,18 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
 
 extern "C" int64_t gn_tblock_tape_bytes(int32_t kind, int32_t C) {
   if (C != TB_C) return 0;
-  const int64_t nslots = kind == GN_TBLOCK_TAIL ? 2 * TB_KT + TB_FF_CHUNKS * 7 : (kind == GN_TBLOCK_MID ? 2 * TB_KT : 0);
-  return nslots ? nslots * TB_SLOT + TB_VEC_BYTES : 0;
+  const int64_t nslots = kind == GN_TBLOCK_TAIL ? 2 * TB_KT + TB_FF_CHUNKS * 7 : (kind == GN_TBLOCK_MID ? 2 * TB_KT : (kind == GN_TBLOCK_FRONT ? 4 * TB_KT : 0));
+  return nslots ? nslots * TB_SLOT + (kind == GN_TBLOCK_FRONT ? TB_FRONT_VEC_BYTES : TB_VEC_BYTES) : 0;
 }
 
 extern "C" int32_t gn_tblock_supported(int32_t kind, int64_t M, int32_t C) {
-  return (kind == GN_TBLOCK_MID || kind == GN_TBLOCK_TAIL) && C == TB_C && M > 0 && M % TB_BM == 0 ? 1 : 0;
+  return (kind == GN_TBLOCK_FRONT || kind == GN_TBLOCK_MID || kind == GN_TBLOCK_TAIL) && C == TB_C && M > 0 && M % TB_BM == 0 ? 1 : 0;
 }
 
 int32_t gn_launch_tblock(gn_ctx* ctx, const gn_tblock_desc* d) {
-  GN_REQUIRE(d && d->a && d->res1 && d->out && d->tape, "gn_tblock: null a / res1 / out / tape");
-  GN_REQUIRE(d->kind == GN_TBLOCK_MID || d->kind == GN_TBLOCK_TAIL, "gn_tblock: unknown kind %d", d->kind);
+  GN_REQUIRE(d && d->a && d->out && d->tape, "gn_tblock: null a / out / tape");
+  GN_REQUIRE(d->kind == GN_TBLOCK_FRONT || d->kind == GN_TBLOCK_MID || d->kind == GN_TBLOCK_TAIL, "gn_tblock: unknown kind %d", d->kind);
+  GN_REQUIRE(d->kind == GN_TBLOCK_FRONT || d->res1, "gn_tblock: res1 is required for the MID / TAIL chains");
   GN_REQUIRE(d->C == TB_C, "gn_tblock: built for C = %d (got %d); use the gn_gemm launches for other widths", TB_C, d->C);
   GN_REQUIRE(d->M > 0 && d->M % TB_BM == 0, "gn_tblock: M (%ld) must be a positive multiple of %d", (long)d->M, TB_BM);
   GN_REQUIRE(d->tape_bytes == gn_tblock_tape_bytes(d->kind, d->C), "gn_tblock: tape_bytes %ld != gn_tblock_tape_bytes() = %ld", (long)d->tape_bytes,
@@ -462,11 +476,20 @@ int32_t gn_launch_tblock(gn_ctx* ctx, const gn_tblock_desc* d) {
   TbParams p;
   p.a = (const f16*)d->a; p.res1 = (const f16*)d->res1; p.res2 = (const f16*)d->res2;
   p.out = (f16*)d->out; p.out2 = (f16*)d->out2; p.tape = (const unsigned char*)d->tape;
+  p.scsh = (const float*)d->scsh; p.out3 = (f16*)d->out3; p.ldo3 = d->ldo3; p.rpb = d->rows_per_batch;
   p.lda = d->lda; p.ldr1 = d->ldr1; p.ldr2 = d->ldr2; p.ldo = d->ldo; p.ldo2 = d->ldo2;
   p.a_bytes = (unsigned)((uint64_t)d->M * d->lda * 2); p.tape_bytes = (unsigned)d->tape_bytes;
   p.M = (int)d->M; p.eps = d->ln_eps;
   const dim3 grid((unsigned)(d->M / TB_BM)), block(TB_NT);
-  if (d->kind == GN_TBLOCK_MID) {
+  if (d->kind == GN_TBLOCK_FRONT) {
+    GN_REQUIRE(d->scsh && d->out2 && d->out3 && ((uintptr_t)d->scsh & 15) == 0 && ((uintptr_t)d->out2 & 15) == 0 && ((uintptr_t)d->out3 & 15) == 0,
+               "gn_tblock(front): scsh, out2 (q | k) and out3 (V^T) must be given, 16-byte aligned");
+    GN_REQUIRE(d->ldo2 % 8 == 0 && d->ldo2 >= 2 * TB_C && d->ldo3 % 8 == 0, "gn_tblock(front): ldo2 >= 2 C, strides multiples of 8");
+    GN_REQUIRE(d->rows_per_batch > 0 && d->rows_per_batch % TB_BM == 0 && d->M % d->rows_per_batch == 0 && d->ldo3 >= d->rows_per_batch,
+               "gn_tblock(front): rows_per_batch (%d) must be a multiple of %d dividing M, ldo3 >= rows_per_batch", d->rows_per_batch, TB_BM);
+    p.nslots = 4 * TB_KT;
+    hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_FRONT>), grid, block, 0, ctx->stream, p);
+  } else if (d->kind == GN_TBLOCK_MID) {
     GN_REQUIRE(d->out2 && d->ldo2 % 8 == 0 && ((uintptr_t)d->out2 & 15) == 0, "gn_tblock(mid): out2 (q) must be given, 16-byte aligned, ldo2 %% 8 == 0");
     p.nslots = 2 * TB_KT;
     hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_MID>), grid, block, 0, ctx->stream, p);

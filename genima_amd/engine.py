@@ -21,7 +21,7 @@ from typing import Dict, Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_MID,
+from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_FRONT, TBLOCK_MID,
                    TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, check)
 
 F16 = torch.float16
@@ -84,6 +84,7 @@ class Engine:
         # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:
         # tail 147 vs 201 us at 32768 rows, 121 vs 113 at 16384, 114 vs 64 at 8192)
         self.tblock_min_rows = int(os.environ.get("GN_TBLOCK_MIN_ROWS", "24576"))
+        self.tblock_front_on = os.environ.get("GN_TBLOCK_FRONT", "1") != "0"  # the GroupNorm + proj_in + q | k | v chain (A/B switch of its own)
         self.ln_fold = os.environ.get("GN_LN_FOLD", "1") != "0"  # graphs: LayerNorm folded into the consuming Linear (A/B switch)
         # graphs: self-attention takes V row-major out of one plain q | k | v launch (gn_attn_desc.v_rowmajor) instead of the two-destination
         # launch + V^T.  Measured neutral in the call (107.59 vs 107.67 ms tiled b8, same box) although the kernel alone is 4-7 % faster at
@@ -422,6 +423,25 @@ class Engine:
             self.meta.append(dict(kind="tblock", flops=flops, bytes=nbytes, shape=(int(d.M), int(d.C), int(d.kind)), ref_flops=flops))
         else:
             check(self.lib.gn_tblock(self._ctx, C.byref(d)), "gn_tblock")
+
+    def tblock_front(self, x: torch.Tensor, scsh: torch.Tensor, tape: torch.Tensor, rows_per_batch: int, *, ln_eps: float = 1e-5,
+                     name: Optional[str] = None):
+        """(h, qk, vt): h = GroupNorm(x) @ Wi.T + bi with the GroupNorm applied from its (scale, shift) pairs ``scsh`` (groupnorm_stats) on the
+        rows in LDS; q | k = LayerNorm1(h) @ [Wq | Wk].T -> qk [.., 2C]; V^T [B, C, pad64(rows_per_batch)] -- the operands of the self-attention
+        kernel.  One launch (GN_TBLOCK_FRONT; ``tape`` = packing.pack_tblock_front_tape)."""
+        Cc = x.shape[-1]
+        M = x.numel() // Cc
+        nb = M // rows_per_batch
+        ld = _round_up(rows_per_batch, 64)
+        h = self.buf(name, x.shape)
+        qk = self.buf(None if name is None else name + ".qk", tuple(x.shape[:-1]) + (2 * Cc,))
+        vt = self.buf(None if name is None else name + ".vt", (nb, Cc, ld), zero=ld != rows_per_batch)
+        d = TBlockDesc()
+        d.kind, d.C, d.M = TBLOCK_FRONT, Cc, M
+        d.a, d.scsh, d.out, d.out2, d.out3, d.tape, d.tape_bytes = _ptr(x), _ptr(scsh), _ptr(h), _ptr(qk), _ptr(vt), _ptr(tape), tape.numel() * tape.element_size()
+        d.lda, d.ldo, d.ldo2, d.ldo3, d.rows_per_batch, d.ln_eps = x.stride(-2), h.stride(-2), qk.stride(-2), ld, rows_per_batch, float(ln_eps)
+        self._tblock(d, (x, scsh, h, qk, vt, tape), 2.0 * M * Cc * Cc * 4, 2.0 * M * Cc * 5 + tape.numel())
+        return h, qk, vt
 
     def tblock_mid(self, a: torch.Tensor, res: torch.Tensor, tape: torch.Tensor, *, ln_eps: float = 1e-5, name: Optional[str] = None):
         """(h1, q): h1 = a @ Wo.T + bo + res (attn1.to_out.0 + residual), q = LayerNorm2(h1) @ Wq.T (attn2.to_q) -- one launch

@@ -135,12 +135,29 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
     B, H, Wd, Cc = x.shape
     N = H * Wd
     with E.scope(p):
-        h = E.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups, 1e-6, name="gn")
-        h = E.linear(h.view(B, N, Cc), W[p + ".proj_in.weight"], W[p + ".proj_in.bias"], name="pin")
+        use_tb = (getattr(E, "tblock", True) and not E._fp8_weights and getattr(E, "ln_fold", True) and B * N >= getattr(E, "tblock_min_rows", 0)
+                  and f"{p}.transformer_blocks.0.tblock_tail.tape" in W and E.tblock_supported(B * N, Cc))
+        front = None
+        if use_tb and p + ".tblock_front.tape" in W and N % 128 == 0 and getattr(E, "tblock_front_on", True):
+            # GroupNorm (from its statistics-only pass) + proj_in + norm1 -> q | k | v as ONE launch on rows resident in LDS (csrc/tblock.hip)
+            st = E.groupnorm_stats(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups, 1e-6, name="gns")
+            front = E.tblock_front(x.view(B, N, Cc), st, W[p + ".tblock_front.tape"], N, name="front")
+            h = front[0]
+        else:
+            h = E.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups, 1e-6, name="gn")
+            h = E.linear(h.view(B, N, Cc), W[p + ".proj_in.weight"], W[p + ".proj_in.bias"], name="pin")
         k = 0
         while f"{p}.transformer_blocks.{k}.norm1.weight" in W:
             b = f"{p}.transformer_blocks.{k}"
             with E.scope(f"tb{k}"):
+                if front is not None and k == 0:
+                    _, qk, vt = front
+                    a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
+                    h1, q = E.tblock_mid(a, h, W[b + ".tblock_mid.tape"], name="mid")
+                    ck, cvt = kv[b + ".attn2"]
+                    a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                    out = E.tblock_tail(a, h1, x.view(B, N, Cc), W[b + ".tblock_tail.tape"], name="tail")
+                    return out.view(B, H, Wd, Cc)
                 # LayerNorm folded into the consuming Linear where the packed dict carries the folded weights (packing.fold_layernorms):
                 # the Linear reads the raw rows and takes mean / rstd from its own K loop -- no LayerNorm launch, no round trip
                 fold = _ln_fold(E, W, b + ".attn1.to_qkv")
@@ -166,8 +183,7 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     a = E.attention(qkv[:, :, :Cc], qkv[:, :, Cc:2 * Cc], qkv[:, :, 2 * Cc:], heads, v_rowmajor=True, name="sa")
                 else:
                     a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
-                if (getattr(E, "tblock", True) and k == 0 and b + ".tblock_tail.tape" in W and not E._fp8_weights and getattr(E, "ln_fold", True)
-                        and B * N >= getattr(E, "tblock_min_rows", 0) and E.tblock_supported(B * N, Cc)):
+                if use_tb and k == 0:
                     # attn1.to_out .. attn2.to_q and attn2.to_out .. proj_out as TWO launches that keep their rows of the residual stream in
                     # LDS and stream the weights from a tape (csrc/tblock.hip) instead of six gn_gemm launches
                     h1, q = E.tblock_mid(a, h, W[b + ".tblock_mid.tape"], name="mid")

@@ -178,6 +178,20 @@ def pack_tblock_mid_tape(wo, bo, wq_ln, c1q, c2q) -> torch.Tensor:
     return torch.cat(_nc_slots(wo) + _nc_slots(wq_ln) + [_vec_bytes(bo.half(), c1q.float(), c2q.half())]).contiguous()
 
 
+def pack_tblock_front_tape(w_in, b_in, wqkv_ln, c1, c2) -> torch.Tensor:
+    """Tape of GN_TBLOCK_FRONT: proj_in (weight, bias), then attn1's q | k | v projection with norm1 folded (``attn1.to_qkv.ln_weight`` [960, 320],
+    ``.ln_c1`` f32 [960], ``.ln_c2`` [960]).  Layout: 10 slots (proj_in) + 3 x 10 slots (q, k, v), then a 7 KB vector block
+    b_in f16 [320] | c1 f32 [960] | c2 f16 [960]."""
+    C = TBLOCK_C
+    assert tuple(wqkv_ln.shape) == (3 * C, C), wqkv_ln.shape
+    parts = _nc_slots(w_in)
+    for g in range(3):
+        parts += _nc_slots(wqkv_ln[g * C:(g + 1) * C].contiguous())
+    vec = torch.cat([x.contiguous().reshape(-1).view(torch.uint8) for x in (b_in.half(), c1.float(), c2.half())])
+    parts.append(torch.cat([vec, torch.zeros(7168 - vec.numel(), dtype=torch.uint8, device=vec.device)]))
+    return torch.cat(parts).contiguous()
+
+
 def pack_tblock_tail_tape(wo, bo, w1_ln, c1, c2, w2, b2, wp, bp) -> torch.Tensor:
     """Tape of GN_TBLOCK_TAIL: attn2.to_out.0; ff.net.0.proj with norm3 folded, in the packed GEGLU row order (32-row [hidden | gate]
     blocks) + its c1 (f32) / c2; ff.net.2; proj_out.  Layout: 10 slots (to_out); per 64-column chunk ch of the hidden dimension 5 slots of the
@@ -218,6 +232,9 @@ def add_tblock_tapes(packed: Dict[str, torch.Tensor]) -> None:
             continue
         dev = packed[name].device  # (a dict packed for a ROCm device holds its GEGLU tensors there already, the rest still on the host)
         g = lambda k: packed[k].to(dev)
+        if (b + ".attn1.to_qkv.ln_weight") in packed and (p + ".proj_in.weight") in packed and packed[p + ".proj_in.weight"].dim() == 2:
+            packed[p + ".tblock_front.tape"] = pack_tblock_front_tape(g(p + ".proj_in.weight"), g(p + ".proj_in.bias"), g(b + ".attn1.to_qkv.ln_weight"),
+                                                                     g(b + ".attn1.to_qkv.ln_c1"), g(b + ".attn1.to_qkv.ln_c2"))
         packed[b + ".tblock_mid.tape"] = pack_tblock_mid_tape(g(b + ".attn1.to_out.0.weight"), g(b + ".attn1.to_out.0.bias"), g(b + ".attn2.to_q.ln_weight"),
                                                               g(b + ".attn2.to_q.ln_c1"), g(b + ".attn2.to_q.ln_c2"))
         packed[b + ".tblock_tail.tape"] = pack_tblock_tail_tape(g(b + ".attn2.to_out.0.weight"), g(b + ".attn2.to_out.0.bias"), g(name),

@@ -135,6 +135,9 @@ int32_t gn_quantize_fp8_rows(gn_ctx* ctx, const void* x, int64_t ldx, int64_t ro
  * LDS ring from a "weight tape" (one contiguous buffer holding the LDS image of every 20 KB weight slot in consumption order,
  * genima_amd/packing.py pack_tblock_tape; gn_tblock_tape_bytes() long).  Replaces, inside the diffusers transformer blocks that
  * `self.pipe(...)` runs (controller/agent/sd_controlnet_agent.py:67-76; graphs.emit_transformer), the gn_gemm launches
+ *   GN_TBLOCK_FRONT: out = (a * scale[b] + shift[b]) Wi^T + bi   (Transformer2DModel.norm applied from its statistics-only pass + proj_in)
+ *                   out2 = LayerNorm1(out) [Wq | Wk]^T  row-major [M, 2C];  out3 = (LayerNorm1(out) Wv^T)^T per sample: V^T [B][C][ldo3]
+ *                                                         (norm1 folded into attn1.to_q / to_k / to_v; the attention kernels' operands)
  *   GN_TBLOCK_MID : out  = a Wo^T + bo + res1            (attn1.to_out.0 + residual)
  *                   out2 = LayerNorm2(out) Wq^T           (norm2 folded into attn2.to_q, as gn_gemm_desc.ln_c1)
  *   GN_TBLOCK_TAIL: h2   = a Wo^T + bo + res1            (attn2.to_out.0 + residual)
@@ -143,13 +146,13 @@ int32_t gn_quantize_fp8_rows(gn_ctx* ctx, const void* x, int64_t ldx, int64_t ro
  * h2 / h3 and the [M, 4C] GEGLU intermediate never leave the chip; every intermediate is rounded to f16 where the separate launches round
  * it.  Built for C = 320 (the 64x64-latent level), M % 128 == 0; gn_tblock_supported() says whether a problem qualifies.
  * All tensors f16 row-major, rows 16-byte aligned. */
-enum { GN_TBLOCK_MID = 1, GN_TBLOCK_TAIL = 2 };
+enum { GN_TBLOCK_MID = 1, GN_TBLOCK_TAIL = 2, GN_TBLOCK_FRONT = 3 };
 typedef struct gn_tblock_desc {
   int32_t kind;           /* GN_TBLOCK_* */
   int32_t C;              /* channels (320) */
   int64_t M;              /* rows (tokens) */
   const void* a;          /* [M, lda]: the attention output the first Linear consumes */
-  const void* res1;       /* [M, ldr1]: residual of the first Linear */
+  const void* res1;       /* [M, ldr1]: residual of the first Linear (MID / TAIL) */
   const void* res2;       /* TAIL: [M, ldr2] residual of proj_out (the transformer's input); MID: NULL */
   void* out;              /* [M, ldo]: MID: the residual stream after attn1; TAIL: the transformer's output */
   void* out2;             /* MID: [M, ldo2] cross-attention queries; TAIL: NULL */
@@ -157,6 +160,10 @@ typedef struct gn_tblock_desc {
   int64_t tape_bytes;
   int64_t lda, ldr1, ldr2, ldo, ldo2;
   float ln_eps;
+  const void* scsh;       /* FRONT: f32 [B][C][2] GroupNorm (scale, shift) pairs (gn_groupnorm_fwd with y == NULL) */
+  void* out3;             /* FRONT: V^T [B][C][ldo3] */
+  int64_t ldo3;
+  int32_t rows_per_batch; /* FRONT: tokens per sample (a multiple of 128) */
 } gn_tblock_desc;
 int64_t gn_tblock_tape_bytes(int32_t kind, int32_t C);          /* 0 = not built for this kind / width */
 int32_t gn_tblock_supported(int32_t kind, int64_t M, int32_t C); /* 1 / 0 */

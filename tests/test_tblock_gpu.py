@@ -92,6 +92,41 @@ def test_tblock_tail_vs_reference_and_unfused(engine, packed, M):
     assert rel_l2(out, un.float()) < 3e-4, rel_l2(out, un.float())
 
 
+@pytest.mark.parametrize("B,N", [(1, 128), (3, 256), (2, 2048)])
+def test_tblock_front_vs_reference_and_unfused(engine, packed, B, N):
+    """GroupNorm (no activation) -> proj_in -> norm1 -> q | k | v (V transposed per sample) against torch and against the launches replaced."""
+    sd, W = packed
+    W = dict(W)
+    g = torch.Generator().manual_seed(N)
+    gamma, beta = q16(1.0 + 0.2 * torch.randn(C, generator=g)), q16(0.2 * torch.randn(C, generator=g))
+    w_in, b_in = q16(torch.randn(C, C, generator=g) * C ** -0.5), q16(torch.randn(C, generator=g) * 0.2)
+    full = dict(sd)
+    full.update({"t.norm.weight": gamma, "t.norm.bias": beta, "t.proj_in.weight": w_in, "t.proj_in.bias": b_in})
+    W = packing.pack_state_dict(full, "cuda")
+    assert "t.tblock_front.tape" in W
+    x = q16(torch.randn(B, N, C, generator=g) * 1.5 + 0.5)
+    b = "t.transformer_blocks.0"
+    xn = F.group_norm(x.transpose(1, 2), 32, gamma, beta, 1e-6).transpose(1, 2)
+    rh = q16(q16(xn) @ w_in.T + b_in)
+    ln = F.layer_norm(rh, (C,), sd[f"{b}.norm1.weight"], sd[f"{b}.norm1.bias"], 1e-5)
+    rq, rk, rv = (ln @ sd[f"{b}.attn1.to_{n}.weight"].T for n in "qkv")
+    xd = x.half().cuda()
+    st = engine.groupnorm_stats(xd, W["t.norm.weight"], W["t.norm.bias"], 32, 1e-6)
+    h, qk, vt = engine.tblock_front(xd, st, W["t.tblock_front.tape"], N)
+    assert_close(h, rh, what="front: GroupNorm + proj_in")
+    assert_close(qk[:, :, :C], rq, what="front: q")
+    assert_close(qk[:, :, C:], rk, what="front: k")
+    assert_close(vt[:, :, :N], rv.transpose(1, 2), what="front: V^T")
+    if vt.shape[2] != N:
+        assert float(vt[:, :, N:].abs().max()) == 0.0
+    # the launches it replaces
+    n0 = engine.groupnorm(xd, W["t.norm.weight"], W["t.norm.bias"], 32, 1e-6)
+    h0 = engine.linear(n0, W["t.proj_in.weight"], W["t.proj_in.bias"])
+    qk0, vt0 = engine.linear(h0, W[b + ".attn1.to_qkv.ln_weight"], W[b + ".attn1.to_qkv.ln_c2"], ln_c1=W[b + ".attn1.to_qkv.ln_c1"], split_n=2 * C,
+                             rows_per_batch=N, pad_cols=vt.shape[2])
+    assert rel_l2(h, h0.float()) < 2e-4 and rel_l2(qk, qk0.float()) < 3e-4 and rel_l2(vt, vt0.float()) < 3e-4
+
+
 def test_tblock_rejects_what_it_is_not_built_for(engine, packed):
     from genima_amd._lib import GenimaHipError
 

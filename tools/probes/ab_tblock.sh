@@ -3,8 +3,8 @@
 #   tools/probes/ab_tblock.sh [steps]     (on the GPU box; writes gpurun_out/ab_tblock_{1,0}.json)
 steps=${1:-10}
 mkdir -p gpurun_out
-for v in 1 0 1 0; do
-  GN_TBLOCK=$v GN_CONV_GN=$v python bench.py --steps $steps --warmup 3 --no-train --no-single-view 2>/dev/null | tail -1 > gpurun_out/ab_tblock_$v.json
+for v in ${AB_ORDER:-1 0 1 0}; do
+  GN_TBLOCK=${AB_TBLOCK:-$v} GN_CONV_GN=${AB_CONV_GN:-$v} GN_TBLOCK_FRONT=${AB_FRONT:-$v} python bench.py --steps $steps --warmup 3 --no-train --no-single-view 2>/dev/null | tail -1 > gpurun_out/ab_tblock_$v.json
   python - <<PY
 import json
 d = json.load(open("gpurun_out/ab_tblock_$v.json"))
