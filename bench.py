@@ -66,15 +66,20 @@ def _pmc_traffic_file():
 PMC_TRAFFIC_FILE = _pmc_traffic_file()
 
 
-def pmc_traffic_per_launch(family: str):
+def pmc_traffic_per_launch(family: str, launches_per_call=None):
     """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-    collected as MI355X_MICROARCH.md prescribes).  None when the file is missing."""
+    collected as MI355X_MICROARCH.md prescribes).  None when the file is missing -- or when its stamp counts a different number of
+    launches per call than the program this run replays (``launches_per_call``): the counters then belong to another lowering."""
     path = os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)  # tools/probes/pmc_traffic.sh re-collects it
     try:
         with open(path) as f:
             d = json.load(f)
         fe, wr = d["FETCH_SIZE"][family], d["WRITE_SIZE"][family]
-        return (2.0 * fe["sum_counter"] / fe["launches"] + wr["sum_counter"] / wr["launches"]) * 1024.0
+        stamped = d.get("stamp", {}).get("gemm_ops_per_call")
+        if family == "gemm" and launches_per_call is not None and stamped is not None and abs(stamped - launches_per_call) > 0.5:
+            return None
+        # per OP of the recorded program (`launches_per_call` counts those: a split-K gn_gemm's reduce launch belongs to its op)
+        return (2.0 * fe["sum_counter"] / fe.get("ops", fe["launches"]) + wr["sum_counter"] / wr.get("ops", wr["launches"])) * 1024.0
     except (OSError, KeyError, ValueError, ZeroDivisionError):
         return None
 
@@ -427,7 +432,7 @@ def main():
         ach = g_fl / (g_ms * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": "gemm_dma_kernel / gemm_kernel<BM,BN,WM,WN,CONV> (MFMA implicit-GEMM conv3x3/1x1 + Linear) + tblock_kernel (fused Linear chains)",
                            "achieved": ach, "peak": MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / MFMA_PEAK_TF,
-                           "traffic": pmc_traffic_per_launch("gemm") if args.workload == "tiled_b8" else None,
+                           "traffic": pmc_traffic_per_launch("gemm", n_l) if args.workload == "tiled_b8" else None,
                            "traffic_note": "HBM bytes per launch of this kernel family from the committed rocprofv3 --pmc passes of this "
                                            f"workload (profiles/{PMC_TRAFFIC_FILE}: 2 x FETCH_SIZE + WRITE_SIZE, KB -> bytes; "
                                            "the x2 is MI355X_MICROARCH.md's gfx950 FETCH_SIZE correction); not re-collected by this run",
