@@ -77,3 +77,46 @@ def test_upsample_phase_weights_are_the_collapsed_taps():
     assert float((out - ref).abs().max()) < 1e-12
 
 
+
+
+def test_tblock_tape_layout_byte_for_byte():
+    """The weight tapes of the fused transformer-block chains (csrc/tblock.hip): every slot is the LDS image the kernel copies verbatim, so
+    the layout is restated here byte by byte from the kernel's own addressing -- row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4) inside a
+    [rows x 32] sub-tile (csrc/common.h lds_swz<64>), 20 KB slots in consumption order, the GEGLU chunk's c1 / c2 at byte 16384 of its last
+    projection slot, the vector block behind the last slot."""
+    import numpy as np
+
+    from genima_amd import packing as P
+
+    C = 320
+    g = torch.Generator().manual_seed(0)
+    r16 = lambda *s: torch.randn(*s, generator=g).half()  # noqa: E731
+    wo, bo, w1, w2, b2, wp, bp = r16(C, C), r16(C), r16(8 * C, C), r16(C, 4 * C), r16(C), r16(C, C), r16(C)
+    c1, c2 = torch.randn(8 * C, generator=g), r16(8 * C)
+    tape = P.pack_tblock_tail_tape(wo, bo, w1, c1, c2, w2, b2, wp, bp).numpy()
+    assert tape.dtype == np.uint8 and tape.size == 160 * 20480 + 3072
+
+    def elem(slot, sub_off, row, k):  # the f16 the kernel's MFMA fragment read finds for (row, k) of a sub-tile at byte sub_off of a slot
+        off = slot * 20480 + sub_off + row * 64 + (((k >> 3) ^ ((row >> 2) & 3)) << 4) + (k & 7) * 2
+        return tape[off:off + 2].view(np.float16)[0]
+
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n, k = int(rng.integers(C)), int(rng.integers(C))
+        assert elem(k // 32, 0, n, k % 32) == wo[n, k].numpy()                       # attn2.to_out: slots 0..9
+        assert elem(150 + k // 32, 0, n, k % 32) == wp[n, k].numpy()                 # proj_out: slots 150..159
+        ch, r = int(rng.integers(20)), int(rng.integers(128))
+        assert elem(10 + 7 * ch + k // 64, 8192 * ((k % 64) // 32), r, k % 32) == w1[128 * ch + r, k].numpy()   # GEGLU projection chunk
+        kk = int(rng.integers(64))
+        assert elem(10 + 7 * ch + 5 + kk // 32, 0, n, kk % 32) == w2[n, 64 * ch + kk].numpy()                   # ff.net.2 chunk
+        base = (10 + 7 * ch + 4) * 20480 + 16384
+        assert tape[base + 4 * r:base + 4 * r + 4].view(np.float32)[0] == c1[128 * ch + r].numpy()
+        assert tape[base + 512 + 2 * r:base + 512 + 2 * r + 2].view(np.float16)[0] == c2[128 * ch + r].numpy()
+    vec = tape[160 * 20480:]
+    assert (vec[:640].view(np.float16) == bo.numpy()).all() and (vec[640:1280].view(np.float16) == b2.numpy()).all()
+    assert (vec[1280:1920].view(np.float16) == bp.numpy()).all() and not vec[1920:].any()
+    mid = P.pack_tblock_mid_tape(wo, bo, wp, c1[:C], c2[:C]).numpy()
+    assert mid.size == 20 * 20480 + 3072 and (mid[20 * 20480 + 640:20 * 20480 + 1920].view(np.float32) == c1[:C].numpy()).all()
+    front = P.pack_tblock_front_tape(wo, bo, w1[:3 * C], c1[:3 * C], c2[:3 * C]).numpy()
+    assert front.size == 40 * 20480 + 7168
+    assert (front[40 * 20480 + 640:40 * 20480 + 640 + 3840].view(np.float32) == c1[:3 * C].numpy()).all()
