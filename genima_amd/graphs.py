@@ -135,7 +135,10 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
     B, H, Wd, Cc = x.shape
     N = H * Wd
     with E.scope(p):
-        use_tb = (getattr(E, "tblock", True) and not E._fp8_weights and getattr(E, "ln_fold", True) and B * N >= getattr(E, "tblock_min_rows", 0)
+        # (E.tblock_any_fold: the trainer's frozen front switches the folded gn_gemm launches off -- their tune table is the inference
+        # graphs' -- but keeps the chains, which carry their own folded weights in the tape)
+        use_tb = (getattr(E, "tblock", True) and not E._fp8_weights and (getattr(E, "ln_fold", True) or getattr(E, "tblock_any_fold", False))
+                  and B * N >= getattr(E, "tblock_min_rows", 0)
                   and f"{p}.transformer_blocks.0.tblock_tail.tape" in W and E.tblock_supported(B * N, Cc))
         front = None
         if use_tb and p + ".tblock_front.tape" in W and N % 128 == 0 and getattr(E, "tblock_front_on", True):

@@ -685,11 +685,12 @@ def unet_frozen_front(E: Engine, net: FrozenParams, cfg, x8: torch.Tensor, t_dev
     kv_inf = graphs.emit_cross_kv(E, W, ctx, "unet_train")
     h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"])
     fold, E.ln_fold = E.ln_fold, False  # the folded LayerNorm -> Linear launches are tuned for the inference shapes only
+    any_fold, E.tblock_any_fold = getattr(E, "tblock_any_fold", False), fold  # (the fused chains of csrc/tblock.hip need no tuning: kept)
     try:
         h, skips = graphs._emit_encoder(E, W, cfg, h, shifts, kv_inf)
         h = graphs._emit_mid(E, W, cfg, h, shifts, kv_inf)
     finally:
-        E.ln_fold = fold
+        E.ln_fold, E.tblock_any_fold = fold, any_fold
     return shifts, h, skips
 
 
