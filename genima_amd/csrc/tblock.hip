@@ -83,7 +83,7 @@ __device__ __forceinline__ void pack_tile(const float (&v)[16], u32x4 (&q)[2]) {
   }
 }
 
-template <int KIND, int ABL = 0>  // ABL: timing ablations (GN_TBLOCK_ABL, wrong results): 1 no MFMA, 2 no weight DMA, 3 no GELU, 4 no slot barriers
+template <int KIND>
 __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[TB_LDS];  // ONE LDS object (a second one makes hipcc drain vmcnt around the DMAs)
 
@@ -127,7 +127,6 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   int n_issued = 0, ibuf = 0;
   auto issue = [&]() __attribute__((always_inline)) {
     // past the last slot: offsets out of range = zero fill, no fetch -- every wave keeps issuing the same number of VMEM instructions
-    if constexpr (ABL == 2) return;
     const unsigned off = (unsigned)n_issued * TB_SLOT + lane * 16 + (n_issued < p.nslots ? 0u : 0x80000000u);
     unsigned char* dst = smem + TB_RING_OFF + ibuf * TB_SLOT;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_t, (lds_ptr_t)(dst + pc0 * 1024), 16, off + pc0 * 1024, 0, 0, 0);
@@ -152,7 +151,7 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
       if (wave < 4) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     }
-    if constexpr (ABL != 4) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
     issue();
     f(smem + TB_RING_OFF + cbuf * TB_SLOT);
@@ -167,7 +166,6 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
   // ---- MFMA pieces.  Operands swapped as in gemm.hip (D = W_tile A_tile^T): the lane holds D[n = 8g + 4hi + (r & 3)][m = l31].
   // one [320 x 32] weight slot against one [128 x 32] sub-tile of the A image: this wave's 32 rows x 160 columns
   auto mma_nc = [&](f32x16 (&acc)[5], const unsigned char* As, const unsigned char* Ws) __attribute__((always_inline)) {
-    if constexpr (ABL == 1) return;
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       const int c = kk * 2 + hi;
@@ -393,7 +391,7 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
         consume([&](const unsigned char* Ws) __attribute__((always_inline)) {
           // slot = two [128 x 32] pieces of the chunk's 128 packed rows [hidden 0..31 | gate 0..31 | hidden 32..63 | gate 32..63]
 #pragma unroll
-          for (int sub = 0; sub < (ABL == 1 ? 0 : 2); ++sub) {
+          for (int sub = 0; sub < 2; ++sub) {
             const unsigned char* As = smem + (2 * js + sub) * TB_SUB;
             const unsigned char* Wp = Ws + sub * TB_SUB;
 #pragma unroll
@@ -421,7 +419,7 @@ __global__ __launch_bounds__(TB_NT, 2) void tblock_kernel(const TbParams p) {
               for (int e = 0; e < 4; ++e) {
                 const float hv = (st[1] * hacc[0][4 * g + e] + st[0] * c1h[e]) + (float)c2h[e];
                 const float gv = (st[1] * hacc[1][4 * g + e] + st[0] * c1g[e]) + (float)c2g[e];
-                v[4 * g + e] = ABL == 3 ? hv * gv : hv * gelu_fast(gv);
+                v[4 * g + e] = hv * gelu_fast(gv);
               }
             }
             u32x4 q[2];
@@ -496,14 +494,7 @@ int32_t gn_launch_tblock(gn_ctx* ctx, const gn_tblock_desc* d) {
   } else {
     GN_REQUIRE(d->res2 && d->ldr2 % 8 == 0 && ((uintptr_t)d->res2 & 15) == 0, "gn_tblock(tail): res2 (the block input) must be given, 16-byte aligned");
     p.nslots = 2 * TB_KT + TB_FF_CHUNKS * 7;
-    static const int abl = [] { const char* e = getenv("GN_TBLOCK_ABL"); return e ? atoi(e) : 0; }();
-    switch (abl) {
-      case 1: hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_TAIL, 1>), grid, block, 0, ctx->stream, p); break;
-      case 2: hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_TAIL, 2>), grid, block, 0, ctx->stream, p); break;
-      case 3: hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_TAIL, 3>), grid, block, 0, ctx->stream, p); break;
-      case 4: hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_TAIL, 4>), grid, block, 0, ctx->stream, p); break;
-      default: hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_TAIL>), grid, block, 0, ctx->stream, p); break;
-    }
+    hipLaunchKernelGGL((tblock_kernel<GN_TBLOCK_TAIL>), grid, block, 0, ctx->stream, p);
   }
   GN_LAUNCH_CHECK();
   return GN_OK;
