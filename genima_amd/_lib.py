@@ -82,6 +82,10 @@ class TBlockDesc(C.Structure):
 TBLOCK_MID, TBLOCK_TAIL, TBLOCK_FRONT = 1, 2, 3
 
 
+class TBlockTapeSrc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("C", C.c_int32)] + [(n, C.c_void_p) for n in ("w_a", "b_a", "w_ln", "c1", "c2", "w2", "b2", "w_p", "b_p")]
+
+
 class ConvGnDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("scsh", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("out", C.c_void_p),
@@ -116,6 +120,7 @@ SIGNATURES = {
     "gn_tblock_tape_bytes": (_I64, [_I32, _I32]),
     "gn_tblock_supported": (_I32, [_I32, _I64, _I32]),
     "gn_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),
+    "gn_pack_tblock_tape": (_I32, [_P, C.POINTER(TBlockTapeSrc), _P, _I64]),
     "gn_program_add_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),
     "gn_conv3x3_gn_supported": (_I32, [_I32, _I32, _I32, _I32, _I32]),
     "gn_conv3x3_gn": (_I32, [_P, C.POINTER(ConvGnDesc)]),

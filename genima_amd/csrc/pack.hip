@@ -60,6 +60,74 @@ __global__ __launch_bounds__(256) void fold_ln_kernel(const f16* __restrict__ w,
   }
 }
 
+
+// ---- weight tapes of the fused transformer-block chains (csrc/tblock.hip): one thread per 16-byte chunk of the tape ------------------------
+struct TapeSrc {
+  const f16* w_a; const f16* b_a;
+  const f16* w_ln; const float* c1; const f16* c2;
+  const f16* w2; const f16* b2;
+  const f16* w_p; const f16* b_p;
+  int kind, C, nslots;
+  long nchunks;
+};
+
+// 16 bytes of the LDS image of an [rows x 32] sub-tile (64-byte rows, chunk ^ ((row >> 2) & 3): csrc/common.h lds_swz<64>): physical chunk
+// `pc` of row `row` holds the logical chunk pc ^ ((row >> 2) & 3) of m[row][k0 .. k0 + 32)
+__device__ __forceinline__ uint4 image_chunk(const f16* m, long ld, int row, int pc, int k0) {
+  const int lc = pc ^ ((row >> 2) & 3);
+  return *reinterpret_cast<const uint4*>(m + (long)row * ld + k0 + lc * 8);
+}
+
+__global__ __launch_bounds__(256) void pack_tblock_tape_kernel(const TapeSrc s, uint4* __restrict__ tape) {
+  const long q = (long)blockIdx.x * 256 + threadIdx.x;
+  if (q >= s.nchunks) return;
+  const int C = s.C;
+  const long slot = q / 1280;
+  const int w = (int)(q - slot * 1280);
+  uint4 v = make_uint4(0, 0, 0, 0);
+  auto nc = [&](const f16* m, long ld, int k0) { return image_chunk(m, ld, w >> 2, w & 3, k0); };
+  if (slot < s.nslots) {
+    const int sl = (int)slot;
+    if (sl < 10) {
+      v = nc(s.w_a, C, 32 * sl);
+    } else if (s.kind == GN_TBLOCK_FRONT) {
+      const int g = (sl - 10) / 10, j = (sl - 10) % 10;
+      v = nc(s.w_ln + (long)g * C * C, C, 32 * j);
+    } else if (s.kind == GN_TBLOCK_MID) {
+      v = nc(s.w_ln, C, 32 * (sl - 10));
+    } else if (sl >= 150) {
+      v = nc(s.w_p, C, 32 * (sl - 150));
+    } else {
+      const int t = sl - 10, ch = t / 7, j = t % 7;
+      if (j >= 5) {
+        v = nc(s.w2, 4l * C, 64 * ch + 32 * (j - 5));
+      } else if (w < 1024) {  // two [128 x 32] pieces of the chunk's packed GEGLU rows
+        const int sub = w >> 9, r = (w & 511) >> 2;
+        v = image_chunk(s.w_ln + (long)(128 * ch) * C, C, r, w & 3, 64 * j + 32 * sub);
+      } else if (j == 4 && w < 1024 + 32) {  // the chunk's c1 (f32 [128]) ...
+        v = *reinterpret_cast<const uint4*>(s.c1 + 128 * ch + (w - 1024) * 4);
+      } else if (j == 4 && w < 1024 + 48) {  // ... and c2 (f16 [128])
+        v = *reinterpret_cast<const uint4*>(s.c2 + 128 * ch + (w - 1056) * 8);
+      }
+    }
+  } else {  // the vector block behind the last slot
+    const int b = (int)((q - (long)s.nslots * 1280) * 16);
+    const int nb = C * 2;  // bytes of an f16 [C] vector
+    auto from = [&](const void* p, int off) { return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(p) + off); };
+    if (b < nb) {
+      v = from(s.b_a, b);
+    } else if (s.kind == GN_TBLOCK_TAIL) {
+      if (b < 2 * nb) v = from(s.b2, b - nb);
+      else if (b < 3 * nb) v = from(s.b_p, b - 2 * nb);
+    } else {
+      const int ncol = s.kind == GN_TBLOCK_FRONT ? 3 * C : C;  // columns of the folded Linear
+      if (b < nb + ncol * 4) v = from(s.c1, b - nb);
+      else if (b < nb + ncol * 6) v = from(s.c2, b - nb - ncol * 4);
+    }
+  }
+  tape[q] = v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -93,3 +161,22 @@ int32_t gn_pack_fold_layernorm(gn_ctx* ctx, const void* w, const void* gamma, co
 }
 
 }  // extern "C"
+
+extern "C" int32_t gn_pack_tblock_tape(gn_ctx* ctx, const gn_tblock_tape_src* d, void* tape, int64_t tape_bytes) {
+  GN_REQUIRE(ctx && d && tape, "gn_pack_tblock_tape: null argument");
+  GN_REQUIRE(tape_bytes > 0 && tape_bytes == gn_tblock_tape_bytes(d->kind, d->C), "gn_pack_tblock_tape: tape_bytes %ld != gn_tblock_tape_bytes(%d, %d) = %ld",
+             (long)tape_bytes, d->kind, d->C, (long)gn_tblock_tape_bytes(d->kind, d->C));
+  GN_REQUIRE(d->w_a && d->b_a && d->w_ln && d->c1 && d->c2, "gn_pack_tblock_tape: w_a / b_a / w_ln / c1 / c2 are required");
+  if (d->kind == GN_TBLOCK_TAIL) GN_REQUIRE(d->w2 && d->b2 && d->w_p && d->b_p, "gn_pack_tblock_tape(tail): w2 / b2 / w_p / b_p are required");
+  const void* ptrs[] = {d->w_a, d->b_a, d->w_ln, d->c1, d->c2, d->w2, d->b2, d->w_p, d->b_p, tape};
+  for (const void* q : ptrs) GN_REQUIRE(((uintptr_t)q & 15) == 0, "gn_pack_tblock_tape: every operand must be 16-byte aligned");
+  TapeSrc s;
+  s.w_a = (const f16*)d->w_a; s.b_a = (const f16*)d->b_a; s.w_ln = (const f16*)d->w_ln; s.c1 = d->c1; s.c2 = (const f16*)d->c2;
+  s.w2 = (const f16*)d->w2; s.b2 = (const f16*)d->b2; s.w_p = (const f16*)d->w_p; s.b_p = (const f16*)d->b_p;
+  s.kind = d->kind; s.C = d->C;
+  s.nslots = d->kind == GN_TBLOCK_TAIL ? 160 : (d->kind == GN_TBLOCK_MID ? 20 : 40);
+  s.nchunks = tape_bytes / 16;
+  hipLaunchKernelGGL(pack_tblock_tape_kernel, dim3(pk_nblk(s.nchunks)), dim3(256), 0, ctx->stream, s, (uint4*)tape);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}

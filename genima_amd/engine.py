@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_FRONT, TBLOCK_MID,
-                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, check)
+                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, TBlockTapeSrc, check)
 
 F16 = torch.float16
 
@@ -606,6 +606,22 @@ class Engine:
         check(self.lib.gn_pack_geglu_rows(self._ctx, _ptr(w), f16, _ptr(wp), H, K), "gn_pack_geglu_rows")
         check(self.lib.gn_pack_geglu_rows(self._ctx, _ptr(b), f16, _ptr(bp), H, 1), "gn_pack_geglu_rows")
         return wp, bp
+
+    def pack_tblock_tape(self, kind: int, w_a, b_a, w_ln, c1, c2, w2=None, b2=None, w_p=None, b_p=None) -> torch.Tensor:
+        """The weight tape of a fused transformer-block chain (gn_pack_tblock_tape) from packed f16 device tensors (c1 f32) -> uint8 tensor."""
+        assert not self.record
+        ts = [None if t is None else t.contiguous() for t in (w_a, b_a, w_ln, c1, c2, w2, b2, w_p, b_p)]
+        for t, want in zip(ts, (F16, F16, F16, torch.float32, F16, F16, F16, F16, F16)):
+            assert t is None or (t.is_cuda and t.dtype == want), (None if t is None else (t.dtype, t.device))
+        Cc = ts[0].shape[1]
+        nbytes = int(self.lib.gn_tblock_tape_bytes(kind, Cc))
+        tape = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        d = TBlockTapeSrc()
+        d.kind, d.C = kind, Cc
+        d.w_a, d.b_a, d.w_ln, d.c1, d.c2, d.w2, d.b2, d.w_p, d.b_p = (_ptr(t) for t in ts)
+        check(self.lib.gn_pack_tblock_tape(self._ctx, C.byref(d), _ptr(tape), nbytes), "gn_pack_tblock_tape")
+        self._pack_keep = ts  # (the sources stay alive until the stream has run the kernel: the caller synchronises before dropping the engine)
+        return tape
 
     # ------------------------------------------------------------------------------------------------ attention
     def attention(self, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, *, Nk: Optional[int] = None,

@@ -215,7 +215,7 @@ def pack_tblock_tail_tape(wo, bo, w1_ln, c1, c2, w2, b2, wp, bp) -> torch.Tensor
     return torch.cat(parts).contiguous()
 
 
-def add_tblock_tapes(packed: Dict[str, torch.Tensor]) -> None:
+def add_tblock_tapes(packed: Dict[str, torch.Tensor], hip=None) -> None:
     """For every single-block Transformer2DModel of width 320 in a PACKED f16 dict (after fold_layernorms) add ``<block>.tblock_mid.tape`` and
     ``<block>.tblock_tail.tape`` (uint8): graphs.emit_transformer then runs attn1.to_out .. attn2.to_q and attn2.to_out .. proj_out as two
     gn_tblock launches instead of six gn_gemm launches."""
@@ -231,8 +231,22 @@ def add_tblock_tapes(packed: Dict[str, torch.Tensor]) -> None:
         if any(k not in packed for k in need) or packed[p + ".proj_out.weight"].dim() != 2:
             continue
         dev = packed[name].device  # (a dict packed for a ROCm device holds its GEGLU tensors there already, the rest still on the host)
-        g = lambda k: packed[k].to(dev)
-        if (b + ".attn1.to_qkv.ln_weight") in packed and (p + ".proj_in.weight") in packed and packed[p + ".proj_in.weight"].dim() == 2:
+        g = lambda k: packed[k].to(dev)  # noqa: E731
+        front = (b + ".attn1.to_qkv.ln_weight") in packed and (p + ".proj_in.weight") in packed and packed[p + ".proj_in.weight"].dim() == 2
+        if hip is not None and dev.type == "cuda":
+            # the library's own packer (gn_pack_tblock_tape: the entry point a non-Python host calls); bit-identical to the torch restatements above
+            from ._lib import TBLOCK_FRONT, TBLOCK_MID, TBLOCK_TAIL
+            if front:
+                packed[p + ".tblock_front.tape"] = hip.pack_tblock_tape(TBLOCK_FRONT, g(p + ".proj_in.weight"), g(p + ".proj_in.bias"), g(b + ".attn1.to_qkv.ln_weight"),
+                                                                        g(b + ".attn1.to_qkv.ln_c1"), g(b + ".attn1.to_qkv.ln_c2"))
+            packed[b + ".tblock_mid.tape"] = hip.pack_tblock_tape(TBLOCK_MID, g(b + ".attn1.to_out.0.weight"), g(b + ".attn1.to_out.0.bias"), g(b + ".attn2.to_q.ln_weight"),
+                                                                  g(b + ".attn2.to_q.ln_c1"), g(b + ".attn2.to_q.ln_c2"))
+            packed[b + ".tblock_tail.tape"] = hip.pack_tblock_tape(TBLOCK_TAIL, g(b + ".attn2.to_out.0.weight"), g(b + ".attn2.to_out.0.bias"), g(name),
+                                                                   g(b + ".ff.net.0.proj.ln_c1"), g(b + ".ff.net.0.proj.ln_c2"), g(b + ".ff.net.2.weight"),
+                                                                   g(b + ".ff.net.2.bias"), g(p + ".proj_out.weight"), g(p + ".proj_out.bias"))
+            hip.synchronize()
+            continue
+        if front:
             packed[p + ".tblock_front.tape"] = pack_tblock_front_tape(g(p + ".proj_in.weight"), g(p + ".proj_in.bias"), g(b + ".attn1.to_qkv.ln_weight"),
                                                                      g(b + ".attn1.to_qkv.ln_c1"), g(b + ".attn1.to_qkv.ln_c2"))
         packed[b + ".tblock_mid.tape"] = pack_tblock_mid_tape(g(b + ".attn1.to_out.0.weight"), g(b + ".attn1.to_out.0.bias"), g(b + ".attn2.to_q.ln_weight"),
@@ -341,7 +355,7 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16, up
                     out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
     if dtype == torch.float16:
         fold_layernorms(out)
-        add_tblock_tapes(out)
+        add_tblock_tapes(out, hip)
     meta = {}
     if temb_w:
         out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(dtype).contiguous()

@@ -168,6 +168,21 @@ typedef struct gn_tblock_desc {
 int64_t gn_tblock_tape_bytes(int32_t kind, int32_t C);          /* 0 = not built for this kind / width */
 int32_t gn_tblock_supported(int32_t kind, int64_t M, int32_t C); /* 1 / 0 */
 int32_t gn_tblock(gn_ctx* ctx, const gn_tblock_desc* d);
+/* The chain's weight tape from the packed f16 tensors (what genima_amd/packing.py pack_tblock_*_tape does with torch ops, bit for bit): every
+ * 20 KB slot is the LDS image the kernel copies verbatim -- [rows x 32] sub-tiles with 64-byte rows whose 16-byte chunks are XOR-swizzled by
+ * (row >> 2) & 3 -- in consumption order, the bias / c1 / c2 vectors behind the last slot.  Run once per checkpoint load.
+ *   w_a, b_a : the chain's first Linear [C, C], [C]     (FRONT proj_in; MID attn1.to_out.0; TAIL attn2.to_out.0)
+ *   w_ln, c1, c2 : its LayerNorm-folded Linear (gn_pack_fold_layernorm): FRONT attn1 q | k | v [3C, C]; MID attn2.to_q [C, C];
+ *                  TAIL ff.net.0.proj [8C, C] in the packed GEGLU row order (gn_pack_geglu_rows); c1 f32, c2 f16
+ *   w2, b2 : TAIL ff.net.2 [C, 4C], [C];   w_p, b_p : TAIL proj_out [C, C], [C] */
+typedef struct gn_tblock_tape_src {
+  int32_t kind, C;
+  const void* w_a; const void* b_a;
+  const void* w_ln; const float* c1; const void* c2;
+  const void* w2; const void* b2;
+  const void* w_p; const void* b_p;
+} gn_tblock_tape_src;
+int32_t gn_pack_tblock_tape(gn_ctx* ctx, const gn_tblock_tape_src* src, void* tape, int64_t tape_bytes);
 
 /* ---- K4/K5/K11: flash-style attention forward --------------------------------------------------------------------
  * o[b, i, h*D + :] = softmax_j(scale * q[b,i,h] . k[b,j,h]) v[b,j,h]; V is consumed TRANSPOSED (vt[b][h*D + d][j], produced

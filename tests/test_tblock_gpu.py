@@ -163,3 +163,21 @@ def test_transformer_graph_with_and_without_the_fused_chains(engine, packed):
     finally:
         engine.tblock, engine.tblock_min_rows = old, old_min
     assert rel_l2(y1, y0) < 5e-4, rel_l2(y1, y0)
+
+
+def test_device_tape_packer_matches_the_torch_restatement(engine):
+    """gn_pack_tblock_tape (the library's packer, what pack_state_dict uses on a ROCm device) against packing.pack_tblock_*_tape (torch ops; the
+    layout tests/test_packing_cpu.py restates byte for byte): identical bytes for all three chains."""
+    from genima_amd._lib import TBLOCK_FRONT, TBLOCK_MID, TBLOCK_TAIL
+
+    g = torch.Generator().manual_seed(3)
+    r16 = lambda *s: torch.randn(*s, generator=g).half()  # noqa: E731
+    wo, bo, w1, w2, b2, wp, bp = r16(C, C), r16(C), r16(8 * C, C), r16(C, 4 * C), r16(C), r16(C, C), r16(C)
+    c1, c2 = torch.randn(8 * C, generator=g), r16(8 * C)
+    d = lambda t: t.cuda()  # noqa: E731
+    tail = engine.pack_tblock_tape(TBLOCK_TAIL, d(wo), d(bo), d(w1), d(c1), d(c2), d(w2), d(b2), d(wp), d(bp))
+    assert torch.equal(tail.cpu(), packing.pack_tblock_tail_tape(wo, bo, w1, c1, c2, w2, b2, wp, bp))
+    mid = engine.pack_tblock_tape(TBLOCK_MID, d(wo), d(bo), d(wp), d(c1[:C]), d(c2[:C]))
+    assert torch.equal(mid.cpu(), packing.pack_tblock_mid_tape(wo, bo, wp, c1[:C], c2[:C]))
+    front = engine.pack_tblock_tape(TBLOCK_FRONT, d(wo), d(bo), d(w1[:3 * C]), d(c1[:3 * C].contiguous()), d(c2[:3 * C]))
+    assert torch.equal(front.cpu(), packing.pack_tblock_front_tape(wo, bo, w1[:3 * C], c1[:3 * C], c2[:3 * C]))
