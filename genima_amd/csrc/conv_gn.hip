@@ -27,10 +27,8 @@ constexpr int CG_PH = CG_TH + 2, CG_PW = CG_TW + 2;       // patch with halo
 constexpr int CG_NPIX = CG_PH * CG_PW;                    // 180
 constexpr int CG_CG = 128;                                // channels per patch (one channel group)
 constexpr int CG_PATCH = CG_NPIX * CG_CG * 2;             // 46080 bytes
-constexpr int CG_WT = 128 * 128;                          // one weight K tile [128 rows x 64 k] = 16384 bytes
-constexpr int CG_W_OFF = CG_PATCH;
-constexpr int CG_LDS = CG_W_OFF + 2 * CG_WT;              // 78848
-static_assert(2 * CG_LDS <= 160 * 1024, "two workgroups per CU");
+constexpr int CG_W_OFF = CG_PATCH;                        // behind the patch: two weight K tiles [BN rows x 64 k] (BN = 128: 2 x 16 KB)
+static_assert(2 * (CG_W_OFF + 2 * 128 * 128) <= 160 * 1024, "two workgroups per CU");
 
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
@@ -47,13 +45,18 @@ struct CgParams {
   unsigned x_bytes, w_bytes;
 };
 
-__global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[CG_LDS];  // ONE LDS object (see tblock.hip on hipcc's vmcnt drains)
+// BN = 128: the ResNet convs (2 x 2 waves, 64 x 64 wave tiles).  BN = 32: convs with a handful of output channels -- the VAE's conv_out (3 of 8
+// padded channels) behind conv_norm_out + SiLU: 4 x 1 waves of one 32 x 32 tile each, the launch is the patch load + normalisation + one read of x
+template <int BN>
+__device__ __forceinline__ void conv3x3_gn_body(const CgParams& p, unsigned char* smem) {
+  constexpr int WN = BN == 128 ? 2 : 1, WM = 4 / WN, TM = 128 / (32 * WM), TN = BN / (32 * WN);
+  constexpr int CG_WT = BN * 128;  // one weight K tile [BN rows x 64 k]
+  constexpr int GB = BN / 32;      // weight DMA instructions per wave and K tile
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, hi = lane >> 5;
 
   // XCD-aware block -> tile map (block b runs on XCD b % 8): an XCD walks a contiguous run of tiles, the N tiles of one patch side by
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
   t /= p.tiles_x;
   const int ty = t % p.tiles_y;
   const int b = t / p.tiles_y;
-  const int y0 = ty * CG_TH, x0 = tx * CG_TW, n0 = tile_n * 128;
+  const int y0 = ty * CG_TH, x0 = tx * CG_TW, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -79,48 +82,48 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
   const int lr = lane >> 3;
   const int wchunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
   const long ldw = 9l * p.Cin;
-  unsigned woff[4];
+  unsigned woff[GB];  // (rows past Cout start past the buffer's end: they land as zeros)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) woff[i] = (unsigned)(((long)(n0 + 8 * (wave + 4 * i) + lr) * ldw + wchunk * 8) * 2);  // (Cout % 128 == 0: rows in range)
+  for (int i = 0; i < GB; ++i) woff[i] = (unsigned)(((long)(n0 + 8 * (wave + 4 * i) + lr) * ldw + wchunk * 8) * 2);
   auto dma_w = [&](int stage, int kelem) __attribute__((always_inline)) {
     unsigned char* Ws = smem + CG_W_OFF + stage * CG_WT;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < GB; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Ws + (wave + 4 * i) * 1024), 16, woff[i] + (unsigned)kelem * 2u, 0, 0, 0);
   };
 
   // ---- A fragment addressing: GEMM row m = 16 py + px of the tile; its tap (dy, dx) pixel sits at patch index (py + dy) * 18 + px + dx
-  int pidx0[2];
+  int pidx0[TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < TM; ++i) {
+    const int m = wm * (32 * TM) + i * 32 + l31;
     pidx0[i] = (m >> 4) * CG_PW + (m & 15);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[TN][TM];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][i][r] = 0.0f;
 
   // residual rows of this wave's tiles, requested ahead of the K loop (raw 16-byte pieces; the lane swap waits for the data: epilogue)
-  long orow[2];
+  long orow[TM];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < TM; ++i) {
+    const int m = wm * (32 * TM) + i * 32 + l31;
     orow[i] = ((long)b * p.H + y0 + (m >> 4)) * p.W + x0 + (m & 15);
   }
-  u32x4v rraw[2][2][2];
-  if (p.res) {
+  u32x4v rraw[TM][TN][2];
+  if (BN == 128 && p.res) {  // (the narrow variant takes no residual)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          rraw[i][j][h] = *reinterpret_cast<const u32x4v*>(p.res + orow[i] * p.ldr + n0 + wn * 64 + j * 32 + 16 * h + 8 * hi);
+          rraw[i][j][h] = *reinterpret_cast<const u32x4v*>(p.res + orow[i] * p.ldr + n0 + wn * (32 * TN) + j * 32 + 16 * h + 8 * hi);
   }
 
   const int ngroups = p.Cin / CG_CG;
@@ -198,18 +201,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
         const int cl = kc * 8 + kk * 2 + hi;  // logical 16-byte chunk of the pixel's 128 channels
-        f16x8 fa[2], fw[2];
+        f16x8 fa[TM], fw[TN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < TM; ++i) {
           const int idx = pidx0[i] + toff;
           fa[i] = *reinterpret_cast<const f16x8*>(smem + idx * 256 + ((cl ^ (idx & 15)) << 4));
         }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const f16x8*>(Ws + lds_swz<128>(wn * 64 + j * 32 + l31, kk * 2 + hi));
+        for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f16x8*>(Ws + lds_swz<128>(wn * (32 * TN) + j * 32 + l31, kk * 2 + hi));
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+          for (int i = 0; i < TM; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[j], fa[i], acc[j][i], 0, 0, 0);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -219,23 +222,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
 
   // ---- epilogue: + bias (+ residual) -> f16, 16-byte row stores (lanes l / l + 32 trade halves, as gemm_common.h's wide path)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < TM; ++i) {
     f16* orw = p.out + orow[i] * p.ldo;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int nb = n0 + wn * 64 + j * 32;
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + wn * (32 * TN) + j * 32;
       float v[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) v[e] = acc[j][i][e];
       if (p.bias) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const f16x4 bb = *reinterpret_cast<const f16x4*>(p.bias + nb + 8 * g + 4 * hi);
+          if (BN == 128 || nb + 8 * g + 4 * hi + 4 <= p.Cout) {
+            const f16x4 bb = *reinterpret_cast<const f16x4*>(p.bias + nb + 8 * g + 4 * hi);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[4 * g + e] += (float)bb[e];
+            for (int e = 0; e < 4; ++e) v[4 * g + e] += (float)bb[e];
+          }
         }
       }
-      if (p.res) {
+      if (BN == 128 && p.res) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const u32x4v r = rraw[i][j][h];
@@ -255,16 +260,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
         const uint2 ua = *reinterpret_cast<const uint2*>(&ha), ub = *reinterpret_cast<const uint2*>(&hb);
         const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
         const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
-        *reinterpret_cast<u32x4v*>(orw + nb + 8 * g + 8 * hi) = u32x4v{r0[0], r1[0], r0[1], r1[1]};
+        if (BN == 128 || nb + 8 * g + 8 * hi + 8 <= p.Cout) *reinterpret_cast<u32x4v*>(orw + nb + 8 * g + 8 * hi) = u32x4v{r0[0], r1[0], r0[1], r1[1]};
       }
     }
   }
 }
 
+// (two plain kernels around the templated body: each owns its ONE LDS object -- see tblock.hip on hipcc's vmcnt drains)
+__global__ __launch_bounds__(256, 2) void conv3x3_gn_kernel(const CgParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CG_W_OFF + 2 * 128 * 128];
+  conv3x3_gn_body<128>(p, smem);
+}
+__global__ __launch_bounds__(256, 2) void conv3x3_gn_narrow_kernel(const CgParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[CG_W_OFF + 2 * 32 * 128];
+  conv3x3_gn_body<32>(p, smem);
+}
+
 }  // namespace
 
 extern "C" int32_t gn_conv3x3_gn_supported(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
-  return B > 0 && H > 0 && W > 0 && H % CG_TH == 0 && W % CG_TW == 0 && Cin >= CG_CG && Cin % CG_CG == 0 && Cout % 128 == 0 &&
+  return B > 0 && H > 0 && W > 0 && H % CG_TH == 0 && W % CG_TW == 0 && Cin >= CG_CG && Cin % CG_CG == 0 && (Cout % 128 == 0 || (Cout % 8 == 0 && Cout > 0 && Cout <= 32)) &&
                  (int64_t)B * H * W * Cin * 2 < 0xFFFFFF00ll && (int64_t)Cout * 9 * Cin * 2 < 0xFFFFFF00ll
              ? 1 : 0;
 }
@@ -272,7 +287,7 @@ extern "C" int32_t gn_conv3x3_gn_supported(int32_t B, int32_t H, int32_t W, int3
 extern "C" int32_t gn_conv3x3_gn(gn_ctx* ctx, const gn_conv3x3_gn_desc* d) {
   GN_REQUIRE(ctx && d && d->x && d->w && d->out, "gn_conv3x3_gn: null ctx / x / w / out");
   GN_REQUIRE(gn_conv3x3_gn_supported(d->B, d->H, d->W, d->Cin, d->Cout),
-             "gn_conv3x3_gn: needs H %% 8 == 0, W %% 16 == 0, Cin %% 128 == 0, Cout %% 128 == 0 (got %dx%d, %d -> %d); use gn_gemm otherwise", d->H, d->W,
+             "gn_conv3x3_gn: needs H %% 8 == 0, W %% 16 == 0, Cin %% 128 == 0, Cout %% 128 == 0 or Cout in {8, 16, 24, 32} (got %dx%d, %d -> %d); use gn_gemm otherwise", d->H, d->W,
              d->Cin, d->Cout);
   GN_REQUIRE(((uintptr_t)d->x & 15) == 0 && ((uintptr_t)d->w & 15) == 0 && ((uintptr_t)d->out & 15) == 0 && d->ldo % 8 == 0 && d->ldo >= d->Cout,
              "gn_conv3x3_gn: x / w / out must be 16-byte aligned, ldo a multiple of 8 and >= Cout");
@@ -283,10 +298,13 @@ extern "C" int32_t gn_conv3x3_gn(gn_ctx* ctx, const gn_conv3x3_gn_desc* d) {
   p.out = (f16*)d->out; p.ldr = d->ldr; p.ldo = d->ldo;
   p.B = d->B; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Cout = d->Cout; p.silu = d->act == GN_ACT_SILU ? 1 : 0;
   GN_REQUIRE(d->act == GN_ACT_NONE || d->act == GN_ACT_SILU, "gn_conv3x3_gn: act (applied after the affine, before the conv) must be NONE or SILU");
-  p.tiles_x = d->W / CG_TW; p.tiles_y = d->H / CG_TH; p.tiles_n = d->Cout / 128;
+  const bool narrow = d->Cout % 128 != 0;
+  GN_REQUIRE(!narrow || !d->residual, "gn_conv3x3_gn: the narrow (Cout <= 32) variant takes no residual");
+  p.tiles_x = d->W / CG_TW; p.tiles_y = d->H / CG_TH; p.tiles_n = narrow ? 1 : d->Cout / 128;
   p.x_bytes = (unsigned)((uint64_t)d->B * d->H * d->W * d->Cin * 2); p.w_bytes = (unsigned)((uint64_t)d->Cout * 9 * d->Cin * 2);
   const long nblocks = (long)d->B * p.tiles_x * p.tiles_y * p.tiles_n;
-  hipLaunchKernelGGL(conv3x3_gn_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, p);
+  if (narrow) hipLaunchKernelGGL(conv3x3_gn_narrow_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, p);
+  else hipLaunchKernelGGL(conv3x3_gn_kernel, dim3((unsigned)nblocks), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

@@ -364,8 +364,14 @@ def emit_vae_decode(E: Engine, W, cfg, z8: torch.Tensor) -> torch.Tensor:
             if i != n - 1:
                 p = f"decoder.up_blocks.{i}.upsamplers.0.conv"
                 h = _emit_upsample_conv(E, W, p, h)
+        cw = W["decoder.conv_out.weight"]
+        if (getattr(E, "conv_gn", True) and h.shape[1] * h.shape[2] >= getattr(E, "conv_gn_min_hw", 0) and cw.shape[1] == 9 * h.shape[-1]
+                and E.conv2d_gn_supported(h, cw.shape[0])):
+            # conv_norm_out + SiLU on the conv's LDS patch (the narrow variant of csrc/conv_gn.hip: 3 of 8 padded output channels)
+            st = E.groupnorm_stats(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, _vae_eps(W), name="norm_out_s")
+            return E.conv2d_gn(h, st, cw, W["decoder.conv_out.bias"], name="conv_out")
         h = E.groupnorm(h, W["decoder.conv_norm_out.weight"], W["decoder.conv_norm_out.bias"], G, _vae_eps(W), act=ACT_SILU, name="norm_out")
-        return E.conv2d(h, W["decoder.conv_out.weight"], W["decoder.conv_out.bias"], name="conv_out")
+        return E.conv2d(h, cw, W["decoder.conv_out.bias"], name="conv_out")
 
 
 def emit_vae_encode_moments(E: Engine, W, cfg, x8: torch.Tensor) -> torch.Tensor:

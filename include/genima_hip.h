@@ -263,7 +263,8 @@ int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d);
  * norm2 -> SiLU -> conv2 (+ shortcut) without the normalised tensor's round trip through HBM (the VAE decoder inside `self.pipe(...)`,
  * controller/agent/sd_controlnet_agent.py:67-76).  A workgroup keeps the 10 x 18 input patch of an 8 x 16 output tile in LDS, normalises it
  * there (the arithmetic of gn_groupnorm_fwd's apply pass: the MFMA sees the same f16 values) and reads all nine taps from it.
- * Needs H % 8 == 0, W % 16 == 0, Cin % 128 == 0, Cout % 128 == 0 (gn_conv3x3_gn_supported). */
+ * Needs H % 8 == 0, W % 16 == 0, Cin % 128 == 0, and Cout % 128 == 0 or -- the narrow variant, no residual: the VAE's conv_norm_out -> SiLU ->
+ * conv_out with its 3 (padded 8) output channels -- Cout in {8, 16, 24, 32} (gn_conv3x3_gn_supported). */
 typedef struct gn_conv3x3_gn_desc {
   const void* x;          /* NHWC f16 [B, H, W, Cin]: the RAW tensor the GroupNorm reads */
   const void* scsh;       /* f32 [B][Cin][2] (scale, shift) from the statistics-only GroupNorm call, or NULL: plain convolution */

@@ -29,7 +29,8 @@ def _case(B, H, W, Cin, Cout, seed):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout,residual", [(1, 8, 16, 128, 128, False), (2, 16, 32, 128, 128, True), (1, 24, 48, 256, 128, True),
-                                                     (2, 16, 16, 128, 256, False), (1, 8, 32, 384, 256, True)])
+                                                     (2, 16, 16, 128, 256, False), (1, 8, 32, 384, 256, True),
+                                                     (2, 16, 32, 128, 8, False), (1, 8, 16, 256, 24, False)])  # the narrow variant (VAE conv_out)
 def test_conv3x3_gn_vs_torch_and_unfused(engine, B, H, W, Cin, Cout, residual):
     x, w, bias, gamma, beta, res = _case(B, H, W, Cin, Cout, seed=H + Cin)
     G, eps = 32, 1e-6

@@ -24,7 +24,7 @@ def timeit(fn, iters=10):
     return E.event_elapsed_ms(a, e) / iters * 1000.0
 
 
-for H, Cin, Cout in [tuple(int(v) for v in t.split("x")) for t in os.environ.get("SHAPES", "512x128x128,512x256x128,256x256x256,256x512x256,128x512x512,64x512x512,64x384x384").split(",")]:
+for H, Cin, Cout in [tuple(int(v) for v in t.split("x")) for t in os.environ.get("SHAPES", "512x128x8,512x128x128,512x256x128,256x256x256,256x512x256,128x512x512,64x512x512,64x384x384").split(",")]:
     x = torch.randn(B, H, H, Cin, device="cuda").half()
     w = (torch.randn(Cout, 9 * Cin, device="cuda") * (9 * Cin) ** -0.5).half()
     bias, gamma, beta = torch.randn(Cout, device="cuda").half(), torch.ones(Cin, device="cuda").half(), torch.zeros(Cin, device="cuda").half()
