@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from util import assert_close, q16, randn_h
+from util import assert_close, q16, randn_h, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -132,14 +132,34 @@ def test_conv2d_asymmetric_pad(engine):
 
 
 # ---------------------------------------------------------------------------------------------------- attention
-def ref_attention(q, k, v, heads, causal=False):
+def ref_attention(q, k, v, heads, causal=False, f16_storage=False):
+    """fp32 attention of the f16-rounded inputs; f16_storage: what ANY f16-storage kernel computes -- the probabilities (relative to the
+    row maximum) rounded to f16 before P.V, the row sum taken of those rounded values, the output rounded to f16."""
     B, Nq, C = q.shape
     d = C // heads
     qh, kh, vh = (t.view(B, -1, heads, d).transpose(1, 2) for t in (q, k, v))
     s = qh @ kh.transpose(-1, -2) * d ** -0.5
     if causal:
         s = s + torch.full((Nq, k.shape[1]), float("-inf")).triu(1)
+    if f16_storage:
+        pr = q16(torch.exp(s - s.amax(-1, keepdim=True)))
+        return q16((pr @ vh) / pr.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, Nq, C)
     return (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Nq, C)
+
+
+def assert_attention(o, q, k, v, heads, causal=False, what="", factor=1.35):
+    """The attention bar.  BASELINE north_star's 1e-3 (relative, fp16 tolerance) is asserted OUTRIGHT: rel-L2 from the fp32 softmax(QK^T)V of
+    the same f16 inputs < 1e-3.  On top of it the kernel may not be worse than `factor` x what ANY f16-storage attention costs (the
+    restatement above: P and O rounded to f16), + 5e-5.  Measured on MI355X (printed with -s): 2.7e-4 .. 3.6e-4 against 2.3e-4 .. 2.8e-4 for
+    the restatement = 1.21 .. 1.29x on all plain shapes (the kernel also rounds Q * scale * log2 e to f16: the MFMA then yields exponents);
+    rows that re-reference their softmax mid-sequence (spiked keys, the stream kernel's fallback) reach 1.7 .. 2.1x, still <= 4.1e-4."""
+    q, k, v = (t.float().cpu() for t in (q, k, v))
+    r32, r16 = ref_attention(q, k, v, heads, causal), ref_attention(q, k, v, heads, causal, f16_storage=True)
+    e, e16 = rel_l2(o.float().cpu(), r32), rel_l2(r16, r32)
+    print(f"attention {what}: rel-L2 {e:.3e} (f16-storage restatement {e16:.3e}, ratio {e / max(e16, 1e-12):.2f})")
+    assert_close(o, r32, rel=1e-3, what=what)  # shape, finiteness, rel-L2 < 1e-3, the elementwise bound
+    assert e <= factor * e16 + 5e-5, f"{what}: {e:.3e} vs f16-storage {e16:.3e}"
+    return e
 
 
 @pytest.mark.parametrize("B,heads,Nq,Nk,D,causal", [
@@ -152,8 +172,7 @@ def test_attention(engine, B, heads, Nq, Nk, D, causal):
     vt = torch.full((B, C, Np), float("nan"), dtype=torch.float16, device="cuda")  # pad columns are never trusted
     vt[:, :, :Nk] = v.transpose(1, 2)
     o = engine.attention(q, k, vt, heads, Nk=Nk, causal=causal)
-    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, causal)
-    assert_close(o, ref, rel=2e-3, what=f"attention {B}x{heads}x{Nq}x{Nk}x{D} causal={causal}")
+    assert_attention(o, q, k, v, heads, causal, what=f"{B}x{heads}x{Nq}x{Nk}x{D} causal={causal}")
 
 
 def test_attention_strided_qk_and_spike(engine):
@@ -165,8 +184,7 @@ def test_attention_strided_qk_and_spike(engine):
     v = randn_h(B, N, C, seed=3)
     vt = v.transpose(1, 2).contiguous()
     o = engine.attention(qk[:, :, :C], qk[:, :, C:], vt, heads)
-    ref = ref_attention(qk[:, :, :C].float().cpu(), qk[:, :, C:].float().cpu(), v.float().cpu(), heads)
-    assert_close(o, ref, rel=2e-3, what="strided/spiked attention")
+    assert_attention(o, qk[:, :, :C], qk[:, :, C:], v, heads, what="strided/spiked", factor=2.0)
 
 
 @pytest.mark.parametrize("where", ["far_tile", "one_row", "every_tile"])
@@ -192,13 +210,31 @@ def test_attention_stream_kernel_fallback(engine, where):
     vt = v.transpose(1, 2).contiguous()
     lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
     o = engine.attention(q, k, vt, heads, lse=lse)
-    ref = ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads)
-    assert_close(o, ref, rel=2e-3, what=f"stream-kernel fallback ({where})")
+    assert_attention(o, q, k, v, heads, what=f"stream-kernel fallback ({where})", factor=2.5)
     s = (q.float().view(B, N, heads, D).transpose(1, 2) @ k.float().view(B, N, heads, D).transpose(1, 2).transpose(-1, -2)) * D ** -0.5
     ref_lse = (torch.logsumexp(s, -1) * 1.4426950408889634).cpu()
     assert float((lse.cpu() - ref_lse).abs().max()) < 2e-2, "lse after the fallback"
     o2 = engine.attention(q, k, v, heads, v_rowmajor=True)  # the generic kernel on the same problem
     assert_close(o, o2.float(), rel=1e-3, what=f"stream kernel vs generic kernel ({where})")
+
+
+@pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 5, 4096, 77), (1, 10, 1000, 77), (2, 5, 16421, 77), (1, 3, 37, 65), (2, 2, 300, 96), (1, 20, 64, 80)])
+def test_cross_attention_short_key_set(engine, B, heads, Nq, Nk):
+    """The prompt cross-attention of every BasicTransformerBlock (64 < Nk <= 96 keys, D = 64, V^T given): ragged row counts, q as a column
+    slice, NaN in V^T's pad columns, the lse output; against fp32 and against the row-major-V form of the same problem.  (Written for the
+    register-resident key-set kernel of tools/probes/attn_cross_experiment.patch, which did not beat the generic kernel and is not built.)"""
+    C = heads * 64
+    qq, k, v = randn_h(B, Nq, C + 64, seed=31), randn_h(B, Nk, C, seed=32), randn_h(B, Nk, C, seed=33)
+    q = qq[:, :, 64:]  # row stride C + 64
+    vt = torch.full((B, C, 128), float("nan"), dtype=torch.float16, device="cuda")
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    lse = torch.empty(B, heads, Nq, dtype=torch.float32, device="cuda")
+    o = engine.attention(q, k, vt, heads, Nk=Nk, lse=lse)
+    assert_attention(o, q, k, v, heads, what=f"cross {B}x{heads}x{Nq}x{Nk}")
+    lse2 = torch.empty_like(lse)
+    o2 = engine.attention(q, k, v, heads, Nk=Nk, v_rowmajor=True, lse=lse2)
+    assert_close(o, o2.float(), rel=1e-3, what="V^T form vs row-major V")
+    assert float((lse - lse2).abs().max()) < 2e-3, "lse (log2 units)"
 
 
 @pytest.mark.parametrize("heads,Nq,Nk,causal", [(5, 512, 512, False), (4, 200, 77, False), (2, 77, 77, True)])
@@ -217,7 +253,7 @@ def test_attention_rowmajor_v(engine, heads, Nq, Nk, causal):
         assert torch.equal(o1, o2)  # one kernel, two ways to its V fragments
     else:  # the V^T form of these shapes runs the branch-free kernel (attention_stream.hip): another summation order
         assert_close(o1, o2.float(), rel=1e-3, what="V^T (stream kernel) vs row-major V (generic kernel)")
-    assert_close(o2, ref_attention(q.float().cpu(), k.float().cpu(), v.float().cpu(), heads, causal=causal), rel=2e-3, what="row-major V attention")
+    assert_attention(o2, q, k, v, heads, causal, what="row-major V")
 
 
 # ---------------------------------------------------------------------------------------------------- norms

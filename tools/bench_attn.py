@@ -23,7 +23,7 @@ def timeit(fn, iters=20):
 
 
 for heads, nq, nk, causal in [(5, 4096, 4096, False), (10, 1024, 1024, False), (20, 256, 256, False), (20, 64, 64, False),
-                              (5, 4096, 77, False), (16, 77, 77, True)]:
+                              (5, 4096, 77, False), (10, 1024, 77, False), (20, 256, 77, False), (16, 77, 77, True)]:
     C = heads * 64
     qk = (torch.randn(B, nq, 2 * C, device="cuda")).half()
     k = qk[:, :, C:] if nk == nq else torch.randn(B, nk, C, device="cuda").half()

@@ -51,3 +51,18 @@ for s, e, n in sel:
 print("idle by gap length (5 us bins, last = >= 45 us), ms/step:", {k * 5: round(v / 1e6 / steps, 2) for k, v in sorted(hist.items())})
 for (a, b), (c, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{t/1e6/steps:7.3f} ms/step idle  {c/steps:6.1f} gaps/step  avg {t/c/1e3:7.1f} us   {a} -> {b}")
+# CONTEXT=<kernel substring>: the launches around the last occurrence of that kernel (start / end relative to it, queue) -- what the GPU was
+# doing across one particular seam
+import os
+ctx = os.environ.get("CONTEXT")
+if ctx:
+    full = []
+    for p in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            full.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r.get("Queue_Id", "?"), r["Kernel_Name"]))
+    full.sort()
+    idx = max(i for i, r in enumerate(full) if ctx in r[3])
+    base = full[idx][0]
+    for s, e, q, n in full[max(0, idx - 14):idx + 6]:
+        n = n.replace("(anonymous namespace)::", ""); n = re.sub(r"^void ", "", n); n = re.sub(r"\(.*", "", n)
+        print(f"  start {(s - base) / 1e3:9.1f} us  end {(e - base) / 1e3:9.1f} us  queue {q:>3}  {n[:90]}")
