@@ -223,6 +223,8 @@ SIGNATURES = {
     "gn_program_add_softmax_rows": (_I32, [_P, _P, _I64, _I32, _I32, _F]),
     "gn_program_add_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_program_num_ops": (_I64, [_P]),
+    "gn_program_get_gemm": (_I32, [_P, _I64, _P]),
+    "gn_program_set_gemm_plan": (_I32, [_P, _I64, _I32, _I32, _P]),
     "gn_program_run": (_I32, [_P, _I64, _I64]),
     "gn_program_capture": (_I32, [_P]),
     "gn_program_launch": (_I32, [_P]),

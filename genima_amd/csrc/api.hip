@@ -287,6 +287,24 @@ int32_t gn_program_add_main(gn_program* p) { return push_generic(p, OP_MAIN, nul
 int32_t gn_program_add_join(gn_program* p) { return push_generic(p, OP_JOIN, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0.f, 0.f); }
 int64_t gn_program_num_ops(const gn_program* p) { return p ? (int64_t)p->ops.size() : 0; }
 
+// in-call tile tuning (genima_amd/incall_tune.py): read back a recorded gn_gemm op, and replace its tile / K split (+ the workspace its
+// split-K partial sums use).  A tile never changes the summation order along K; a K split does (as documented on gn_gemm_desc).
+int32_t gn_program_get_gemm(const gn_program* p, int64_t op, gn_gemm_desc* out) {
+  GN_REQUIRE(p && out && op >= 0 && op < (int64_t)p->ops.size(), "gn_program_get_gemm: bad argument");
+  if (p->ops[(size_t)op].type != OP_GEMM) return GN_ERR_INVALID;  // (no error text: callers probe every op)
+  *out = p->ops[(size_t)op].gemm;
+  return GN_OK;
+}
+int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_t splitk, void* workspace) {
+  GN_REQUIRE(p && op >= 0 && op < (int64_t)p->ops.size() && p->ops[(size_t)op].type == OP_GEMM, "gn_program_set_gemm_plan: op %ld is not a gn_gemm", (long)op);
+  GN_REQUIRE(!p->exec, "gn_program_set_gemm_plan: the program is captured (re-capture after tuning)");
+  gn_gemm_desc& d = p->ops[(size_t)op].gemm;
+  d.tile = tile; d.splitk = splitk;
+  if (workspace) d.workspace = workspace;
+  GN_REQUIRE(gn_gemm_workspace_bytes(&d) == 0 || d.workspace, "gn_program_set_gemm_plan: this plan splits K and needs a workspace");
+  return GN_OK;
+}
+
 static int32_t ensure_side_stream(gn_program* p) {
   if (!p->side) {
     GN_HIP(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));

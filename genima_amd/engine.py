@@ -344,20 +344,20 @@ class Engine:
         """Ops recorded from here run on the program's side stream (after everything recorded so far)."""
         if self.record:
             check(self.lib.gn_program_add_fork(self._prog), "gn_program_add_fork")
-            self.meta.append(dict(kind="stream", flops=0.0, bytes=0.0, shape=()))  # meta stays index-aligned with the op list
+            self.meta.append(dict(kind="stream", op="fork", flops=0.0, bytes=0.0, shape=()))  # meta stays index-aligned with the op list
             self._on_side = True
 
     def main(self):
         """Back to the main stream; the side stream keeps running concurrently until join()."""
         if self.record:
             check(self.lib.gn_program_add_main(self._prog), "gn_program_add_main")
-            self.meta.append(dict(kind="stream", flops=0.0, bytes=0.0, shape=()))
+            self.meta.append(dict(kind="stream", op="main", flops=0.0, bytes=0.0, shape=()))
             self._on_side = False
 
     def join(self):
         if self.record:
             check(self.lib.gn_program_add_join(self._prog), "gn_program_add_join")
-            self.meta.append(dict(kind="stream", flops=0.0, bytes=0.0, shape=()))
+            self.meta.append(dict(kind="stream", op="join", flops=0.0, bytes=0.0, shape=()))
             self._on_side = False
 
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,

@@ -501,6 +501,13 @@ int32_t gn_program_add_copy4d(gn_program* p, const void* in, void* out, const in
                               const int64_t* out_strides, int32_t L);
 int32_t gn_program_add_argmax_rows_i32(gn_program* p, const int32_t* x, int32_t* out, int32_t rows, int32_t cols);
 int64_t gn_program_num_ops(const gn_program* p);
+/* In-call tile tuning.  The reference has no counterpart (diffusers leaves kernel selection to cuDNN's own autotuner inside
+ * `self.pipe(...)`, controller/agent/sd_controlnet_agent.py:67-76); here the tile / K split of a recorded gn_gemm op can be read back and
+ * replaced, so that candidates are timed INSIDE the recorded call (cold operands, the neighbours' cache state) instead of in an isolated
+ * hot loop.  get: GN_ERR_INVALID when op is not a gn_gemm.  set: `workspace` (may be NULL when the plan does not split K) replaces the
+ * op's split-K scratch pointer; refused on a captured program. */
+int32_t gn_program_get_gemm(const gn_program* p, int64_t op, gn_gemm_desc* out);
+int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_t splitk, void* workspace);
 /* first..last (exclusive) op range; last < 0 = to the end */
 int32_t gn_program_run(gn_program* p, int64_t first, int64_t last);
 int32_t gn_program_capture(gn_program* p);   /* capture the whole program into a hipGraph on the ctx stream */
