@@ -55,7 +55,7 @@ def gemm_ops(E):
 def valid_plans(d):
     tiles = list(GEGLU_TILES) if d.act == ACT_GEGLU else list(range(1, Engine.N_TILE_CFGS + 1))
     if d.ln_c1:
-        tiles = [t for t in tiles if t >= 7 and t != 15]
+        tiles = [t for t in tiles if t >= 7 and t not in (15, 24)]
     return tiles
 
 
