@@ -451,6 +451,8 @@ def main():
         extra = []
         for k in sorted(agg, key=lambda k: -agg[k]["ms"]):
             a = agg[k]
+            if k == "stream":  # fork / main / join markers of the two-stream program: no launch, no bytes -- not a roofline row
+                continue
             row = {"kernel": k, "ms_per_call": a["ms"], "launches": a["launches"]}
             if a["flops"] > 0:
                 tf = a["flops"] / (a["ms"] * 1e-3) / 1e12

@@ -361,19 +361,24 @@ def elastic_displacement(H: int, W: int, alpha: float = 80.0, sigma: float = 10.
     """torchvision v2.ElasticTransform._get_params: per axis, uniform [-1, 1) noise, Gaussian blur (kernel int(8 sigma + 1) made odd,
     reflect padding) and a scale of alpha / size -- in the normalised [-1, 1] grid units, converted here to pixels (x (size - 1) / 2).
     Host work on one [H, W] field per call (the transform is called on the whole batch: one field for every image)."""
+    import numpy as np
+    from numpy.lib.stride_tricks import sliding_window_view
+
     k = int(8 * sigma + 1)
     k += (k % 2 == 0)
     half = (k - 1) * 0.5
-    pdf = torch.exp(-0.5 * (torch.linspace(-half, half, k) / sigma) ** 2)
-    ker = (pdf / pdf.sum()).double()
+    pdf = torch.exp(-0.5 * (torch.linspace(-half, half, k) / sigma) ** 2)  # (torchvision builds the kernel in f32)
+    ker = (pdf / pdf.sum()).double().numpy()
     out = []
     for size, n in ((W, (H, W)), (H, (H, W))):
-        f = (torch.rand([1, 1] + list(n), generator=generator) * 2 - 1).double()
+        # the draw stays torch's (the generator's stream is part of the recipe); the separable blur of ONE [H, W] field is host arithmetic
+        # in f64 -- plain numpy: a sliding window along each axis against the kernel, no tensor-library convolution in the package
+        f = (torch.rand([1, 1] + list(n), generator=generator) * 2 - 1).double().numpy()[0, 0]
         pad = k // 2
-        f = torch.nn.functional.pad(f, (pad, pad, pad, pad), mode="reflect")
-        f = torch.nn.functional.conv2d(f, ker.view(1, 1, 1, k))
-        f = torch.nn.functional.conv2d(f, ker.view(1, 1, k, 1))
-        out.append((f[0, 0] * alpha / size) * (size - 1) * 0.5)
+        f = np.pad(f, pad, mode="reflect")
+        f = sliding_window_view(f, k, axis=1) @ ker   # along W
+        f = sliding_window_view(f, k, axis=0) @ ker   # along H
+        out.append(torch.from_numpy((f * alpha / size) * (size - 1) * 0.5))
     return torch.stack(out, dim=-1).float().contiguous()  # [H, W, 2] = (dx, dy) in pixels
 
 
