@@ -504,8 +504,8 @@ int64_t gn_program_num_ops(const gn_program* p);
 /* In-call tile tuning.  The reference has no counterpart (diffusers leaves kernel selection to cuDNN's own autotuner inside
  * `self.pipe(...)`, controller/agent/sd_controlnet_agent.py:67-76); here the tile / K split of a recorded gn_gemm op can be read back and
  * replaced, so that candidates are timed INSIDE the recorded call (cold operands, the neighbours' cache state) instead of in an isolated
- * hot loop.  get: GN_ERR_INVALID when op is not a gn_gemm.  set: `workspace` (may be NULL when the plan does not split K) replaces the
- * op's split-K scratch pointer; refused on a captured program. */
+ * hot loop.  get: GN_ERR_INVALID when op is not a gn_gemm.  set: `workspace` replaces the op's split-K scratch pointer (NULL keeps the
+ * recorded one; a plan that splits K with neither is refused); refused on a captured program. */
 int32_t gn_program_get_gemm(const gn_program* p, int64_t op, gn_gemm_desc* out);
 int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_t splitk, void* workspace);
 /* first..last (exclusive) op range; last < 0 = to the end */

@@ -1,0 +1,53 @@
+"""-m gpu: gn_program_get_gemm / gn_program_set_gemm_plan -- the in-call tuner's two entry points (tools/incall_tune.py).  A recorded
+gn_gemm op can be read back and its tile / K split replaced: a tile never changes the result (K is walked alike), a K split changes only
+the summation order."""
+import ctypes as C
+
+import pytest
+import torch
+
+from genima_amd._lib import GemmDesc
+from genima_amd.engine import Engine
+from util import assert_close, randn_h
+
+pytestmark = pytest.mark.gpu
+
+
+def test_recorded_gemm_plan_can_be_read_back_and_replaced():
+    E = Engine("cuda:0", record=True)
+    x, w, b = randn_h(512, 1280), randn_h(640, 1280, scale=0.03), randn_h(640)
+    y = E.linear(x, w, b, name="lin")
+    g = E.conv2d(randn_h(2, 16, 16, 128), randn_h(128, 9 * 128, scale=0.03), randn_h(128), name="conv")
+    n = E.num_ops
+    descs = []
+    for i in range(n):
+        d = GemmDesc()
+        assert E.lib.gn_program_get_gemm(E._prog, i, C.byref(d)) == 0
+        descs.append(d)
+    assert (descs[0].M, descs[0].N, descs[0].K, descs[0].conv) == (512, 640, 1280, 0)
+    assert (descs[1].M, descs[1].N, descs[1].K, descs[1].conv) == (512, 128, 1152, 1)
+    E.run()
+    E.synchronize()
+    ref = x.float() @ w.float().t() + b.float()
+    assert_close(y, ref, 1e-3)
+    g_rec = g.clone()  # (the recorded plan of the conv may split K: its sums differ from the unsplit ones in the last bit)
+    # every block tile gives the same bits (no K split: the workspace stays untouched)
+    y0 = g0 = None
+    for tile in (10, 9, 11, 17, 18, 23):
+        for i in range(n):
+            assert E.lib.gn_program_set_gemm_plan(E._prog, i, tile, 1, None) == 0
+        y.zero_(); g.zero_()
+        E.run()
+        E.synchronize()
+        if y0 is None:
+            y0, g0 = y.clone(), g.clone()
+            assert_close(g0, g_rec, 1e-3)
+        assert torch.equal(y, y0) and torch.equal(g, g0), tile
+    # a K split needs a workspace, changes the summation order only
+    ws = torch.empty(4 * 512 * 640, dtype=torch.float32, device="cuda")
+    assert E.lib.gn_program_set_gemm_plan(E._prog, 0, 18, 4, C.c_void_p(ws.data_ptr())) == 0
+    y.zero_()
+    E.run()
+    E.synchronize()
+    assert_close(y, ref, 1e-3)
+    assert E.lib.gn_program_get_gemm(E._prog, n, C.byref(GemmDesc())) != 0           # out of range
