@@ -263,8 +263,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   const int lr = lane >> 3;
   const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
   int kcur = kbeg + chunk * 8;
+  int kt0 = kbeg;  // wave-uniform K origin of the next tile to stage (k_append: which segment it lies in)
 
-  const int Cin = p.C1 + p.C2;
+  const int Cin = p.kapp ? p.C1 : p.C1 + p.C2;  // channels under each filter tap (k_append: the second source is not under the taps)
   const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
   int iy0[GA], ix0[GA], pbase[GA], pix[GA];
   unsigned aoff[GA];  // dense: byte offset of the row start (kOOB if the row is out of range)
@@ -321,22 +322,37 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a3 ? p.a3 : p.a), 0, (int)p.a3_bytes, 0x00020000);  // k_append: second appended source
 
   auto dma_tile = [&](int buf) {
     const bool kok = kcur < kend;
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* Bs = As + A_BYTES;
     if constexpr (CONV) {
-      const bool first = cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
-      const int cs = first ? p.C1 : p.C2;
-      const int co = first ? cc : cc - p.C1;
+      if (p.kapp && kt0 >= p.kapp_k0) {  // wave-uniform: the appended 1x1 segment (C1 % 64 == 0: a K tile lies on one side)
+        int cs, cbase;
+        const bool s2 = kapp_src(p, kt0, cs, cbase);
+        const int co = kcur - cbase;
 #pragma unroll
-      for (int i = 0; i < GA; ++i) {
-        unsigned voff = (kok && pix[i] >= 0) ? (unsigned)(((long)pix[i] * cs + co) * 2) : kOOB;
-        GN_PIN(voff);
-        lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
-        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+        for (int i = 0; i < GA; ++i) {
+          unsigned voff = kok ? kapp_voff(p, iy0[i], ix0[i], pbase[i], cs, co) : kOOB;
+          GN_PIN(voff);
+          lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
+          if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a3, dst, 16, voff, 0, 0, 0);
+        }
+      } else {
+        const bool first = p.kapp || cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
+        const int cs = first ? p.C1 : p.C2;
+        const int co = first ? cc : cc - p.C1;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+          unsigned voff = (kok && pix[i] >= 0) ? (unsigned)(((long)pix[i] * cs + co) * 2) : kOOB;
+          GN_PIN(voff);
+          lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
+          if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -353,6 +369,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
     kcur += BK;
+    kt0 += BK;
     if constexpr (CONV) {
       cu += BK;
       while (cu >= Cin) cu -= Cin;
@@ -670,7 +687,7 @@ bool dma_eligible(const gn_gemm_desc* d) {
   const DmaBytes b = dma_bytes(d);
   const uint64_t lim = 0xFFFFFF00ull;
   if (b.a >= lim || b.a2 >= lim || b.w >= lim) return false;
-  if (d->conv && d->a2 && (d->C1 % 64 != 0 || (d->C1 + d->C2) % 64 != 0)) return false;  // a K tile must not straddle the concat
+  if (d->conv && d->a2 && !d->k_append && (d->C1 % 64 != 0 || (d->C1 + d->C2) % 64 != 0)) return false;  // a K tile must not straddle the concat
   return true;
 }
 
@@ -712,6 +729,10 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (geglu && !kCfg[best].geglu) best = 1;
   if (d->ln_c1) {  // LayerNorm fold: the LDS-DMA kernels (two-stage and ring) carry it
     static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22};
+    best = to_dma[best];
+  }
+  if (d->k_append && !kCfg[best].dma) {  // the appended segment lives in the LDS-DMA loaders
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22};
     best = to_dma[best];
   }
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
@@ -828,7 +849,14 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   if (d->conv) {
     GN_REQUIRE(d->C1 % 8 == 0 && d->C2 % 8 == 0 && d->C1 > 0, "gn_gemm(conv): C1/C2 (%d/%d) must be multiples of 8", d->C1, d->C2);
     GN_REQUIRE((d->C2 == 0) == (d->a2 == nullptr), "gn_gemm(conv): a2 and C2 must be given together");
-    GN_REQUIRE(d->K == (int64_t)d->KH * d->KW * (d->C1 + d->C2), "gn_gemm(conv): K != KH*KW*(C1+C2)");
+    if (d->k_append) {
+      GN_REQUIRE(d->K == (int64_t)d->KH * d->KW * d->C1 + d->C2 + d->C3 && d->a2 && d->C2 > 0, "gn_gemm(conv, k_append): K != KH*KW*C1 + C2 + C3");
+      GN_REQUIRE((d->C3 == 0) == (d->a3 == nullptr) && d->C3 % 8 == 0 && (d->C3 == 0 || d->C2 % 64 == 0), "gn_gemm(conv, k_append): a3 / C3 together, C3 %% 8 == 0, C2 %% 64 == 0 in front of a3");
+      GN_REQUIRE(d->stride == 1 && !d->upsample2x && d->C1 % 64 == 0 && d->Ho == d->H && d->Wo == d->W && d->batch <= 1 && !d->up_phases,
+                 "gn_gemm(conv, k_append): a stride-1 same-size conv with C1 %% 64 == 0 (the 1x1 segment reads the output pixel of the second source)");
+      GN_REQUIRE(dma_eligible(d), "gn_gemm(conv, k_append): operands must fit 32-bit buffer offsets (LDS-DMA loaders)");
+    } else
+      GN_REQUIRE(d->K == (int64_t)d->KH * d->KW * (d->C1 + d->C2), "gn_gemm(conv): K != KH*KW*(C1+C2)");
     GN_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "gn_gemm(conv): M != B*Ho*Wo");
     GN_REQUIRE(d->stride >= 1 && d->KH >= 1 && d->KW >= 1 && d->H > 0 && d->W > 0, "gn_gemm(conv): bad geometry");
     GN_REQUIRE((int64_t)d->B * d->H * d->W < (1ll << 31), "gn_gemm(conv): source tensor has too many pixels");
@@ -854,6 +882,10 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     p.cm_tiles = cm_env >= 0 ? cm_env : (w_el > 2 * a_el && d->batch <= 1 ? 1 : 0);
   }
   p.tiles_m = (int)cdiv64(d->M, pl.bm); p.tiles_n = (int)cdiv64(d->N, pl.bn);
+  p.kapp = d->k_append ? 1 : 0;
+  p.kapp_k0 = d->KH * d->KW * d->C1;
+  p.a3 = d->k_append ? (const f16*)d->a3 : nullptr; p.C3 = d->k_append ? d->C3 : 0;
+  p.a3_bytes = p.a3 ? (unsigned)((uint64_t)d->B * d->H * d->W * d->C3 * 2) : p.a_bytes;
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
 
   if (d->fp8) {

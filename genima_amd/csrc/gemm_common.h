@@ -42,7 +42,26 @@ struct GemmParams {
   int up_ph;                             // 1: blockIdx.z = output phase 2 dy + dx of an upsampling conv (batch_offset below)
   int orw;                               // row-major f16 output with a two-level row pitch: row m lives at (m / orw) * ldo_hi + (m % orw) * ldo
   long ldo_hi;                           // (one phase of a nearest-2x upsampling conv writes every other pixel of every other image row); 0 = m * ldo
+  int kapp, kapp_k0;                     // conv with a 1x1 conv APPENDED along K (gn_gemm_desc.k_append): K tiles from kapp_k0 = KH * KW * C1 on read
+                                         // the output pixel of the appended sources a2 (C2 channels), then a3 (C3) -- the LDS-DMA kernels' loaders
+  const f16* a3; int C3; unsigned a3_bytes;
 };
+
+// the appended 1x1 segment of a k_append conv: source offset of staged row i for the K tile whose lane offset inside the segment is `co`
+// (iy0 / ix0 / pbase as the conv loaders keep them: the row's top-left tap coordinate and image base; rows >= M carry -(1 << 28))
+// cs / co: channel count of the source this K tile lies in and the lane's channel inside it (kapp_src below)
+__device__ __forceinline__ unsigned kapp_voff(const GemmParams& p, int iy0, int ix0, int pbase, int cs, int co) {
+  const int cy = iy0 + p.pad_t, cx = ix0 + p.pad_l;  // stride 1: the output pixel itself
+  return iy0 > -(1 << 27) ? (unsigned)(((long)(pbase + cy * p.W + cx) * cs + co) * 2) : 0xFFFFFFF0u;
+}
+// which appended source the K tile at (wave-uniform) origin kt0 reads: a2 for the first C2 channels of the segment, a3 behind it (C2 % 64 == 0
+// when there are two).  -> true = a2
+__device__ __forceinline__ bool kapp_src(const GemmParams& p, int kt0, int& cs, int& cbase) {
+  const bool s2 = kt0 - p.kapp_k0 < p.C2;
+  cs = s2 ? p.C2 : p.C3;
+  cbase = s2 ? p.kapp_k0 : p.kapp_k0 + p.C2;
+  return s2;
+}
 
 // element offset of output row m (row-major f16 outputs)
 __device__ __forceinline__ long out_row_off(const GemmParams& p, int m) {

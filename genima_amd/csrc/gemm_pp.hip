@@ -57,7 +57,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
   const int kl = chunk * 8;  // this lane's K offset inside a tile
 
-  const int Cin = p.C1 + p.C2;
+  const int Cin = p.kapp ? p.C1 : p.C1 + p.C2;  // channels under each filter tap (k_append: the second source is not under the taps)
   const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
   // Out-of-range lanes OR kOOB into their 16-byte aligned offset (= exactly kOOB): pure ALU, because a select on a per-lane
   // condition invites hipcc to branch around the DMA -- and a counted vmcnt needs the SAME number of VMEM instructions on every path.
@@ -116,6 +116,7 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a3 ? p.a3 : p.a), 0, (int)p.a3_bytes, 0x00020000);  // k_append: second appended source
 
   // stage the next tile of A half `h` into LDS stage `buf` (2 DMA instructions) and advance that stream by one K tile
   auto stage_a = [&](int h, int buf) {
@@ -123,7 +124,20 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
     unsigned char* dst = smem + buf * PP_STAGE + h * PP_HALF + wave * 1024;
     if constexpr (CONV) {
       const unsigned kmask = kA[h] < kend ? 0u : kOOB;  // wave-uniform (K % 64 == 0)
-      const bool first = ccA[h] < p.C1;
+      if (p.kapp && kA[h] >= p.kapp_k0) {  // the appended 1x1 segment of a k_append conv: the centre pixel of the second source
+        int cs, cbase;
+        const bool s2 = kapp_src(p, kA[h], cs, cbase);
+        const int co = kA[h] - cbase + kl;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned voff = kapp_voff(p, iy0[h][i], ix0[h][i], pbase[h][i], cs, co) | kmask;
+          if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 8192), 16, voff, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a3, (lds_ptr_t)(dst + i * 8192), 16, voff, 0, 0, 0);
+        }
+        kA[h] += BK;
+        return;
+      }
+      const bool first = p.kapp || ccA[h] < p.C1;
       const int cs = first ? p.C1 : p.C2;
       const int co = (first ? ccA[h] : ccA[h] - p.C1) + kl;
 #pragma unroll

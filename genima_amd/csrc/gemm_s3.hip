@@ -60,8 +60,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   const int lr = lane >> 3;
   const int chunk = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
   int kcur = kbeg + chunk * 8;
+  int kt0 = kbeg;  // wave-uniform K origin of the next tile to stage (k_append: which segment it lies in)
 
-  const int Cin = p.C1 + p.C2;
+  const int Cin = p.kapp ? p.C1 : p.C1 + p.C2;  // channels under each filter tap (k_append: the second source is not under the taps)
   const int Hin = p.ups ? 2 * p.H : p.H, Win = p.ups ? 2 * p.W : p.W;
   int iy0[GA], ix0[GA], pbase[GA], pix[GA];
   unsigned aoff[GA], amask[GA];  // dense: byte offset of the row start (kOOB if the row is out of range)
@@ -120,21 +121,35 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)p.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a2 ? p.a2 : p.a), 0, (int)p.a2_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a3 ? p.a3 : p.a), 0, (int)p.a3_bytes, 0x00020000);  // k_append: second appended source
 
   auto dma_tile = [&](int buf) {
     const unsigned kmask = kcur < kend ? 0u : kOOB;  // OR-masks, not selects: every path must issue the same VMEM instructions
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
     unsigned char* Bs = As + A_BYTES;
     if constexpr (CONV) {
-      const bool first = cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
-      const int cs = first ? p.C1 : p.C2;
-      const int co = first ? cc : cc - p.C1;
+      if (p.kapp && kt0 >= p.kapp_k0) {  // wave-uniform: the appended 1x1 segment (the same number of VMEM instructions on either side)
+        int cs, cbase;
+        const bool s2 = kapp_src(p, kt0, cs, cbase);
+        const int co = kcur - cbase;
 #pragma unroll
-      for (int i = 0; i < GA; ++i) {
-        const unsigned voff = ((unsigned)(pix[i] * cs + co) * 2u) | ((unsigned)(pix[i] >> 31) & kOOB) | kmask;
-        lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
-        if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+        for (int i = 0; i < GA; ++i) {
+          const unsigned voff = kapp_voff(p, iy0[i], ix0[i], pbase[i], cs, co) | kmask;
+          lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
+          if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a3, dst, 16, voff, 0, 0, 0);
+        }
+      } else {
+        const bool first = p.kapp || cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
+        const int cs = first ? p.C1 : p.C2;
+        const int co = first ? cc : cc - p.C1;
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+          const unsigned voff = ((unsigned)(pix[i] * cs + co) * 2u) | ((unsigned)(pix[i] >> 31) & kOOB) | kmask;
+          lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
+          if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -149,6 +164,7 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
     }
     kcur += BK;
+    kt0 += BK;
     if constexpr (CONV) {
       cu += BK;
       while (cu >= Cin) cu -= Cin;

@@ -80,6 +80,9 @@ class Engine:
         # 1251 -> 915 us, 512^2 x 256 -> 128 2066 -> 1657 us; a wash at 256^2 x 256 (789 -> 774), a loss below (the SiLU of the 1.4x halo patch is
         # VALU time beside the MFMAs of a 128-wide output tile)
         self.conv_gn_min_hw = int(os.environ.get("GN_CONV_GN_MIN_HW", str(512 * 512)))
+        # graphs: ResnetBlock2D's conv_shortcut inside conv2's K loop (gn_gemm_desc.k_append, packing `conv2sc`; A/B switch)
+        self.k_append = os.environ.get("GN_K_APPEND", "1") != "0"
+        self.k_append_min_rows = int(os.environ.get("GN_K_APPEND_MIN_ROWS", "0"))
         self.tblock = os.environ.get("GN_TBLOCK", "1") != "0"  # graphs: fused transformer-block chains at C = 320 (csrc/tblock.hip; A/B switch)
         # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:
         # tail 147 vs 201 us at 32768 rows, 121 vs 113 at 16384, 114 vs 64 at 8192)
@@ -208,6 +211,8 @@ class Engine:
             key += f"|o2{int(d.split_n)}"
         if d.ln_c1:
             key += "|ln"
+        if d.k_append:
+            key += "|ka"
         return key
 
     @staticmethod
@@ -230,6 +235,8 @@ class Engine:
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         if d.ln_c1:  # the LayerNorm fold lives in the LDS-DMA kernels (the library maps the other tiles onto them)
             cands = [c for c in cands if c % 100 >= 7 and c % 100 != 15]
+        if d.k_append:  # so does the appended 1x1 segment
+            cands = [c for c in cands if c % 100 >= 7]
         e0, e1 = self.event(), self.event()
 
         def race(plan: int) -> float:
@@ -535,10 +542,17 @@ class Engine:
                stride: int = 1, pad: Tuple[int, int, int, int] = None, x2: Optional[torch.Tensor] = None,
                shift: Optional[torch.Tensor] = None, ldshift: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
-               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False, up_phases: bool = False) -> torch.Tensor:
-        """NHWC conv.  ``up_phases``: w is [4][Cout][4 * Cin] -- the four phase convs of an Upsample2D as ONE launch (conv2d_up2x).  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
+               name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False, up_phases: bool = False,
+               append: Optional[torch.Tensor] = None, append2: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``append`` [B, H, W, C2] (+ ``append2`` [B, H, W, C3], the rest of a concatenated input): a 1x1 conv appended along K
+        (gn_gemm_desc.k_append) -- w = [Cout, k*k*C1 + C2 + C3], the 1x1 weight behind the packed k x k weight (packing: ``*.conv2sc.weight``):
+        ResnetBlock2D's conv2(h) + conv_shortcut(x) as one launch.
+        NHWC conv.  ``up_phases``: w is [4][Cout][4 * Cin] -- the four phase convs of an Upsample2D as ONE launch (conv2d_up2x).  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
         pad = (top, left, bottom, right); default k//2 all round.  shift: [B, ldshift or Cout] per-batch channel shift."""
         B, H, W, C1 = x.shape
+        if append is not None:
+            assert x2 is None and stride == 1 and not upsample2x and not up_phases and tuple(append.shape[:3]) == (B, H, W)
+            x2 = append
         C2 = x2.shape[-1] if x2 is not None else 0
         N = w.shape[1] if up_phases else w.shape[0]
         k = ksize
@@ -552,7 +566,9 @@ class Engine:
         d = GemmDesc()
         d.a, d.a2, d.w, d.bias, d.shift, d.residual, d.out = (_ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(shift),
                                                               _ptr(residual), _ptr(out))
-        d.M, d.N, d.K = B * Ho * Wo, N, k * k * (C1 + C2)
+        C3 = append2.shape[-1] if append2 is not None else 0
+        d.M, d.N, d.K = B * Ho * Wo, N, (k * k * C1 + C2 + C3) if append is not None else k * k * (C1 + C2)
+        d.k_append, d.a3, d.C3 = int(append is not None), _ptr(append2), C3
         assert w.shape[-1] == d.K, (tuple(w.shape), d.K)
         d.ldw, d.ldo, d.ldshift = w.stride(-2), out.stride(-2), ldshift
         if up_phases:
@@ -568,7 +584,7 @@ class Engine:
         d.upsample2x, d.act, d.out_mode, d.rows_per_batch, d.splitk, d.out_scale = (int(upsample2x), act, OUT_ROWMAJOR,
                                                                                      Ho * Wo, splitk, out_scale)
         d.residual_before_act = int(residual_before_act)
-        self._gemm(d, (x, x2, w, bias, shift, residual, out))
+        self._gemm(d, (x, x2, w, bias, shift, residual, out, append2))
         return out
 
     def conv2d_up2x(self, x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor] = None, *, name: Optional[str] = None) -> torch.Tensor:

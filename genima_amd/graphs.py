@@ -76,7 +76,12 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
         # the 1x1 shortcut conv only reads the block input: where the program's side stream is idle (the UNet decoder, after the
         # ControlNet has been joined) AND the batch is too small to fill the chip, it runs there beside GroupNorm -> conv1 -> GroupNorm
         side = has_sc and getattr(E, "side_free", False) and E.record
-        if has_sc:
+        # ... otherwise it rides in conv2's K loop (one launch, no round trip of its output): gn_gemm_desc.k_append, packing `conv2sc`
+        kapp = (has_sc and not side and getattr(E, "k_append", True) and (p + ".conv2sc.weight") in W and x.dim() == 4
+                and (x2 is None or x.shape[-1] % 64 == 0) and x.shape[0] * x.shape[1] * x.shape[2] >= getattr(E, "k_append_min_rows", 0))
+        if kapp:
+            sc = None
+        elif has_sc:
             if side:
                 E.fork()
             sc = E.conv2d(x, W[p + ".conv_shortcut.weight"], W[p + ".conv_shortcut.bias"], ksize=1, x2=x2, name="sc")
@@ -106,6 +111,8 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
         h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
         if side:
             E.join()
+        if kapp:  # (a concatenated block input -- the up blocks -- is appended as its two tensors)
+            return E.conv2d(h, W[p + ".conv2sc.weight"], W[p + ".conv2sc.bias"], append=x, append2=x2, name="c2sc")
         return E.conv2d(h, c2w, W[p + ".conv2.bias"], residual=sc, name="c2")
 
 

@@ -353,6 +353,19 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16, up
                 if qn == ".attn1.to_q.weight" and base + ".attn1.to_v.weight" in sd and qb not in sd:
                     # q | k | v as ONE launch (two-destination GEMM: q, k row-major + V^T): the inference graphs' self-attention
                     out[base + ".attn1.to_qkv.weight"] = torch.cat([sd[name], sd[base + kn], sd[base + ".attn1.to_v.weight"]], dim=0).to(dtype).contiguous()
+    if dtype == torch.float16 and up_phases:
+        # ResnetBlock2D with a conv_shortcut: conv2(h) + conv_shortcut(x) as ONE conv whose K axis carries the 1x1 weight behind the 3x3 one
+        # (gn_gemm_desc.k_append) -- [Cout, 9 * C + Cx] and the two biases' sum (fp32 sum, one rounding).  Inference dicts only (as up4).
+        for name in list(sd.keys()):
+            if not name.endswith(".conv_shortcut.weight"):
+                continue
+            base = name[: -len(".conv_shortcut.weight")]
+            w2, ws = out.get(base + ".conv2.weight"), out.get(name)
+            if w2 is None or ws is None or sd[base + ".conv2.weight"].shape[2:] != (3, 3) or (w2.shape[1] // 9) % 64 != 0 or ws.shape[0] != w2.shape[0]:
+                continue
+            out[base + ".conv2sc.weight"] = torch.cat([w2, ws.to(w2.device)], dim=1).contiguous()
+            b = sd[base + ".conv2.bias"].detach().float() + sd[base + ".conv_shortcut.bias"].detach().float()
+            out[base + ".conv2sc.bias"] = pack_vec(b, w2.shape[0], dtype=dtype)
     if dtype == torch.float16:
         fold_layernorms(out)
         add_tblock_tapes(out, hip)

@@ -120,6 +120,16 @@ typedef struct gn_gemm_desc {
    * pad_t / pad_l / out / ldo / ldo_hi / out_row_width describe phase (0, 0); phase (dy, dx) uses padding 1 - dy / 1 - dx and writes
    * ldo_hi / 2 * dy + ldo / 2 * dx elements further. */
   int32_t up_phases;
+  /* 1: a 1x1 conv of a SECOND tensor appended along K -- out = conv_KHxKW(a; w[:, :KH*KW*C1]) + conv_1x1(a2; w[:, KH*KW*C1:]) + bias:
+   * diffusers ResnetBlock2D's  conv2(h) + conv_shortcut(x)  (the blocks whose channel count changes: every up block of the UNet reads a
+   * concatenation) as ONE launch instead of a 1x1 launch, its output's round trip and a residual read.  a2 = [B, H, W, C2] (C2 channels, same
+   * pixels as the output), K = KH*KW*C1 + C2, w = [N][K] with the 1x1 weight behind the packed KHxKW weight, bias = the two biases' sum.
+   * A block whose input is a concatenation (the up blocks: cat(hidden, skip)) appends BOTH tensors: a2 (C2 channels, C2 % 64 == 0) then a3
+   * (C3 channels), K = KH*KW*C1 + C2 + C3.  Stride 1, same-size output, C1 % 64 == 0, no fused upsample; LDS-DMA tiles (7..23; the others are
+   * mapped onto them). */
+  int32_t k_append;
+  const void* a3;         /* k_append: optional second appended source [B, H, W, C3] or NULL */
+  int32_t C3;
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */

@@ -56,6 +56,8 @@ def valid_plans(d):
     tiles = list(GEGLU_TILES) if d.act == ACT_GEGLU else list(range(1, Engine.N_TILE_CFGS + 1))
     if d.ln_c1:
         tiles = [t for t in tiles if t >= 7 and t not in (15, 24)]
+    if d.k_append:  # the appended 1x1 segment lives in the LDS-DMA loaders
+        tiles = [t for t in tiles if t >= 7]
     return tiles
 
 
