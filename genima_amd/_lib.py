@@ -39,7 +39,7 @@ class GemmDesc(C.Structure):
         ("accumulate", C.c_int32), ("fp8", C.c_int32), ("scale_a", C.c_void_p), ("scale_w", C.c_void_p),
         ("out2", C.c_void_p), ("ldo2", C.c_int64), ("split_n", C.c_int32),
         ("ln_eps", C.c_float), ("ln_c1", C.c_void_p), ("out_row_width", C.c_int32), ("ldo_hi", C.c_int64), ("up_phases", C.c_int32),
-        ("k_append", C.c_int32), ("a3", C.c_void_p), ("C3", C.c_int32),
+        ("k_append", C.c_int32), ("a3", C.c_void_p), ("C3", C.c_int32), ("lda2", C.c_int64),
     ]
 
 

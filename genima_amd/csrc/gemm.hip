@@ -354,6 +354,14 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
           else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
         }
       }
+    } else if (!LNF && p.kapp && kt0 >= p.kapp_k0) {  // dense k_append: the second operand's columns (wave-uniform: kapp_k0 % 64 == 0)
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const int m = m0 + 8 * (wave + NW * i) + lr;
+        unsigned voff = (kok && m < p.M) ? (unsigned)((long)m * p.lda2 * 2) + (unsigned)(kcur - p.kapp_k0) * 2u : kOOB;
+        GN_PIN(voff);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
@@ -678,7 +686,7 @@ DmaBytes dma_bytes(const gn_gemm_desc* d) {
     const uint64_t px = (uint64_t)d->B * d->H * d->W;
     b.a = px * d->C1 * 2; b.a2 = px * d->C2 * 2;
   } else {
-    b.a = (uint64_t)d->M * d->lda * 2; b.a2 = 0;
+    b.a = (uint64_t)d->M * d->lda * 2; b.a2 = d->k_append ? (uint64_t)d->M * d->lda2 * 2 : 0;
   }
   b.w = (uint64_t)d->N * d->ldw * 2;
   return b;
@@ -860,6 +868,10 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     GN_REQUIRE(d->M == (int64_t)d->B * d->Ho * d->Wo, "gn_gemm(conv): M != B*Ho*Wo");
     GN_REQUIRE(d->stride >= 1 && d->KH >= 1 && d->KW >= 1 && d->H > 0 && d->W > 0, "gn_gemm(conv): bad geometry");
     GN_REQUIRE((int64_t)d->B * d->H * d->W < (1ll << 31), "gn_gemm(conv): source tensor has too many pixels");
+  } else if (d->k_append) {
+    GN_REQUIRE(d->a2 && d->C2 > 0 && d->C2 % 8 == 0 && (d->K - d->C2) % 64 == 0 && d->K > d->C2, "gn_gemm(k_append): a2 with C2 (%d) columns behind K - C2 (%% 64 == 0)", d->C2);
+    GN_REQUIRE(d->lda % 8 == 0 && d->lda >= d->K - d->C2 && d->lda2 % 8 == 0 && d->lda2 >= d->C2 && ((uintptr_t)d->a2 & 15) == 0, "gn_gemm(k_append): lda / lda2 must be multiples of 8 covering their columns");
+    GN_REQUIRE(!d->ln_c1 && !d->fp8 && d->batch <= 1 && dma_eligible(d), "gn_gemm(k_append): plain dense problems on the LDS-DMA tiles");
   } else {
     GN_REQUIRE(d->lda % 8 == 0 && d->lda >= d->K, "gn_gemm: lda (%ld) must be a multiple of 8 and >= K", (long)d->lda);
   }
@@ -883,7 +895,8 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   }
   p.tiles_m = (int)cdiv64(d->M, pl.bm); p.tiles_n = (int)cdiv64(d->N, pl.bn);
   p.kapp = d->k_append ? 1 : 0;
-  p.kapp_k0 = d->KH * d->KW * d->C1;
+  p.kapp_k0 = d->conv ? d->KH * d->KW * d->C1 : (int)(d->K - d->C2);
+  p.lda2 = d->lda2;
   p.a3 = d->k_append ? (const f16*)d->a3 : nullptr; p.C3 = d->k_append ? d->C3 : 0;
   p.a3_bytes = p.a3 ? (unsigned)((uint64_t)d->B * d->H * d->W * d->C3 * 2) : p.a_bytes;
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);

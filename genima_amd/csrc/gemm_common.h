@@ -45,6 +45,7 @@ struct GemmParams {
   int kapp, kapp_k0;                     // conv with a 1x1 conv APPENDED along K (gn_gemm_desc.k_append): K tiles from kapp_k0 = KH * KW * C1 on read
                                          // the output pixel of the appended sources a2 (C2 channels), then a3 (C3) -- the LDS-DMA kernels' loaders
   const f16* a3; int C3; unsigned a3_bytes;
+  long lda2;                             // dense k_append: out = [A | A2] . W^T -- K tiles from kapp_k0 on read A2 (row stride lda2) through a2
 };
 
 // the appended 1x1 segment of a k_append conv: source offset of staged row i for the K tile whose lane offset inside the segment is `co`

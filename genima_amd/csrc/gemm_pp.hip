@@ -155,10 +155,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
       }
     } else {
       const unsigned kmask = kA[h] < kend ? 0u : kOOB;
+      if (p.kapp && kA[h] >= p.kapp_k0) {  // dense k_append: the second operand's columns
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned voff = (aoff[h][i] + (unsigned)(kA[h] + kl) * 2u) | amask[h][i] | kmask;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(dst + i * 8192), 16, voff, 0, 0, 0);
+        for (int i = 0; i < 2; ++i) {
+          const int m = min(m0 + 128 * h + 8 * (wave + 8 * i) + lr, p.M - 1);
+          const unsigned voff = ((unsigned)((long)m * p.lda2 * 2) + (unsigned)(kA[h] - p.kapp_k0 + kl) * 2u) | amask[h][i] | kmask;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(dst + i * 8192), 16, voff, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned voff = (aoff[h][i] + (unsigned)(kA[h] + kl) * 2u) | amask[h][i] | kmask;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(dst + i * 8192), 16, voff, 0, 0, 0);
+        }
       }
       kA[h] += BK;
     }

@@ -151,6 +151,13 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
           else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
         }
       }
+    } else if (!LNF && p.kapp && kt0 >= p.kapp_k0) {  // dense k_append: the second operand's columns (wave-uniform: kapp_k0 % 64 == 0)
+#pragma unroll
+      for (int i = 0; i < GA; ++i) {
+        const int m = m0 + 8 * (wave + NW * i) + lr;
+        const unsigned voff = ((unsigned)((long)min(m, p.M - 1) * p.lda2 * 2) + (unsigned)(kcur - p.kapp_k0) * 2u) | amask[i] | kmask;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < GA; ++i) {

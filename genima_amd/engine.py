@@ -83,6 +83,7 @@ class Engine:
         # graphs: ResnetBlock2D's conv_shortcut inside conv2's K loop (gn_gemm_desc.k_append, packing `conv2sc`; A/B switch)
         self.k_append = os.environ.get("GN_K_APPEND", "1") != "0"
         self.k_append_min_rows = int(os.environ.get("GN_K_APPEND_MIN_ROWS", "0"))
+        self.side_free_max_rows = int(os.environ.get("GN_SIDE_FREE_MAX_ROWS", "4096"))  # decoder shortcuts on the idle side stream up to this many latent rows
         self.tblock = os.environ.get("GN_TBLOCK", "1") != "0"  # graphs: fused transformer-block chains at C = 320 (csrc/tblock.hip; A/B switch)
         # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:
         # tail 147 vs 201 us at 32768 rows, 121 vs 113 at 16384, 114 vs 64 at 8192)
@@ -370,7 +371,8 @@ class Engine:
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
                transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0,
-               split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5):
+               split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
+               append: Optional[torch.Tensor] = None):
         """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
         transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel).
         split_n > 0: ONE launch with two destinations (the q | k | v projections of a self-attention block): columns [0, split_n)
@@ -380,9 +382,12 @@ class Engine:
         K = x.shape[-1]
         M = x.numel() // K
         N = w.shape[0]
+        if append is not None:  # y = [x | append] @ w.T: gn_gemm_desc.k_append (dense) -- two Linears without a nonlinearity between them as one
+            assert ln_c1 is None and append.numel() // append.shape[-1] == M and x.shape[-1] % 64 == 0
+            K += append.shape[-1]
         assert w.shape[1] == K, (w.shape, x.shape)
         fp8w = self._fp8_weights.get(w.data_ptr()) if self._fp8_weights else None
-        if fp8w is not None and not transposed_out and splitk == 0 and M >= self.fp8_min_rows and not self.record:
+        if fp8w is not None and append is None and not transposed_out and splitk == 0 and M >= self.fp8_min_rows and not self.record:
             xq, xs = self._fp8_activation(x)
             return self.linear_fp8(xq, xs, fp8w[0], fp8w[1], bias, act=act, residual=residual, out=out, name=name)
         n_out = N // 2 if act == ACT_GEGLU else N
@@ -411,12 +416,14 @@ class Engine:
         d.a, d.w, d.bias, d.residual, d.out = _ptr(x), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out)
         d.M, d.N, d.K = M, N, K
         d.lda, d.ldw = x.stride(-2) if x.dim() > 1 else K, w.stride(0)
+        if append is not None:
+            d.k_append, d.a2, d.C2, d.lda2 = 1, _ptr(append), append.shape[-1], append.stride(-2)
         d.ldr = residual.stride(-2) if residual is not None else 0
         d.act, d.splitk, d.out_scale = act, splitk, 1.0
         if ln_c1 is not None:
             assert bias is not None and ln_c1.dtype == torch.float32 and ln_c1.numel() == N and not transposed_out
             d.ln_c1, d.ln_eps = _ptr(ln_c1), float(ln_eps)
-        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1))
+        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1, append))
         return (out, out2) if split_n else out
 
     # ---- fused chains of a transformer block's Linears (csrc/tblock.hip): one launch keeps 128 rows of the residual stream in LDS ----------

@@ -217,6 +217,10 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                 else:
                     n = E.layernorm(h, W[b + ".norm3.weight"], W[b + ".norm3.bias"], name="ln3")
                     g = E.linear(n, W[b + ".ff.net.0.proj.weight"], W[b + ".ff.net.0.proj.bias"], act=ACT_GEGLU, name="ffg")
+                if k == 0 and getattr(E, "k_append", True) and (p + ".ffo_pout.weight") in W and not E._fp8_weights:
+                    # the block's last Linear and the transformer's proj_out as one GEMM over [g | h] (packing `ffo_pout`, gn_gemm_desc.k_append)
+                    out = E.linear(g, W[p + ".ffo_pout.weight"], W[p + ".ffo_pout.bias"], residual=x.view(B, N, Cc), append=h, name="ffpo")
+                    return out.view(B, H, Wd, Cc)
                 h = E.linear(g, W[b + ".ff.net.2.weight"], W[b + ".ff.net.2.bias"], residual=h, name="ffo")
             k += 1
         out = E.linear(h, W[p + ".proj_out.weight"], W[p + ".proj_out.bias"], residual=x.view(B, N, Cc), name="pout")
@@ -273,7 +277,7 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
         h = _emit_mid(E, W, cfg, h, shifts, kv)
         if before_residuals is not None:
             before_residuals()
-            E.side_free = x8.shape[0] * x8.shape[1] * x8.shape[2] <= 4096  # the caller joined its side stream: free for the decoder at small batch
+            E.side_free = x8.shape[0] * x8.shape[1] * x8.shape[2] <= getattr(E, "side_free_max_rows", 4096)  # the caller joined its side stream: free for the decoder at small batch
         # the residual adds only feed the decoder, so they sit after the mid block (same values; lets the encoder + mid overlap the ControlNet)
         if down_res is not None:
             skips = [E.add(s, r, name=f"skip_add{i}") for i, (s, r) in enumerate(zip(skips, down_res))]

@@ -126,10 +126,14 @@ typedef struct gn_gemm_desc {
    * pixels as the output), K = KH*KW*C1 + C2, w = [N][K] with the 1x1 weight behind the packed KHxKW weight, bias = the two biases' sum.
    * A block whose input is a concatenation (the up blocks: cat(hidden, skip)) appends BOTH tensors: a2 (C2 channels, C2 % 64 == 0) then a3
    * (C3 channels), K = KH*KW*C1 + C2 + C3.  Stride 1, same-size output, C1 % 64 == 0, no fused upsample; LDS-DMA tiles (7..23; the others are
-   * mapped onto them). */
+   * mapped onto them).
+   * Dense problems (conv == 0): out = [A | A2] . W^T -- the last C2 of the K columns come from a2 (row stride lda2), K - C2 a multiple of 64.
+   * That is how TWO Linears without a nonlinearity between them run as one: Transformer2DModel's  proj_out(ff.net.2(g) + h) + x  is
+   * [W_po W_ff2 | W_po] . [g ; h] + (W_po b_ff2 + b_po) + x  (packing `ffo_pout`: the product in fp32, one rounding). */
   int32_t k_append;
-  const void* a3;         /* k_append: optional second appended source [B, H, W, C3] or NULL */
+  const void* a3;         /* k_append (conv): optional second appended source [B, H, W, C3] or NULL */
   int32_t C3;
+  int64_t lda2;           /* k_append (dense): row stride of a2 */
 } gn_gemm_desc;
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */

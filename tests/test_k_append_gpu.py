@@ -56,3 +56,41 @@ def test_appended_shortcut_matches_the_two_launches(B, H, C, C2, C3, N, splitk):
     ref = _ref(h, x, w3, b3, w1, b1)
     e1, e2 = assert_close(y, ref, 1e-3, "appended"), assert_close(y2, ref, 1e-3, "two launches")
     assert e1 <= 1.2 * e2 + 1e-5  # one rounding instead of two: no further from fp32 than the launches it replaces
+
+
+@pytest.mark.parametrize("tile", [0] + list(range(7, 24)))
+def test_dense_append_every_dma_tile(tile):
+    """y = [g | h] @ w.T + b + x on every LDS-DMA tile (rows not a multiple of any tile, the second operand with its own row stride)."""
+    E = Engine("cuda:0")
+    E.autotune = False
+    M, K1, K2, N = 616, 256, 192, 320
+    g, hbig, x = randn_h(M, K1, seed=tile), randn_h(M, K2 + 64, seed=tile + 1), randn_h(M, N, seed=tile + 2)
+    h = hbig[:, :K2]  # row stride K2 + 64
+    w, b = randn_h(N, K1 + K2, seed=tile + 3, scale=0.05), randn_h(N, seed=tile + 4)
+    ref = torch.cat([g.float(), h.float()], dim=1) @ w.float().t() + b.float() + x.float()
+    if tile:
+        E.lib.gn_set_gemm_tile_override(tile - 1)
+    try:
+        y = E.linear(g, w, b, residual=x, append=h)
+    finally:
+        E.lib.gn_set_gemm_tile_override(-1)
+    E.synchronize()
+    assert_close(y, ref, 1e-3, f"tile {tile}")
+
+
+@pytest.mark.parametrize("M,C,splitk", [(2048, 1280, 0), (8192, 640, 0), (64, 1280, 4), (1024, 320, 0)])
+def test_composed_ff_out_and_proj_out(M, C, splitk):
+    """Transformer2DModel's proj_out(ff.net.2(g) + h) + x as ONE GEMM over [g | h] with the composed weight (packing `ffo_pout`) against the
+    two launches it replaces and fp32."""
+    E = Engine("cuda:0")
+    g, h, x = randn_h(M, 4 * C, seed=1), randn_h(M, C, seed=2), randn_h(M, C, seed=3)
+    wf, bf = randn_h(C, 4 * C, seed=4, scale=0.02), randn_h(C, seed=5, scale=0.1)
+    wp, bp = randn_h(C, C, seed=6, scale=0.03), randn_h(C, seed=7, scale=0.1)
+    wcat = torch.cat([wp.double() @ wf.double(), wp.double()], dim=1).half().contiguous()
+    bcat = (wp.double() @ bf.double() + bp.double()).half()
+    y = E.linear(g, wcat, bcat, residual=x, append=h, splitk=splitk)
+    y2 = E.linear(E.linear(g, wf, bf, residual=h), wp, bp, residual=x)
+    E.synchronize()
+    ref = ((g.float() @ wf.float().t() + bf.float() + h.float()) @ wp.float().t() + bp.float() + x.float())
+    e1, e2 = assert_close(y, ref, 1e-3, "composed"), assert_close(y2, ref, 1e-3, "two launches")
+    assert e1 <= 1.5 * e2 + 1e-5
