@@ -75,10 +75,11 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
         has_sc = (p + ".conv_shortcut.weight") in W
         # the 1x1 shortcut conv only reads the block input: where the program's side stream is idle (the UNet decoder, after the
         # ControlNet has been joined) AND the batch is too small to fill the chip, it runs there beside GroupNorm -> conv1 -> GroupNorm
-        side = has_sc and getattr(E, "side_free", False) and E.record
-        # ... otherwise it rides in conv2's K loop (one launch, no round trip of its output): gn_gemm_desc.k_append, packing `conv2sc`
-        kapp = (has_sc and not side and getattr(E, "k_append", True) and (p + ".conv2sc.weight") in W and x.dim() == 4
+        # ... unless it rides in conv2's K loop (one launch, no round trip of its output): gn_gemm_desc.k_append, packing `conv2sc` -- better
+        # than the side stream at every batch size (single view 20.1 vs 20.8 ms, tiled B = 1 29.0 vs 29.9: profiles/r04_v6_side_free_ab.txt)
+        kapp = (has_sc and getattr(E, "k_append", True) and (p + ".conv2sc.weight") in W and x.dim() == 4
                 and (x2 is None or x.shape[-1] % 64 == 0) and x.shape[0] * x.shape[1] * x.shape[2] >= getattr(E, "k_append_min_rows", 0))
+        side = has_sc and not kapp and getattr(E, "side_free", False) and E.record
         if kapp:
             sc = None
         elif has_sc:
