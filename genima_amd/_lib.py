@@ -151,6 +151,7 @@ SIGNATURES = {
     "gn_program_add_copy4d": (_I32, [_P, _P, _P, _P, _P, _P, _I32]),
     "gn_program_add_argmax_rows_i32": (_I32, [_P, _P, _P, _I32, _I32]),
     "gn_add": (_I32, [_P, _P, _P, _P, _I64]),
+    "gn_add_multi": (_I32, [_P, _P, _P, _P, _P, _I32]),
     "gn_act": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_film": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32]),
     "gn_program_add_film": (_I32, [_P, _P, _P, _P, _P, _I64, _I64, _I64, _I32, _I32]),
@@ -218,6 +219,7 @@ SIGNATURES = {
     "gn_program_add_main": (_I32, [_P]),
     "gn_program_add_join": (_I32, [_P]),
     "gn_program_add_add": (_I32, [_P, _P, _P, _P, _I64]),
+    "gn_program_add_add_multi": (_I32, [_P, _P, _P, _P, _P, _I32]),
     "gn_program_add_add_noise": (_I32, [_P, _P, _P, _P, _P, _P, _I32, _I64]),
     "gn_program_add_act": (_I32, [_P, _P, _P, _I64, _I32]),
     "gn_program_add_embedding": (_I32, [_P, _P, _P, _P, _P, _I32, _I32, _I32]),

@@ -20,7 +20,7 @@ namespace {
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
   OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE, OP_FILM, OP_SCALE_CAT_PAD,
-  OP_TBLOCK, OP_CONV_GN,
+  OP_TBLOCK, OP_CONV_GN, OP_ADD_MULTI,
   OP_FORK, OP_MAIN, OP_JOIN  // stream control: ops after FORK go to the program's side stream until MAIN; JOIN makes main wait for it
 };
 
@@ -33,9 +33,12 @@ struct GenericArgs {  // argument block of the small ops
   float g[6];     // normalize: mul[3], add[3]
 };
 
+struct AddMultiOp { const void* a[GN_ADD_MULTI_MAX]; const void* b[GN_ADD_MULTI_MAX]; void* out[GN_ADD_MULTI_MAX]; int64_t n[GN_ADD_MULTI_MAX]; int32_t count; };
+
 struct Op {
   int type;
   union {
+    AddMultiOp addm;
     gn_gemm_desc gemm;
     gn_attn_desc attn;
     gn_groupnorm_desc gnorm;
@@ -72,6 +75,7 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_F16_TO_U8: return gn_image_f16_to_u8(ctx, g.p0, (uint8_t*)g.p3, g.n0, g.i0);
     case OP_U8_TO_F16: return gn_image_u8_to_f16(ctx, (const uint8_t*)g.p0, g.p3, g.n0, g.i0, g.f0, g.f1);
     case OP_ADD: return gn_add(ctx, g.p0, g.p1, g.p3, g.n0);
+    case OP_ADD_MULTI: return gn_add_multi(ctx, op.addm.a, op.addm.b, op.addm.out, op.addm.n, op.addm.count);
     case OP_ACT: return gn_act(ctx, g.p0, g.p3, g.n0, g.i0);
     case OP_FILM: return gn_film(ctx, g.p0, g.p3, g.p1, g.p2, g.m[0], g.m[1], g.n0, g.i0, g.i1);
     case OP_EMBED: return gn_embedding(ctx, (const int32_t*)g.p0, g.p1, g.p2, g.p3, g.i0, g.i1, g.i2);
@@ -232,6 +236,16 @@ int32_t gn_program_add_image_u8_to_f16(gn_program* p, const uint8_t* in, void* o
 }
 int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n) {
   return push_generic(p, OP_ADD, a, b, nullptr, out, n, 0, 0, 0, 0, 0, 0.f, 0.f);
+}
+int32_t gn_program_add_add_multi(gn_program* p, const void* const* a, const void* const* b, void* const* out, const int64_t* n, int32_t count) {
+  GN_REQUIRE(p && a && b && out && n && count >= 1 && count <= GN_ADD_MULTI_MAX, "gn_program_add_add_multi: 1 .. %d tensors", GN_ADD_MULTI_MAX);
+  Op op;
+  memset(&op, 0, sizeof(op));
+  op.type = OP_ADD_MULTI;
+  for (int i = 0; i < count; ++i) { op.addm.a[i] = a[i]; op.addm.b[i] = b[i]; op.addm.out[i] = out[i]; op.addm.n[i] = n[i]; }
+  op.addm.count = count;
+  p->ops.push_back(op);
+  return GN_OK;
 }
 int32_t gn_program_add_film(gn_program* p, const void* x, void* out, const void* gamma, const void* beta, int64_t ld_film,
                             int64_t rows_per_film, int64_t rows, int32_t C, int32_t act) {

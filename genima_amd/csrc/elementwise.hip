@@ -148,6 +148,25 @@ __global__ void add_kernel(const uint4* __restrict__ a, const uint4* __restrict_
   out[i] = *reinterpret_cast<uint4*>(&o);
 }
 
+// up to GN_ADD_MULTI_MAX independent  out = a + b  in ONE launch (blockIdx.y = which): the UNet's twelve skip + ControlNet-residual adds and the
+// mid-block one sit behind the stream join on the call's critical path, 13 launch boundaries per denoise step for a few microseconds of work
+struct AddMultiArgs { const uint4* a[GN_ADD_MULTI_MAX]; const uint4* b[GN_ADD_MULTI_MAX]; uint4* out[GN_ADD_MULTI_MAX]; long n8[GN_ADD_MULTI_MAX]; };
+__global__ void add_multi_kernel(const AddMultiArgs p) {
+  const int t = blockIdx.y;
+  const uint4* __restrict__ a = p.a[t];
+  const uint4* __restrict__ b = p.b[t];
+  uint4* __restrict__ out = p.out[t];
+  const long n8 = p.n8[t];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+    const uint4 ra = a[i], rb = b[i];
+    const f16x8 va = *reinterpret_cast<const f16x8*>(&ra), vb = *reinterpret_cast<const f16x8*>(&rb);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (f16)((float)va[e] + (float)vb[e]);
+    out[i] = *reinterpret_cast<uint4*>(&o);
+  }
+}
+
 __global__ void act_kernel(const uint4* __restrict__ a, uint4* __restrict__ out, long n8, int act) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n8) return;
@@ -367,6 +386,22 @@ int32_t gn_image_f16_to_u8(gn_ctx* ctx, const void* in, uint8_t* out, int64_t pi
 int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n) {
   GN_REQUIRE(ctx && a && b && out && n > 0 && n % 8 == 0, "gn_add: n must be a positive multiple of 8");
   hipLaunchKernelGGL(add_kernel, dim3(nblk(n / 8)), dim3(256), 0, ctx->stream, (const uint4*)a, (const uint4*)b, (uint4*)out, (long)(n / 8));
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_add_multi(gn_ctx* ctx, const void* const* a, const void* const* b, void* const* out, const int64_t* n, int32_t count) {
+  GN_REQUIRE(ctx && a && b && out && n && count >= 1 && count <= GN_ADD_MULTI_MAX, "gn_add_multi: 1 .. %d tensors", GN_ADD_MULTI_MAX);
+  AddMultiArgs p;
+  long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    GN_REQUIRE(a[i] && b[i] && out[i] && n[i] > 0 && n[i] % 8 == 0, "gn_add_multi: tensor %d: n must be a positive multiple of 8", i);
+    p.a[i] = (const uint4*)a[i]; p.b[i] = (const uint4*)b[i]; p.out[i] = (uint4*)out[i]; p.n8[i] = (long)(n[i] / 8);
+    nmax = p.n8[i] > nmax ? p.n8[i] : nmax;
+  }
+  long blocks = (nmax + 255) / 256;
+  if (blocks > 2048) blocks = 2048;  // (grid-stride: the largest tensor sets the x extent, smaller ones leave their tail blocks idle)
+  hipLaunchKernelGGL(add_multi_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
   return GN_OK;
 }

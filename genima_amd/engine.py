@@ -83,6 +83,7 @@ class Engine:
         # graphs: ResnetBlock2D's conv_shortcut inside conv2's K loop (gn_gemm_desc.k_append, packing `conv2sc`; A/B switch)
         self.k_append = os.environ.get("GN_K_APPEND", "1") != "0"
         self.k_append_min_rows = int(os.environ.get("GN_K_APPEND_MIN_ROWS", "0"))
+        self.add_multi_on = os.environ.get("GN_ADD_MULTI", "1") != "0"  # graphs: the UNet's skip + ControlNet-residual adds as one launch
         self.side_free_max_rows = int(os.environ.get("GN_SIDE_FREE_MAX_ROWS", "4096"))  # decoder shortcuts on the idle side stream up to this many latent rows
         self.tblock = os.environ.get("GN_TBLOCK", "1") != "0"  # graphs: fused transformer-block chains at C = 320 (csrc/tblock.hip; A/B switch)
         # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:
@@ -862,6 +863,18 @@ class Engine:
             out = self.buf(name, a.shape)
         self._small("add", (a, b, out), _ptr(a), _ptr(b), _ptr(out), a.numel())
         return out
+
+    def add_multi(self, pairs, *, name=None):
+        """[(a, b), ...] (<= 16) -> [a + b, ...] as ONE launch (gn_add_multi): independent small adds that would each pay a launch boundary."""
+        n = len(pairs)
+        outs = [self.buf(None if name is None else f"{name}{i}", a.shape) for i, (a, _) in enumerate(pairs)]
+        A = (C.c_void_p * n)(*[_ptr(a) for a, _ in pairs])
+        Bp = (C.c_void_p * n)(*[_ptr(b) for _, b in pairs])
+        O = (C.c_void_p * n)(*[_ptr(o) for o in outs])
+        N = (C.c_int64 * n)(*[a.numel() for a, _ in pairs])
+        keep = tuple(t for pr in pairs for t in pr) + tuple(outs)
+        self._small("add_multi", keep, A, Bp, O, N, n)
+        return outs
 
     def act(self, x: torch.Tensor, act: int, *, out=None, name=None):
         if out is None:

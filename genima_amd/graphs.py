@@ -280,10 +280,14 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
             before_residuals()
             E.side_free = x8.shape[0] * x8.shape[1] * x8.shape[2] <= getattr(E, "side_free_max_rows", 4096)  # the caller joined its side stream: free for the decoder at small batch
         # the residual adds only feed the decoder, so they sit after the mid block (same values; lets the encoder + mid overlap the ControlNet)
-        if down_res is not None:
-            skips = [E.add(s, r, name=f"skip_add{i}") for i, (s, r) in enumerate(zip(skips, down_res))]
-        if mid_res is not None:
-            h = E.add(h, mid_res, name="mid_add")
+        if down_res is not None and mid_res is not None and len(skips) < 16 and getattr(E, "add_multi_on", True):
+            outs = E.add_multi(list(zip(skips, down_res)) + [(h, mid_res)], name="res_add")  # thirteen adds, one launch (gn_add_multi)
+            skips, h = outs[:-1], outs[-1]
+        else:
+            if down_res is not None:
+                skips = [E.add(s, r, name=f"skip_add{i}") for i, (s, r) in enumerate(zip(skips, down_res))]
+            if mid_res is not None:
+                h = E.add(h, mid_res, name="mid_add")
         nlev = len(cfg["block_out_channels"])
         for i, btype in enumerate(cfg["up_block_types"]):
             for j in range(cfg["layers_per_block"] + 1):

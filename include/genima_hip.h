@@ -350,6 +350,11 @@ int32_t gn_copy4d(gn_ctx* ctx, const void* in, void* out, const int64_t* sizes, 
 
 /* ---- misc elementwise / gather ------------------------------------------------------------------------------------ */
 int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n);              /* f16, n % 8 == 0 */
+/* count <= GN_ADD_MULTI_MAX independent out[i] = a[i] + b[i] (n[i] % 8 == 0) as ONE launch: UNet2DConditionModel.forward's
+ * `down_block_res_samples + down_block_additional_residuals` / `sample + mid_block_additional_residual` additions (thirteen torch adds
+ * inside `self.pipe(...)`, controller/agent/sd_controlnet_agent.py:67-76) */
+#define GN_ADD_MULTI_MAX 16
+int32_t gn_add_multi(gn_ctx* ctx, const void* const* a, const void* const* b, void* const* out, const int64_t* n, int32_t count);
 int32_t gn_act(gn_ctx* ctx, const void* x, void* out, int64_t n, int32_t act);                /* f16, n % 8 == 0 */
 /* FiLM (controller/method/genima_act.py:190: ``encoder_model(image, task_emb)`` with use_lang_cond, genima_act.yaml:39):
  * out[r, :] = act((1 + gamma[r / rows_per_film, :]) * x[r, :] + beta[r / rows_per_film, :]); x / out f16 [rows, C], gamma / beta f16 rows of
@@ -499,6 +504,7 @@ int32_t gn_program_add_fork(gn_program* p);
 int32_t gn_program_add_main(gn_program* p);
 int32_t gn_program_add_join(gn_program* p);
 int32_t gn_program_add_add(gn_program* p, const void* a, const void* b, void* out, int64_t n);
+int32_t gn_program_add_add_multi(gn_program* p, const void* const* a, const void* const* b, void* const* out, const int64_t* n, int32_t count);
 int32_t gn_program_add_add_noise(gn_program* p, const void* x0, const void* noise, const float* sqrt_ac, const float* sqrt_1mac,
                                  void* out, int32_t B, int64_t per_sample);
 int32_t gn_program_add_act(gn_program* p, const void* x, void* out, int64_t n, int32_t act);

@@ -51,3 +51,17 @@ def test_recorded_gemm_plan_can_be_read_back_and_replaced():
     E.synchronize()
     assert_close(y, ref, 1e-3)
     assert E.lib.gn_program_get_gemm(E._prog, n, C.byref(GemmDesc())) != 0           # out of range
+
+
+def test_add_multi_equals_the_single_adds():
+    """gn_add_multi: up to 16 independent f16 adds in one launch (the UNet's skip + ControlNet-residual additions), eager and recorded."""
+    for record in (False, True):
+        E = Engine("cuda:0", record=record)
+        shapes = [(2, 64, 64, 320)] * 3 + [(2, 32, 32, 640)] * 3 + [(2, 16, 16, 1280)] * 3 + [(2, 8, 8, 1280)] * 4
+        pairs = [(randn_h(*s, seed=2 * i), randn_h(*s, seed=2 * i + 1)) for i, s in enumerate(shapes)]
+        outs = E.add_multi(pairs, name="t")
+        if record:
+            E.run()
+        E.synchronize()
+        for (a, b), o in zip(pairs, outs):
+            assert torch.equal(o, (a.float() + b.float()).half())
