@@ -218,7 +218,8 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                 else:
                     n = E.layernorm(h, W[b + ".norm3.weight"], W[b + ".norm3.bias"], name="ln3")
                     g = E.linear(n, W[b + ".ff.net.0.proj.weight"], W[b + ".ff.net.0.proj.bias"], act=ACT_GEGLU, name="ffg")
-                if k == 0 and getattr(E, "k_append", True) and (p + ".ffo_pout.weight") in W and not E._fp8_weights:
+                if (f"{p}.transformer_blocks.{k + 1}.norm1.weight" not in W and getattr(E, "k_append", True) and (p + ".ffo_pout.weight") in W
+                        and not E._fp8_weights):
                     # the block's last Linear and the transformer's proj_out as one GEMM over [g | h] (packing `ffo_pout`, gn_gemm_desc.k_append)
                     out = E.linear(g, W[p + ".ffo_pout.weight"], W[p + ".ffo_pout.bias"], residual=x.view(B, N, Cc), append=h, name="ffpo")
                     return out.view(B, H, Wd, Cc)

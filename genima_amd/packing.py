@@ -367,15 +367,18 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16, up
             b = sd[base + ".conv2.bias"].detach().float() + sd[base + ".conv_shortcut.bias"].detach().float()
             out[base + ".conv2sc.bias"] = pack_vec(b, w2.shape[0], dtype=dtype)
     if dtype == torch.float16 and up_phases:
-        # Transformer2DModel with ONE BasicTransformerBlock and a Linear proj_out: proj_out(ff.net.2(g) + h) + x has no nonlinearity between its
+        # Transformer2DModel with a Linear proj_out: behind its last BasicTransformerBlock, proj_out(ff.net.2(g) + h) + x has no nonlinearity between its
         # two Linears, so it is ONE GEMM over [g | h] (gn_gemm_desc.k_append, dense) with the weight [W_po W_ff2 | W_po] and the bias
         # W_po b_ff2 + b_po -- the products in fp32, one rounding to f16.  Inference dicts only.
         for name in list(sd.keys()):
             if not name.endswith(".proj_out.weight") or sd[name].dim() != 2:
                 continue
             base = name[: -len(".proj_out.weight")]
-            f2 = base + ".transformer_blocks.0.ff.net.2"
-            if f2 + ".weight" not in sd or (base + ".transformer_blocks.1.norm1.weight") in sd or sd[f2 + ".weight"].shape[1] % 64 != 0:
+            last = 0  # the LAST block's ff.net.2 is the Linear in front of proj_out (SD-2.x: one block per transformer; SDXL: 2 or 10)
+            while (base + f".transformer_blocks.{last + 1}.norm1.weight") in sd:
+                last += 1
+            f2 = base + f".transformer_blocks.{last}.ff.net.2"
+            if f2 + ".weight" not in sd or sd[f2 + ".weight"].shape[1] % 64 != 0:
                 continue
             wpo, wf2 = sd[name].detach().double(), sd[f2 + ".weight"].detach().double()
             dev = out[name].device
