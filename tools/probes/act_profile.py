@@ -17,3 +17,20 @@ a.record()
 for _ in range(20): agent.act_tiled(tiled, state, tokens)
 b.record(); torch.cuda.synchronize()
 print(f"act_tiled: {a.elapsed_time(b) / 20:.3f} ms per call")
+# per-op table of the recorded ACT program (HIP events around every op of one replay)
+import collections
+io = agent._run(torch.stack([tiled[:, y:y + 256, x:x + 256] for (x, y) in ((0, 0), (256, 0), (0, 256), (256, 256))], dim=1), state, tokens)
+E = io.engine
+n = E.num_ops
+evs = [E.event() for _ in range(n + 1)]
+E.synchronize(); E.event_record(evs[0])
+for i in range(n):
+    E.run(i, i + 1); E.event_record(evs[i + 1])
+E.synchronize()
+agg = collections.defaultdict(lambda: [0, 0.0])
+for i, m in enumerate(E.meta[:n]):
+    k = (m["kind"], tuple(m["shape"]))
+    agg[k][0] += 1; agg[k][1] += E.event_elapsed_ms(evs[i], evs[i + 1])
+print(f"{n} ops, {sum(v[1] for v in agg.values()):.3f} ms op by op")
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+    print(f"{k[0]:12s} {'x'.join(map(str, k[1])):24s} {v[0]:4d} launches {v[1]*1e3:8.1f} us  ({v[1]*1e3/v[0]:.1f} each)")
