@@ -486,14 +486,29 @@ def main():
         gc.collect()  # the recorded programs sit in reference cycles: free them (and their device buffers) now, not inside a timed train step
         torch.cuda.empty_cache()
         try:
-            import bench_train
+            line = None
+            if world == 1 and os.environ.get("GN_BENCH_TRAIN_INPROC") != "1":
+                # one GPU: the train step is measured as `python bench_train.py --steps K --warmup 3` measures it, in a process of its own.
+                # In THIS process the step reads 3 - 4 ms slower once both inference extras have run (66.1 against 62.7 ms with either one
+                # left out, profiles/r04_v7_train_inline_bisect.txt): the streams and recorded programs they leave behind change which hardware
+                # queues the trainer's five streams land on -- a property of the bench script's history, not of the trainer.
+                import subprocess
 
-            targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "3"])  # (as `bench_train.py --steps 10 --warmup 3`: the trainer builds its lazily
-            # derived state -- weight copies, their one-launch table, gc.freeze -- in its first steps, and consecutive steps overlap)
-            line = bench_train.run(targs)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "3"],
+                                   capture_output=True, text=True, timeout=900)
+                tail = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and tail:
+                    line = json.loads(tail[-1])
+                    line["process"] = "bench_train.py in a process of its own"
+            if line is None:
+                import bench_train
+
+                targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "3"])  # (as `bench_train.py --steps 10 --warmup 3`: the trainer builds its lazily
+                # derived state -- weight copies, their one-launch table, gc.freeze -- in its first steps, and consecutive steps overlap)
+                line = bench_train.run(targs)
             if rank == 0 and line is not None:
                 out["train"] = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "samples_per_sec",
-                                                     "dtype", "config", "roofline", "peak_mem_gb", "loss_first", "loss_last", "scaling")}
+                                                     "dtype", "config", "roofline", "peak_mem_gb", "loss_first", "loss_last", "scaling", "process") if k in line}
         except Exception as e:
             if rank == 0:
                 out["train"] = {"error": repr(e)[:300]}
