@@ -490,8 +490,9 @@ def main():
             if world == 1 and os.environ.get("GN_BENCH_TRAIN_INPROC") != "1":
                 # one GPU: the train step is measured as `python bench_train.py --steps K --warmup 3` measures it, in a process of its own.
                 # In THIS process the step reads 3 - 4 ms slower once both inference extras have run (66.1 against 62.7 ms with either one
-                # left out, profiles/r04_v7_train_inline_bisect.txt): the streams and recorded programs they leave behind change which hardware
-                # queues the trainer's five streams land on -- a property of the bench script's history, not of the trainer.
+                # left out, profiles/r04_v7_train_inline_bisect.txt) -- a property of this script's history (what the extras leave behind in the
+                # process: recorded programs, captured graphs, streams, a large Python heap), not of the trainer; the cause is not located
+                # (not thermal: --warmup 40 reads the same; not the hardware-queue count: GPU_MAX_HW_QUEUES 2 / 4 / 8 read the same).
                 import subprocess
 
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "3"],
