@@ -486,7 +486,7 @@ def main():
         gc.collect()  # the recorded programs sit in reference cycles: free them (and their device buffers) now, not inside a timed train step
         torch.cuda.empty_cache()
         try:
-            line = None
+            line, fallback_note = None, ""
             if world == 1 and os.environ.get("GN_BENCH_TRAIN_INPROC") != "1":
                 # one GPU: the train step is measured as `python bench_train.py --steps K --warmup 3` measures it, in a process of its own.
                 # In THIS process the step reads 3 - 4 ms slower once both inference extras have run (66.1 against 62.7 ms with either one
@@ -501,12 +501,16 @@ def main():
                 if r.returncode == 0 and tail:
                     line = json.loads(tail[-1])
                     line["process"] = "bench_train.py in a process of its own"
+                else:  # the fallback below measures in THIS process: say so, and why (the two methods differ by 3 - 4 ms)
+                    fallback_note = f"subprocess rc {r.returncode}: {(r.stderr or r.stdout).strip()[-200:]}"
             if line is None:
                 import bench_train
 
                 targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "3"])  # (as `bench_train.py --steps 10 --warmup 3`: the trainer builds its lazily
                 # derived state -- weight copies, their one-launch table, gc.freeze -- in its first steps, and consecutive steps overlap)
                 line = bench_train.run(targs)
+                if line is not None:
+                    line["process"] = "in this process (after the inference extras)" + (f"; {fallback_note}" if fallback_note else "")
             if rank == 0 and line is not None:
                 out["train"] = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "samples_per_sec",
                                                      "dtype", "config", "roofline", "peak_mem_gb", "loss_first", "loss_last", "scaling", "process") if k in line}

@@ -679,12 +679,14 @@ bool pp_eligible(const gn_gemm_desc* d) {
 }
 
 // buffer-descriptor extents of the LDS-DMA variant (32-bit byte offsets; kOOB must stay out of range)
-struct DmaBytes { uint64_t a, a2, w; };
+struct DmaBytes { uint64_t a, a2, w, a3; };
 DmaBytes dma_bytes(const gn_gemm_desc* d) {
   DmaBytes b;
+  b.a3 = 0;
   if (d->conv) {
     const uint64_t px = (uint64_t)d->B * d->H * d->W;
     b.a = px * d->C1 * 2; b.a2 = px * d->C2 * 2;
+    if (d->k_append && d->a3) b.a3 = px * d->C3 * 2;  // the second appended source has a buffer descriptor of its own
   } else {
     b.a = (uint64_t)d->M * d->lda * 2; b.a2 = d->k_append ? (uint64_t)d->M * d->lda2 * 2 : 0;
   }
@@ -694,7 +696,7 @@ DmaBytes dma_bytes(const gn_gemm_desc* d) {
 bool dma_eligible(const gn_gemm_desc* d) {
   const DmaBytes b = dma_bytes(d);
   const uint64_t lim = 0xFFFFFF00ull;
-  if (b.a >= lim || b.a2 >= lim || b.w >= lim) return false;
+  if (b.a >= lim || b.a2 >= lim || b.w >= lim || b.a3 >= lim) return false;
   if (d->conv && d->a2 && !d->k_append && (d->C1 % 64 != 0 || (d->C1 + d->C2) % 64 != 0)) return false;  // a K tile must not straddle the concat
   return true;
 }
@@ -898,7 +900,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.kapp_k0 = d->conv ? d->KH * d->KW * d->C1 : (int)(d->K - d->C2);
   p.lda2 = d->lda2;
   p.a3 = d->k_append ? (const f16*)d->a3 : nullptr; p.C3 = d->k_append ? d->C3 : 0;
-  p.a3_bytes = p.a3 ? (unsigned)((uint64_t)d->B * d->H * d->W * d->C3 * 2) : p.a_bytes;
+  p.a3_bytes = p.a3 ? (unsigned)dma_bytes(d).a3 : p.a_bytes;  // (< 0xFFFFFF00: k_append requires dma_eligible)
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
 
   if (d->fp8) {

@@ -77,7 +77,16 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
         # ControlNet has been joined) AND the batch is too small to fill the chip, it runs there beside GroupNorm -> conv1 -> GroupNorm
         # ... unless it rides in conv2's K loop (one launch, no round trip of its output): gn_gemm_desc.k_append, packing `conv2sc` -- better
         # than the side stream at every batch size (single view 20.1 vs 20.8 ms, tiled B = 1 29.0 vs 29.9: profiles/r04_v6_side_free_ab.txt)
-        kapp = (has_sc and getattr(E, "k_append", True) and (p + ".conv2sc.weight") in W and x.dim() == 4
+        c1w, c2w = W[p + ".conv1.weight"], W[p + ".conv2.weight"]
+
+        def fuse(t, cout):  # GroupNorm-apply + SiLU inside the consuming conv's LDS patch (csrc/conv_gn.hip): the large, unconditioned convs
+            return (getattr(E, "conv_gn", True) and t.dim() == 4 and t.shape[1] * t.shape[2] >= getattr(E, "conv_gn_min_hw", 0)
+                    and E.conv2d_gn_supported(t, cout))
+
+        # conv2 on the fused GroupNorm route (conv_gn.hip) takes the shortcut as its epilogue residual, so the two routes are exclusive: where conv2
+        # will be fused the 1x1 shortcut stays its own launch (round 4 dropped it there: ADVICE r4, tests/test_conv_gn_gpu.py::test_vae_resnet_shortcut_routes)
+        fuse2 = x.dim() == 4 and fuse(x[..., :1].expand(*x.shape[:3], c1w.shape[0]), c2w.shape[0])
+        kapp = (has_sc and not fuse2 and getattr(E, "k_append", True) and (p + ".conv2sc.weight") in W and x.dim() == 4
                 and (x2 is None or x.shape[-1] % 64 == 0) and x.shape[0] * x.shape[1] * x.shape[2] >= getattr(E, "k_append_min_rows", 0))
         side = has_sc and not kapp and getattr(E, "side_free", False) and E.record
         if kapp:
@@ -93,18 +102,14 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
             sc = x
         sh, ld = _shift_for(W, shifts, p) if (p + ".time_emb_proj.weight") in W else (None, 0)
 
-        def fuse(t, cout):  # GroupNorm-apply + SiLU inside the consuming conv's LDS patch (csrc/conv_gn.hip): the large, unconditioned convs
-            return (getattr(E, "conv_gn", True) and t.dim() == 4 and t.shape[1] * t.shape[2] >= getattr(E, "conv_gn_min_hw", 0)
-                    and E.conv2d_gn_supported(t, cout))
-
-        c1w, c2w = W[p + ".conv1.weight"], W[p + ".conv2.weight"]
         if x2 is None and sh is None and fuse(x, c1w.shape[0]):
             st = E.groupnorm_stats(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, name="n1s")
             h = E.conv2d_gn(x, st, c1w, W[p + ".conv1.bias"], name="c1")
         else:
             h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, act=ACT_SILU, x2=x2, name="n1")
             h = E.conv2d(h, c1w, W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
-        if fuse(h, c2w.shape[0]):
+        if fuse2:
+            assert not kapp and tuple(h.shape) == tuple(x.shape[:3]) + (c1w.shape[0],)
             st = E.groupnorm_stats(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, name="n2s")
             if side:
                 E.join()

@@ -106,3 +106,35 @@ def test_vae_resnet_graph_with_and_without_the_fusion(engine):
     finally:
         engine.conv_gn, engine.conv_gn_min_hw = old
     assert rel_l2(y1, y0) < 3e-4, rel_l2(y1, y0)
+
+
+@pytest.mark.parametrize("conv_gn,k_append", [(True, True), (True, False), (False, True), (False, False)])
+def test_vae_resnet_shortcut_routes(engine, conv_gn, k_append):
+    """ResnetBlock2D with conv_shortcut (Cin != Cout: the VAE decoder's up_blocks.2/3.resnets.0 inside `self.pipe(...)`,
+    controller/agent/sd_controlnet_agent.py:67-76) on every combination of the fused-GroupNorm conv2 route and the k_append route, against torch
+    fp32 on the same f16-rounded parameters.  Round 4's graph dropped conv_shortcut(x) when both routes applied: the dict is packed
+    with pack_state_dict so `conv2sc` exists, and conv_gn_min_hw = 0 puts the small test image on the fused route."""
+    from genima_amd import graphs
+
+    g = torch.Generator().manual_seed(13)
+    Cin, Cout, G = 256, 128, 32
+    sd = {"r.norm1.weight": 1.0 + 0.1 * torch.randn(Cin, generator=g), "r.norm1.bias": 0.1 * torch.randn(Cin, generator=g),
+          "r.conv1.weight": torch.randn(Cout, Cin, 3, 3, generator=g) * (9 * Cin) ** -0.5, "r.conv1.bias": 0.1 * torch.randn(Cout, generator=g),
+          "r.norm2.weight": 1.0 + 0.1 * torch.randn(Cout, generator=g), "r.norm2.bias": 0.1 * torch.randn(Cout, generator=g),
+          "r.conv2.weight": torch.randn(Cout, Cout, 3, 3, generator=g) * (9 * Cout) ** -0.5, "r.conv2.bias": 0.1 * torch.randn(Cout, generator=g),
+          "r.conv_shortcut.weight": torch.randn(Cout, Cin, 1, 1, generator=g) * Cin ** -0.5, "r.conv_shortcut.bias": 0.1 * torch.randn(Cout, generator=g)}
+    sd = {k: q16(v) for k, v in sd.items()}
+    W = packing.pack_state_dict(sd, "cuda")
+    assert "r.conv2sc.weight" in W, "pack_state_dict must emit the k_append weight for blocks with a conv_shortcut"
+    x = q16(torch.randn(2, Cin, 16, 32, generator=g) * 1.3)
+    h = F.conv2d(F.silu(F.group_norm(x, G, sd["r.norm1.weight"], sd["r.norm1.bias"], 1e-6)), sd["r.conv1.weight"], sd["r.conv1.bias"], padding=1)
+    h = F.conv2d(F.silu(F.group_norm(h, G, sd["r.norm2.weight"], sd["r.norm2.bias"], 1e-6)), sd["r.conv2.weight"], sd["r.conv2.bias"], padding=1)
+    ref = h + F.conv2d(x, sd["r.conv_shortcut.weight"], sd["r.conv_shortcut.bias"])
+    old = engine.conv_gn, engine.conv_gn_min_hw, engine.k_append
+    try:
+        engine.conv_gn, engine.conv_gn_min_hw, engine.k_append = conv_gn, 0, k_append
+        y = graphs.emit_resnet(engine, W, "r", _nhwc(x).half().cuda(), None, None, G, 1e-6)
+    finally:
+        engine.conv_gn, engine.conv_gn_min_hw, engine.k_append = old
+    # 2e-3: two f16-stored intermediates (the bar of the whole-network tests); a dropped shortcut is an error of order 1
+    assert rel_l2(_nhwc_to_nchw(y), ref) < 2e-3, (conv_gn, k_append, rel_l2(_nhwc_to_nchw(y), ref))
