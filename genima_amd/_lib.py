@@ -22,6 +22,18 @@ class GenimaHipError(RuntimeError):
     pass
 
 
+class StatsSink(C.Structure):
+    """gn_stats_sink: the producer side of the GroupNorm bridge (include/genima_hip.h)."""
+    _fields_ = [("stats", C.c_void_p), ("cpg", C.c_int32), ("coff", C.c_int32), ("groups", C.c_int32), ("rows_per_sample", C.c_int32),
+                ("samples", C.c_int32), ("replicas", C.c_int32)]
+
+
+class NormIn(C.Structure):
+    """gn_norm_in: the consumer side of the GroupNorm bridge."""
+    _fields_ = [("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("groups", C.c_int32),
+                ("cpg", C.c_int32), ("act", C.c_int32), ("rows_per_sample", C.c_int32), ("samples", C.c_int32), ("replicas", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("a", C.c_void_p), ("a2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("shift", C.c_void_p),
@@ -40,6 +52,7 @@ class GemmDesc(C.Structure):
         ("out2", C.c_void_p), ("ldo2", C.c_int64), ("split_n", C.c_int32),
         ("ln_eps", C.c_float), ("ln_c1", C.c_void_p), ("out_row_width", C.c_int32), ("ldo_hi", C.c_int64), ("up_phases", C.c_int32),
         ("k_append", C.c_int32), ("a3", C.c_void_p), ("C3", C.c_int32), ("lda2", C.c_int64),
+        ("sink", StatsSink), ("norm_in", NormIn),
     ]
 
 
@@ -66,7 +79,7 @@ class GroupNormDesc(C.Structure):
         ("workspace", C.c_void_p),
         ("B", C.c_int32), ("HW", C.c_int32), ("C1", C.c_int32), ("C2", C.c_int32), ("groups", C.c_int32),
         ("act", C.c_int32), ("eps", C.c_float),
-        ("save_stats", C.c_void_p), ("save_scsh", C.c_void_p),
+        ("save_stats", C.c_void_p), ("save_scsh", C.c_void_p), ("stats_in", C.c_void_p), ("stats_replicas", C.c_int32),
     ]
 
 
@@ -116,6 +129,13 @@ SIGNATURES = {
     "gn_ctx_set_stream": (_I32, [_P, _P]),
     "gn_gemm_workspace_bytes": (_I64, [C.POINTER(GemmDesc)]),
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
+    "gn_gemm_norm_in_supported": (_I32, [C.POINTER(GemmDesc)]),
+    "gn_add_multi_stats": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32]),
+    "gn_program_set_sink": (_I32, [_P, _I64, _I32, C.POINTER(StatsSink), _I32]),
+    "gn_program_add_memset": (_I32, [_P, _P, _I64]),
+    "gn_program_set_memset_bytes": (_I32, [_P, _I64, _I64]),
+    "gn_memset": (_I32, [_P, _P, _I64]),
+    "gn_desc_sizeof": (_I64, [_I32]),
     "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
     "gn_tblock_tape_bytes": (_I64, [_I32, _I32]),
@@ -267,6 +287,10 @@ def load() -> C.CDLL:
             raise GenimaHipError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
+    for which, cls in enumerate((GemmDesc, AttnDesc, GroupNormDesc, TBlockDesc, ConvGnDesc, StatsSink, NormIn)):
+        if int(lib.gn_desc_sizeof(which)) != C.sizeof(cls):  # a stale .so against newer Python (or the reverse) would read garbage descriptors
+            raise GenimaHipError(f"{LIB_PATH}: sizeof({cls.__name__}) is {int(lib.gn_desc_sizeof(which))} in the library, {C.sizeof(cls)} in the "
+                                 "binding (stale build? run `python -m genima_amd.build`)")
     _lib = lib
     return lib
 

@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, h) for h in ("common.h", "gemm_common.h", "attention_common.h")] + [os.path.join(HERE, "..", "include", "genima_hip.h")]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "gemm_common.h", "attention_common.h", "gn_bridge.h")] + [os.path.join(HERE, "..", "include", "genima_hip.h")]
 
     def compile_one(src):
         s = os.path.join(CSRC, src)

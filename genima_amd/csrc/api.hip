@@ -20,7 +20,7 @@ namespace {
 enum OpType {
   OP_GEMM = 0, OP_ATTN, OP_GROUPNORM, OP_LAYERNORM, OP_TEMB, OP_SCALE_PAD, OP_EULER, OP_F16_TO_U8, OP_U8_TO_F16, OP_ADD,
   OP_ACT, OP_EMBED, OP_SOFTMAX, OP_MAXPOOL, OP_NORMALIZE_U8, OP_GATHER_ROWS, OP_COPY4D, OP_ARGMAX, OP_ADD_NOISE, OP_FILM, OP_SCALE_CAT_PAD,
-  OP_TBLOCK, OP_CONV_GN, OP_ADD_MULTI,
+  OP_TBLOCK, OP_CONV_GN, OP_ADD_MULTI, OP_MEMSET,
   OP_FORK, OP_MAIN, OP_JOIN  // stream control: ops after FORK go to the program's side stream until MAIN; JOIN makes main wait for it
 };
 
@@ -33,7 +33,10 @@ struct GenericArgs {  // argument block of the small ops
   float g[6];     // normalize: mul[3], add[3]
 };
 
-struct AddMultiOp { const void* a[GN_ADD_MULTI_MAX]; const void* b[GN_ADD_MULTI_MAX]; void* out[GN_ADD_MULTI_MAX]; int64_t n[GN_ADD_MULTI_MAX]; int32_t count; };
+struct AddMultiOp {
+  const void* a[GN_ADD_MULTI_MAX]; const void* b[GN_ADD_MULTI_MAX]; void* out[GN_ADD_MULTI_MAX]; int64_t n[GN_ADD_MULTI_MAX]; int32_t count;
+  int32_t C[GN_ADD_MULTI_MAX]; gn_stats_sink sink[GN_ADD_MULTI_MAX]; int32_t has_sink;  // GroupNorm bridge (gn_program_set_sink)
+};
 
 struct Op {
   int type;
@@ -75,7 +78,10 @@ static int32_t run_op(gn_ctx* ctx, const Op& op) {
     case OP_F16_TO_U8: return gn_image_f16_to_u8(ctx, g.p0, (uint8_t*)g.p3, g.n0, g.i0);
     case OP_U8_TO_F16: return gn_image_u8_to_f16(ctx, (const uint8_t*)g.p0, g.p3, g.n0, g.i0, g.f0, g.f1);
     case OP_ADD: return gn_add(ctx, g.p0, g.p1, g.p3, g.n0);
-    case OP_ADD_MULTI: return gn_add_multi(ctx, op.addm.a, op.addm.b, op.addm.out, op.addm.n, op.addm.count);
+    case OP_ADD_MULTI:
+      if (op.addm.has_sink) return gn_add_multi_stats(ctx, op.addm.a, op.addm.b, op.addm.out, op.addm.n, op.addm.C, op.addm.sink, op.addm.count);
+      return gn_add_multi(ctx, op.addm.a, op.addm.b, op.addm.out, op.addm.n, op.addm.count);
+    case OP_MEMSET: return gn_memset(ctx, g.p3, g.n0);
     case OP_ACT: return gn_act(ctx, g.p0, g.p3, g.n0, g.i0);
     case OP_FILM: return gn_film(ctx, g.p0, g.p3, g.p1, g.p2, g.m[0], g.m[1], g.n0, g.i0, g.i1);
     case OP_EMBED: return gn_embedding(ctx, (const int32_t*)g.p0, g.p1, g.p2, g.p3, g.i0, g.i1, g.i2);
@@ -319,6 +325,54 @@ int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_
   GN_REQUIRE(gn_gemm_workspace_bytes(&d) == 0 || d.workspace, "gn_program_set_gemm_plan: this plan splits K and needs a workspace");
   p->ops[(size_t)op].gemm = d;
   return GN_OK;
+}
+
+int32_t gn_program_set_sink(gn_program* p, int64_t op, int32_t index, const gn_stats_sink* sink, int32_t channels) {
+  GN_REQUIRE(p && sink && op >= 0 && op < (int64_t)p->ops.size(), "gn_program_set_sink: bad argument");
+  GN_REQUIRE(!p->exec, "gn_program_set_sink: the program is captured");
+  Op& o = p->ops[(size_t)op];
+  if (o.type == OP_GEMM) {
+    GN_REQUIRE(index == 0 && !o.gemm.sink.stats, "gn_program_set_sink: a gn_gemm op has one output and takes one sink");
+    GN_REQUIRE(o.gemm.out_mode == GN_OUT_ROWMAJOR && !o.gemm.out2 && o.gemm.act != GN_ACT_GEGLU && !o.gemm.fp8 && (o.gemm.batch <= 1 || o.gemm.up_phases),
+               "gn_program_set_sink: this gn_gemm does not write a plain row-major f16 tensor");
+    o.gemm.sink = *sink;
+    return GN_OK;
+  }
+  if (o.type == OP_ADD_MULTI) {
+    GN_REQUIRE(index >= 0 && index < o.addm.count && !o.addm.sink[index].stats && channels > 0 && channels % 8 == 0 && o.addm.n[index] % channels == 0,
+               "gn_program_set_sink: bad gn_add_multi tensor index / channel count");
+    for (int i = 0; i < o.addm.count; ++i)
+      if (o.addm.C[i] == 0) o.addm.C[i] = 8;  // tensors without a sink: any row shape
+    o.addm.C[index] = channels;
+    o.addm.sink[index] = *sink;
+    o.addm.has_sink = 1;
+    return GN_OK;
+  }
+  gn_set_error("gn_program_set_sink: op %ld is neither a gn_gemm nor a gn_add_multi", (long)op);
+  return GN_ERR_INVALID;
+}
+int32_t gn_program_set_memset_bytes(gn_program* p, int64_t op, int64_t bytes) {
+  GN_REQUIRE(p && op >= 0 && op < (int64_t)p->ops.size() && p->ops[(size_t)op].type == OP_MEMSET && bytes > 0 && bytes <= p->ops[(size_t)op].g.n0,
+             "gn_program_set_memset_bytes: op %ld is not a memset of at least %ld bytes", (long)op, (long)bytes);
+  GN_REQUIRE(!p->exec, "gn_program_set_memset_bytes: the program is captured");
+  p->ops[(size_t)op].g.n0 = bytes;
+  return GN_OK;
+}
+int64_t gn_desc_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(gn_gemm_desc);
+    case 1: return (int64_t)sizeof(gn_attn_desc);
+    case 2: return (int64_t)sizeof(gn_groupnorm_desc);
+    case 3: return (int64_t)sizeof(gn_tblock_desc);
+    case 4: return (int64_t)sizeof(gn_conv3x3_gn_desc);
+    case 5: return (int64_t)sizeof(gn_stats_sink);
+    case 6: return (int64_t)sizeof(gn_norm_in);
+    default: return -1;
+  }
+}
+int32_t gn_program_add_memset(gn_program* p, void* ptr, int64_t bytes) {
+  GN_REQUIRE(ptr && bytes > 0, "gn_program_add_memset: null / empty");
+  return push_generic(p, OP_MEMSET, nullptr, nullptr, nullptr, ptr, bytes, 0, 0, 0, 0, 0, 0.f, 0.f);
 }
 
 static int32_t ensure_side_stream(gn_program* p) {

@@ -2,6 +2,7 @@
 // elementwise ops, image pre/post-processing, residual adds, CLIP embedding gather, row softmax (VAE attention), max-pool.
 // All f16 storage / f32 math, 16-byte accesses where the layout allows.
 #include "common.h"
+#include "gn_bridge.h"
 
 namespace {
 
@@ -164,6 +165,67 @@ __global__ void add_multi_kernel(const AddMultiArgs p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (f16)((float)va[e] + (float)vb[e]);
     out[i] = *reinterpret_cast<uint4*>(&o);
+  }
+}
+
+// the same adds as producers of the GroupNorm bridge (gn_bridge.h): tensor t is [rows][C] and a block owns a slab of rows x all channels
+// (coalesced 16-byte chunks, the (chunk, pixel-lane) thread map of norm.hip's statistics kernel), so the sums of what it stores are a fixed-
+// order LDS reduction + at most 2 x groups integer atomics per block
+struct AddMultiStatsArgs { AddMultiArgs base; int C[GN_ADD_MULTI_MAX]; GnSinkP sink[GN_ADD_MULTI_MAX]; };
+__global__ __launch_bounds__(256) void add_multi_stats_kernel(const AddMultiStatsArgs p) {
+  extern __shared__ float lds[];  // [PY][C] sums, [PY][C] squares
+  const int t = blockIdx.y, tid = threadIdx.x;
+  const int C = p.C[t], CC = C >> 3;
+  const long rows = p.base.n8[t] / CC;
+  const long rows_blk = (rows + gridDim.x - 1) / gridDim.x;
+  const long r0 = (long)blockIdx.x * rows_blk, r1 = r0 + rows_blk < rows ? r0 + rows_blk : rows;
+  if (r0 >= rows) return;  // (block-uniform)
+  const uint4* __restrict__ a = p.base.a[t];
+  const uint4* __restrict__ b = p.base.b[t];
+  uint4* __restrict__ out = p.base.out[t];
+  const GnSinkP sk = p.sink[t];
+  const int TX = CC < 256 ? CC : 256, PY = 256 / TX;
+  const int cxt = tid % TX, py = tid / TX;
+  float* lsum = lds;
+  float* lsq = lds + PY * C;
+  const long rps = sk.stats ? sk.rps : rows;
+  for (long sb = r0 / rps; sb <= (r1 - 1) / rps; ++sb) {
+    const long s0 = r0 > sb * rps ? r0 : sb * rps, s1 = r1 < (sb + 1) * rps ? r1 : (sb + 1) * rps;
+    if (py < PY) {
+      for (int cx = cxt; cx < CC; cx += TX) {
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        for (long r = s0 + py; r < s1; r += PY) {
+          const uint4 ra = a[r * CC + cx], rb = b[r * CC + cx];
+          const f16x8 va = *reinterpret_cast<const f16x8*>(&ra), vb = *reinterpret_cast<const f16x8*>(&rb);
+          f16x8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            o[e] = (f16)((float)va[e] + (float)vb[e]);
+            const float f = (float)o[e];
+            s[e] += f;
+            q[e] += f * f;
+          }
+          out[r * CC + cx] = *reinterpret_cast<uint4*>(&o);
+        }
+        if (sk.stats) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { lsum[py * C + cx * 8 + e] = s[e]; lsq[py * C + cx * 8 + e] = q[e]; }
+        }
+      }
+    }
+    if (!sk.stats) continue;  // (block-uniform)
+    __syncthreads();
+    const int g0 = sk.coff / sk.cpg, g1 = (sk.coff + C - 1) / sk.cpg;
+    for (int g = g0 + tid; g <= g1; g += 256) {
+      const int c0 = max(g * sk.cpg - sk.coff, 0), c1 = min((g + 1) * sk.cpg - sk.coff, C);
+      float sa = 0.f, sq = 0.f;
+      for (int c = c0; c < c1; ++c)
+        for (int y = 0; y < PY; ++y) { sa += lsum[y * C + c]; sq += lsq[y * C + c]; }
+      gn_stats_add(sk.stats + gn_stats_line((int)(blockIdx.x % sk.reps), (int)sb, g, sk.nb, sk.groups), sa, sq);
+    }
+    __syncthreads();
   }
 }
 
@@ -403,6 +465,45 @@ int32_t gn_add_multi(gn_ctx* ctx, const void* const* a, const void* const* b, vo
   if (blocks > 2048) blocks = 2048;  // (grid-stride: the largest tensor sets the x extent, smaller ones leave their tail blocks idle)
   hipLaunchKernelGGL(add_multi_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_add_multi_stats(gn_ctx* ctx, const void* const* a, const void* const* b, void* const* out, const int64_t* n, const int32_t* C,
+                           const gn_stats_sink* sinks, int32_t count) {
+  GN_REQUIRE(ctx && a && b && out && n && C && count >= 1 && count <= GN_ADD_MULTI_MAX, "gn_add_multi_stats: 1 .. %d tensors", GN_ADD_MULTI_MAX);
+  AddMultiStatsArgs p;
+  long rmax = 0;
+  size_t lds = 0;
+  for (int i = 0; i < count; ++i) {
+    GN_REQUIRE(a[i] && b[i] && out[i] && n[i] > 0 && C[i] > 0 && C[i] % 8 == 0 && n[i] % C[i] == 0, "gn_add_multi_stats: tensor %d: [rows x C] with C %% 8 == 0", i);
+    p.base.a[i] = (const uint4*)a[i]; p.base.b[i] = (const uint4*)b[i]; p.base.out[i] = (uint4*)out[i]; p.base.n8[i] = (long)(n[i] / 8);
+    p.C[i] = C[i];
+    gn_stats_sink none = {nullptr, 1, 0, 1, 1, 1, 1};
+    const gn_stats_sink& s = sinks ? sinks[i] : none;
+    p.sink[i] = gn_sink_params(s);
+    const long rows = (long)(n[i] / C[i]);
+    if (s.stats) {
+      GN_REQUIRE(s.cpg > 0 && s.groups > 0 && s.coff >= 0 && s.rows_per_sample > 0 && rows % s.rows_per_sample == 0 && ((uintptr_t)s.stats & 7) == 0 &&
+                     (int64_t)s.coff + C[i] <= (int64_t)s.cpg * s.groups && s.samples == rows / s.rows_per_sample && s.replicas >= 1,
+                 "gn_add_multi_stats: tensor %d: bad sink", i);
+      const int cc = C[i] / 8, tx = cc < 256 ? cc : 256;
+      const size_t need = (size_t)2 * (256 / tx) * C[i] * sizeof(float);
+      lds = need > lds ? need : lds;
+    }
+    rmax = rows > rmax ? rows : rmax;
+  }
+  GN_REQUIRE(lds <= 64 * 1024, "gn_add_multi_stats: C too large for the statistics slab");
+  long blocks = (rmax + 31) / 32;  // >= 32 rows per block: at most 2 x groups atomics per 32 rows
+  if (blocks > 512) blocks = 512;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(add_multi_stats_kernel, dim3((unsigned)blocks, (unsigned)count), dim3(256), lds, ctx->stream, p);
+  GN_LAUNCH_CHECK();
+  return GN_OK;
+}
+
+int32_t gn_memset(gn_ctx* ctx, void* ptr, int64_t bytes) {
+  GN_REQUIRE(ctx && ptr && bytes > 0, "gn_memset: null / empty");
+  GN_HIP(hipMemsetAsync(ptr, 0, (size_t)bytes, ctx->stream));
   return GN_OK;
 }
 

@@ -211,7 +211,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
     cur ^= 1;
   }
 
-  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z);
+  constexpr int SMEM = 2 * (A_BYTES + B_BYTES);
+  gemm_epilogue<TM, TN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, gemm_sink_lds<BM, BN, SMEM>(p, m0, n0, smem));
+  gemm_sink_tail<NT, BM, BN, SMEM>(p, m0, n0, smem);
 }
 
 // ======================================================================================================================
@@ -467,7 +469,9 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 12
   if constexpr (LNF)  // (the barrier that ended the K loop freed the LDS tiles)
     ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn,
                                   reinterpret_cast<const float*>(smem + 2 * (A_BYTES + B_BYTES)) + wn * WTN, l31, hi);
-  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
+  constexpr int SMEM = 2 * (A_BYTES + B_BYTES);
+  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre, gemm_sink_lds<BM, BN, SMEM>(p, m0, n0, smem));
+  gemm_sink_tail<NW * 64, BM, BN, SMEM>(p, m0, n0, smem);
 }
 
 // ======================================================================================================================
@@ -622,6 +626,53 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   epilogue_store4(p, m, nb, s[0], s[1], s[2], s[3]);
 }
 
+// the same reduce for a producer of the GroupNorm bridge (GemmParams.sink): a block owns an 8-row x 128-column patch of the output (512-byte
+// row pieces of the partial slabs, as many blocks as the plain reduce), so the statistics of what it stores are a column sum through LDS + a
+// handful of atomics per block (gn_bridge.h)
+__global__ __launch_bounds__(256) void splitk_reduce_sink_kernel(const GemmParams p) {
+  __shared__ float ls[8][129], lq[8][129];
+  __shared__ float cs[2][128];
+  const int t = threadIdx.x;
+  const int r = t >> 5, c4 = (t & 31) * 4;
+  const int m0 = blockIdx.y * 8, n0 = blockIdx.x * 128;
+  const int m = m0 + r, nb = n0 + c4;
+  float o[4] = {0.f, 0.f, 0.f, 0.f};
+  if (m < p.M && nb < p.N) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.splitk; ++z) s += *reinterpret_cast<const f32x4*>(p.ws + ((long)z * p.M + m) * p.N + nb);
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    int bidx;
+    epilogue_vals4(p, m, nb, v, bidx);
+    f16x4 h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h[i] = (f16)v[i]; o[i] = (float)h[i]; }
+    *reinterpret_cast<f16x4*>(p.out + out_row_off(p, m) + nb) = h;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { ls[r][c4 + i] = o[i]; lq[r][c4 + i] = o[i] * o[i]; }
+  __syncthreads();
+  const int mend = min(m0 + 8, p.M), nend = min(n0 + 128, p.N);
+  for (int b = m0 / p.sink.rps; b <= (mend - 1) / p.sink.rps; ++b) {
+    const int r0 = max(m0, b * p.sink.rps) - m0, r1 = min(mend, (b + 1) * p.sink.rps) - m0;
+    if (t < 128) {
+      float a = 0.f, q = 0.f;
+      for (int rr = r0; rr < r1; ++rr) { a += ls[rr][t]; q += lq[rr][t]; }
+      cs[0][t] = a;
+      cs[1][t] = q;
+    }
+    __syncthreads();
+    const int g0 = (p.sink.coff + n0) / p.sink.cpg, g1 = (p.sink.coff + nend - 1) / p.sink.cpg;
+    if (t <= g1 - g0) {
+      const int g = g0 + t;
+      const int c0 = max(g * p.sink.cpg - p.sink.coff, n0) - n0, c1 = min((g + 1) * p.sink.cpg - p.sink.coff, nend) - n0;
+      float a = 0.f, q = 0.f;
+      for (int c = c0; c < c1; ++c) { a += cs[0][c]; q += cs[1][c]; }
+      gn_stats_add(p.sink.stats + gn_stats_line((int)(blockIdx.y % p.sink.reps), b, g, p.sink.nb, p.sink.groups), a, q);
+    }
+    __syncthreads();
+  }
+}
+
 template <int BM, int BN, int WM, int WN>
 void launch_cfg(const GemmParams& p, bool conv, hipStream_t st) {
   dim3 grid(p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1);
@@ -745,6 +796,17 @@ Plan plan_gemm(const gn_gemm_desc* d) {
     static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22};
     best = to_dma[best];
   }
+  if (d->norm_in.stats) {  // the normalising A path lives in the ring kernels (gemm_s3.hip): 15 .. 21 = {128x128, 128x64, 64x64, 256x64, 128x160, 64x160, 64x320}
+    static const int to_s3[kNumCfg] = {18, 15, 16, 17, 18, 15, 15, 18, 15, 16, 17, 18, 19, 19, 15, 15, 16, 17, 18, 19, 20, 21, 19};
+    best = to_s3[best];
+    // a row tile spans whole samples or lies inside one (the kernel's scale / shift table covers <= 4 of them)
+    const int64_t rps = d->conv ? (int64_t)d->Ho * d->Wo : d->norm_in.rows_per_sample;
+    if (rps > 0 && kCfg[best].bm > 4 * rps) best = kCfg[best].bn >= 160 ? 20 : 17;  // -> a 64-row tile
+    // the ring + the scale / shift table of the samples a row tile touches must fit the CU's 160 KB (launch_s3_gna): else the 64 x 64 ring
+    const int64_t ct = d->conv ? (d->k_append ? d->C1 : d->C1 + d->C2) : (d->k_append ? d->K - d->C2 : d->K);
+    auto lds_bytes = [&](int c) { return (int64_t)3 * (kCfg[c].bm + kCfg[c].bn) * 128 + (rps >= kCfg[c].bm ? 1 : kCfg[c].bm / (rps > 0 ? rps : 1)) * ct * 8; };
+    if (lds_bytes(best) > 160 * 1024) best = 17;
+  }
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
     static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1};
@@ -782,6 +844,29 @@ Plan plan_gemm(const gn_gemm_desc* d) {
 extern "C" int32_t gn_set_gemm_tile_override(int32_t cfg) {
   g_tile_override = cfg < 0 ? -1 : cfg;
   return GN_OK;
+}
+
+extern "C" int32_t gn_gemm_norm_in_supported(const gn_gemm_desc* d) {
+  if (!d || d->fp8 || d->ln_c1 || d->batch > 1 || d->up_phases || d->upsample2x || !dma_eligible(d)) return 0;
+  if (d->norm_in.groups <= 0 || d->norm_in.cpg <= 0 || d->norm_in.cpg % 2 != 0 || d->norm_in.rows_per_sample <= 0) return 0;
+  if (d->norm_in.act != GN_ACT_NONE && d->norm_in.act != GN_ACT_SILU) return 0;
+  int64_t ct, rps;
+  if (d->conv) {
+    if (d->C1 % 64 != 0 || (d->C2 % 64 != 0)) return 0;  // a K tile (one tap x 64 channels) never straddles a source or a tap
+    ct = d->k_append ? d->C1 : d->C1 + d->C2;
+    rps = (int64_t)d->Ho * d->Wo;
+    if ((int64_t)d->H * d->W != d->norm_in.rows_per_sample) return 0;
+  } else {
+    ct = d->k_append ? d->K - d->C2 : d->K;
+    rps = d->norm_in.rows_per_sample;
+    if (ct % 8 != 0) return 0;
+  }
+  if (ct != (int64_t)d->norm_in.groups * d->norm_in.cpg) return 0;
+  if (rps <= 0 || d->M % rps != 0 || d->norm_in.samples != d->M / rps) return 0;
+  // row tiles of 64 .. 256 rows must span whole samples or sit inside one: rps a power-of-two multiple / divisor of 64, at least 16 rows
+  if (rps < 16 || (rps & (rps - 1)) != 0) return 0;
+  if (4 * ct * 8 + 3 * (64 + 64) * 128 > 160 * 1024) return 0;  // table of up to 4 samples + the smallest ring
+  return 1;
 }
 
 extern "C" int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d) {
@@ -902,6 +987,28 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.a3 = d->k_append ? (const f16*)d->a3 : nullptr; p.C3 = d->k_append ? d->C3 : 0;
   p.a3_bytes = p.a3 ? (unsigned)dma_bytes(d).a3 : p.a_bytes;  // (< 0xFFFFFF00: k_append requires dma_eligible)
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
+  p.sink = gn_sink_params(d->sink);
+  if (d->sink.stats) {
+    GN_REQUIRE(d->out_mode == GN_OUT_ROWMAJOR && !d->out2 && !geglu && !d->fp8 && !d->ln_c1 && (d->batch <= 1 || d->up_phases),
+               "gn_gemm(sink): GroupNorm statistics come from plain row-major f16 outputs");
+    GN_REQUIRE(d->N % 8 == 0 && d->ldo % 8 == 0 && ((uintptr_t)d->out & 15) == 0 && (!d->out_row_width || d->ldo_hi % 8 == 0),
+               "gn_gemm(sink): the statistics tail re-reads the output in 16-byte pieces (N, ldo %% 8 == 0, 16-byte aligned out)");
+    GN_REQUIRE(d->sink.cpg > 0 && d->sink.groups > 0 && d->sink.coff >= 0 && d->sink.rows_per_sample > 0 && ((uintptr_t)d->sink.stats & 7) == 0 &&
+                   (int64_t)d->sink.coff + d->N <= (int64_t)d->sink.cpg * d->sink.groups && d->M % d->sink.rows_per_sample == 0 &&
+                   d->sink.samples == d->M / d->sink.rows_per_sample && d->sink.replicas >= 1 && ((uintptr_t)d->sink.stats & 127) == 0,
+               "gn_gemm(sink): cpg %d / coff %d / groups %d / rows_per_sample %d do not cover this output [%ld x %ld]", d->sink.cpg, d->sink.coff,
+               d->sink.groups, d->sink.rows_per_sample, (long)d->M, (long)d->N);
+  }
+  p.gin.stats = (const long long*)d->norm_in.stats; p.gin.gamma = (const f16*)d->norm_in.gamma; p.gin.beta = (const f16*)d->norm_in.beta;
+  p.gin.eps = d->norm_in.eps; p.gin.groups = d->norm_in.groups; p.gin.cpg = d->norm_in.cpg; p.gin.act = d->norm_in.act;
+  p.gin.rps = d->norm_in.rows_per_sample; p.gin.nb = d->norm_in.samples; p.gin.reps = d->norm_in.replicas > 0 ? d->norm_in.replicas : 1;
+  if (d->norm_in.stats) {
+    GN_REQUIRE(gn_gemm_norm_in_supported(d) && d->norm_in.gamma && d->norm_in.beta && ((uintptr_t)d->norm_in.stats & 7) == 0,
+               "gn_gemm(norm_in): unsupported problem (gn_gemm_norm_in_supported) or missing gamma / beta");
+    GN_REQUIRE(pl.cfg >= kCfgS3 && pl.cfg < kCfgS3End, "gn_gemm(norm_in): the plan must be a ring tile (16 .. 22)");
+    const int64_t rps = d->conv ? (int64_t)d->Ho * d->Wo : d->norm_in.rows_per_sample;
+    GN_REQUIRE(pl.bm <= 4 * rps, "gn_gemm(norm_in): a %d-row tile would span more than 4 samples of %ld rows", pl.bm, (long)rps);
+  }
 
   if (d->fp8) {
     GN_REQUIRE(!d->conv && d->batch <= 1 && d->out_mode == GN_OUT_ROWMAJOR,
@@ -950,7 +1057,10 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {
     const long total = (long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, p);
+    if (p.sink.stats)
+      hipLaunchKernelGGL(splitk_reduce_sink_kernel, dim3((unsigned)cdiv64(p.N, 128), (unsigned)cdiv64(p.M, 8)), dim3(256), 0, ctx->stream, p);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, p);
     GN_LAUNCH_CHECK();
   }
   return GN_OK;

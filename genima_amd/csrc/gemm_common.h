@@ -6,6 +6,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "gn_bridge.h"
 
 namespace {
 
@@ -46,7 +47,49 @@ struct GemmParams {
                                          // the output pixel of the appended sources a2 (C2 channels), then a3 (C3) -- the LDS-DMA kernels' loaders
   const f16* a3; int C3; unsigned a3_bytes;
   long lda2;                             // dense k_append: out = [A | A2] . W^T -- K tiles from kapp_k0 on read A2 (row stride lda2) through a2
+  GnSinkP sink;                          // GroupNorm bridge, producer side (gn_bridge.h): stats == nullptr = off
+  GnInP gin;                             // GroupNorm bridge, consumer side (gemm_s3.hip's normalising A path): stats == nullptr = off
 };
+
+// GroupNorm bridge, producer side (gn_bridge.h).  Where the workgroup's LDS can hold its f16 output tile, the epilogue's 16-byte row stores
+// are mirrored into that tile (SinkLds) and the statistics tail reads LDS -- no store drain, no memory round trip at the end of the small-M
+// launches the tail would otherwise dominate; the largest tiles (256 x 256 / 256 x 320) re-read their output from L2 instead.
+struct SinkLds { unsigned char* base = nullptr; int pitch = 0, m0 = 0, n0 = 0; };  // pitch in BYTES; base == nullptr: off
+constexpr int kSinkScratch = 20 * 1024;  // the tail's reduction scratch behind the tile
+constexpr int sink_pitch(int bn) { return (bn + 8) * 2; }
+#ifdef GN_SINK_NO_LDS
+constexpr bool sink_in_lds(int, int, int) { return false; }
+#else
+constexpr bool sink_in_lds(int bm, int bn, int smem_bytes) { return bm * sink_pitch(bn) + kSinkScratch <= smem_bytes; }
+#endif
+
+template <int BM, int BN, int SMEM>
+__device__ __forceinline__ SinkLds gemm_sink_lds(const GemmParams& p, int m0, int n0, unsigned char* smem) {
+  SinkLds sl;
+  if constexpr (sink_in_lds(BM, BN, SMEM)) {
+    if (p.sink.stats && p.splitk <= 1) { sl.base = smem; sl.pitch = sink_pitch(BN); sl.m0 = m0; sl.n0 = n0; }
+  }
+  return sl;
+}
+
+// the tail of a GEMM workgroup whose tile has gone through gemm_epilogue (row-major f16, no K split)
+template <int NT, int BM, int BN, int SMEM>
+__device__ __forceinline__ void gemm_sink_tail(const GemmParams& p, int m0, int n0, unsigned char* smem) {
+  if (p.sink.stats && p.splitk <= 1) {  // workgroup-uniform
+    const int mend = min(m0 + BM, p.M), nend = min(n0 + BN, p.N);
+    if constexpr (sink_in_lds(BM, BN, SMEM)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __syncthreads();  // every wave's mirrored rows are in the LDS tile
+      gn_sink_tile<NT, true>(p.sink, reinterpret_cast<const f16*>(smem), sink_pitch(BN) / 2, 0, 0, m0, mend, n0, nend, m0, n0,
+                             reinterpret_cast<float*>(smem + BM * sink_pitch(BN)), (SMEM - BM * sink_pitch(BN)) / 4, (m0 / BM) % p.sink.reps);
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's output stores are in L2
+      __syncthreads();                                  // ... every wave's; and nobody reads the K loop's LDS tiles any more
+      gn_sink_tile<NT, false>(p.sink, p.out, p.ldo, p.orw, p.ldo_hi, m0, mend, n0, nend, 0, 0, reinterpret_cast<float*>(smem), SMEM / 4,
+                              (m0 / BM) % p.sink.reps);
+    }
+  }
+}
 
 // the appended 1x1 segment of a k_append conv: source offset of staged row i for the K tile whose lane offset inside the segment is `co`
 // (iy0 / ix0 / pbase as the conv loaders keep them: the row's top-left tap coordinate and image base; rows >= M carry -(1 << 28))
@@ -304,7 +347,7 @@ constexpr bool epi_rich_fits(int tm, int tn, int budget) { return tm * tn * 16 +
 // the NEXT 32-row band requested before the current band's stores.  Otherwise the vectors are fetched tile by tile.
 template <int TM, int TN, bool RICH>
 __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31,
-                                                     int hi, const EpiPre<TM, TN>& pre, bool use_pre) {
+                                                     int hi, const EpiPre<TM, TN>& pre, bool use_pre, const SinkLds& sl) {
   constexpr bool PIPE = RICH && TM * TN <= 8;
   const bool pre_ok = RICH && use_pre;  // the residual of every band is already in registers (epilogue_prefetch)
   const bool has_shift = p.shift != nullptr, has_res = p.res != nullptr;
@@ -404,7 +447,11 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
           const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
           const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
           const int col = nbase + j * 32 + 8 * g + 8 * hi;
-          if (col < p.N) *reinterpret_cast<uint4*>(orow + col) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          if (col < p.N) {
+            const uint4 o4 = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            *reinterpret_cast<uint4*>(orow + col) = o4;
+            if (sl.base) *reinterpret_cast<uint4*>(sl.base + (m - sl.m0) * sl.pitch + (col - sl.n0) * 2) = o4;  // (wave-uniform) GroupNorm bridge
+          }
         }
       } else if (p.out_mode == GN_OUT_ROWMAJOR) {
         f16* orow = p.out + out_row_off(p, m);
@@ -453,7 +500,7 @@ __device__ __forceinline__ void gemm_epilogue_direct(const GemmParams& p, const 
 
 template <int TM, int TN, bool RICH = (TM * TN <= 4)>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi,
-                                              int z, const EpiPre<TM, TN>& pre, bool use_pre) {
+                                              int z, const EpiPre<TM, TN>& pre, bool use_pre, const SinkLds& sl = SinkLds{}) {
   if (p.splitk > 1) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -519,14 +566,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)
       }
     }
   } else {
-    gemm_epilogue_direct<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, pre, use_pre);
+    gemm_epilogue_direct<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, pre, use_pre, sl);
   }
 }
 
 template <int TM, int TN, bool RICH = (TM * TN <= 4)>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi, int z) {
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x16 (&acc)[TN][TM], int mbase, int nbase, int l31, int hi, int z,
+                                              const SinkLds& sl = SinkLds{}) {
   EpiPre<TM, TN> none;  // never read
-  gemm_epilogue<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, z, none, false);
+  gemm_epilogue<TM, TN, RICH>(p, acc, mbase, nbase, l31, hi, z, none, false, sl);
 }
 
 // ---- LayerNorm folded into the consuming Linear (gn_gemm_desc::ln_c1; SURVEY.md K7: "LN -> QKV without a round trip") ---------------------

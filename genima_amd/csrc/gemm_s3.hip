@@ -20,9 +20,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 #undef GN_VMCNT_CASE
 }
 
-template <int BM, int BN, int WM, int WN, bool CONV, bool LNF = false>
+// GNA (GroupNorm bridge, consumer side -- gn_gemm_desc.norm_in): A holds the RAW tensor a GroupNorm (+ SiLU) stands in front of.  Every lane
+// normalises the 16-byte pieces IT staged, in LDS, right after the counted wait that retires them and before the barrier that publishes the
+// tile -- no extra barrier, the MFMAs read the same f16 values a separate GroupNorm launch would have stored.  Pieces that the DMA zero-filled
+// (conv padding, rows / K past the end) stay zero: the conv pads the NORMALISED tensor.  The per-(sample, channel) scale / shift come from a
+// table in LDS behind the ring, built in the prologue from the producers' statistics block.  A tap is re-normalised for each of the KH*KW
+// taps that stage it: the route is for the small-M launches whose SIMDs wait on the weight stream anyway (the host gates it by rows).
+template <int BM, int BN, int WM, int WN, bool CONV, bool LNF = false, bool GNA = false>
 __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 128, WM* WN)) void gemm_s3_kernel(const GemmParams pin) {
   static_assert(!LNF || (!CONV && 4 % WN == 0), "LayerNorm fold: dense problems, K steps dealt over 1 / 2 / 4 column waves");
+  static_assert(!(LNF && GNA), "one normalisation per launch");
   const GemmParams p = batch_offset(pin);
   constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -32,7 +39,16 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   constexpr int GA = BM / 8 / NW, GB = BN / 8 / NW;  // DMA instructions per wave per tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128;
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[3 * (A_BYTES + B_BYTES) + (LNF ? BN * 4 : 0)];  // ONE LDS object (a second one makes hipcc drain vmcnt)
+  // ONE LDS object per instantiation (a second one makes hipcc drain vmcnt): static, or -- GNA: the scale / shift table's size follows the
+  // input's channel count -- the dynamic one
+  unsigned char* smem;
+  if constexpr (GNA) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_dyn[];
+    smem = smem_dyn;
+  } else {
+    __shared__ __attribute__((aligned(16))) unsigned char smem_static[3 * (A_BYTES + B_BYTES) + (LNF ? BN * 4 : 0)];
+    smem = smem_static;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -123,6 +139,87 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_a3 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a3 ? p.a3 : p.a), 0, (int)p.a3_bytes, 0x00020000);  // k_append: second appended source
 
+  // ---- GNA: scale / shift table [S][Ct] (float2) behind the ring; per staged tile the lane's channel offset and the validity bits of its
+  // pieces ride in a two-entry register FIFO from dma_tile (issue) to norm_tile (two tiles later)
+  [[maybe_unused]] const float2* tab = reinterpret_cast<const float2*>(smem + 3 * (A_BYTES + B_BYTES));
+  [[maybe_unused]] int trow[GA];
+  [[maybe_unused]] int gi_c0 = 0, gi_c1 = 0;
+  [[maybe_unused]] unsigned gi_m0 = 0u, gi_m1 = 0u;
+  [[maybe_unused]] bool one_sample = true;
+  if constexpr (GNA) {
+    const int Ct = CONV ? Cin : (p.kapp ? p.kapp_k0 : p.K);  // channels the GroupNorm covers (an appended k_append segment stays raw)
+    const int rps_out = CONV ? p.Ho * p.Wo : p.gin.rps;       // rows of this GEMM per sample
+    const int b0 = m0 / rps_out, b1 = (min(m0 + BM, p.M) - 1) / rps_out;
+    const int S = b1 - b0 + 1;
+    one_sample = S == 1;
+#pragma unroll
+    for (int i = 0; i < GA; ++i) {
+      const int m = min(m0 + 8 * (wave + NW * i) + lr, p.M - 1);
+      trow[i] = (m / rps_out - b0) * Ct;
+    }
+    // (mean, rstd) of the S x groups slabs first -- into the head of the still empty ring --, then the per-channel pairs, 8 channels a thread
+    float2* gst = reinterpret_cast<float2*>(smem);
+    const double inv_count = 1.0 / ((double)p.gin.rps * (double)p.gin.cpg);
+    for (int idx = tid; idx < S * p.gin.groups; idx += NW * 64) {
+      const int sb = idx / p.gin.groups, g = idx - sb * p.gin.groups;
+      float mean, rstd;
+      gn_group_mean_rstd(p.gin.stats, b0 + sb, g, p.gin.nb, p.gin.groups, p.gin.reps, inv_count, p.gin.eps, mean, rstd);
+      gst[idx] = make_float2(mean, rstd);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float2* wtab = reinterpret_cast<float2*>(smem + 3 * (A_BYTES + B_BYTES));
+    const int C8 = Ct >> 3;
+    for (int idx = tid; idx < S * C8; idx += NW * 64) {
+      const int sb = idx / C8, c = (idx - sb * C8) * 8;
+      const uint4 graw = *reinterpret_cast<const uint4*>(p.gin.gamma + c), braw = *reinterpret_cast<const uint4*>(p.gin.beta + c);
+      const f16x8 gv = *reinterpret_cast<const f16x8*>(&graw), bv = *reinterpret_cast<const f16x8*>(&braw);
+      int g = c / p.gin.cpg, gend = (g + 1) * p.gin.cpg;
+      float2 ms = gst[sb * p.gin.groups + g];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (c + e >= gend) { ++g; gend += p.gin.cpg; ms = gst[sb * p.gin.groups + g]; }
+        const float sc = ms.y * (float)gv[e];
+        wtab[sb * Ct + c + e] = make_float2(sc, (float)bv[e] - ms.x * sc);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // nothing of the table is in flight when the counted DMA ring starts
+    __builtin_amdgcn_s_barrier();                                 // ... and gst (the ring's head) is free for the first DMA
+  }
+  // normalise the pieces of the tile in slot `buf` that THIS lane staged (call after the counted wait that retired them)
+  auto norm_tile = [&](int buf) __attribute__((always_inline)) {
+    if constexpr (GNA) {
+      const unsigned vm = gi_m0;
+      if (vm) {
+        unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
+        const int c = gi_c0;
+        const bool silu = p.gin.act == GN_ACT_SILU;
+        float sc[8], sh[8];
+        auto load_tab = [&](int base) __attribute__((always_inline)) {
+          const f32x4* t4 = reinterpret_cast<const f32x4*>(tab + base + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const f32x4 q = t4[e];
+            sc[2 * e] = q[0]; sh[2 * e] = q[1]; sc[2 * e + 1] = q[2]; sh[2 * e + 1] = q[3];
+          }
+        };
+        if (one_sample) load_tab(0);
+#pragma unroll
+        for (int i = 0; i < GA; ++i) {
+          if ((vm >> i) & 1u) {
+            if (!one_sample) load_tab(trow[i]);
+            f16x8* q = reinterpret_cast<f16x8*>(As + (wave + NW * i) * 1024 + lane * 16);
+            *q = gn_apply8(*q, sc, sh, silu);
+          }
+        }
+      }
+    }
+  };
+  // dma_tile's side of the FIFO: the tile being issued has channel offset c (inside the GroupNorm's channel range) and live-piece bits m
+  auto gna_push = [&](int c, unsigned m) __attribute__((always_inline)) {
+    if constexpr (GNA) { gi_c0 = gi_c1; gi_m0 = gi_m1; gi_c1 = c; gi_m1 = m; }
+  };
+
   auto dma_tile = [&](int buf) {
     const unsigned kmask = kcur < kend ? 0u : kOOB;  // OR-masks, not selects: every path must issue the same VMEM instructions
     unsigned char* As = smem + buf * (A_BYTES + B_BYTES);
@@ -139,17 +236,21 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
           if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
           else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a3, dst, 16, voff, 0, 0, 0);
         }
+        gna_push(0, 0u);  // the appended segment is not under the GroupNorm
       } else {
         const bool first = p.kapp || cu < p.C1;  // wave-uniform: with two sources C1 % 64 == 0, so a K tile never straddles them
         const int cs = first ? p.C1 : p.C2;
         const int co = first ? cc : cc - p.C1;
+        unsigned live = 0u;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
           const unsigned voff = ((unsigned)(pix[i] * cs + co) * 2u) | ((unsigned)(pix[i] >> 31) & kOOB) | kmask;
           lds_ptr_t dst = (lds_ptr_t)(As + (wave + NW * i) * 1024);
           if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, dst, 16, voff, 0, 0, 0);
           else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, dst, 16, voff, 0, 0, 0);
+          if constexpr (GNA) live |= ((pix[i] >= 0 && kmask == 0u) ? 1u : 0u) << i;  // in the image and inside K: the piece holds data
         }
+        gna_push(cc, live);
       }
     } else if (!LNF && p.kapp && kt0 >= p.kapp_k0) {  // dense k_append: the second operand's columns (wave-uniform: kapp_k0 % 64 == 0)
 #pragma unroll
@@ -158,12 +259,16 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
         const unsigned voff = ((unsigned)((long)min(m, p.M - 1) * p.lda2 * 2) + (unsigned)(kcur - p.kapp_k0) * 2u) | amask[i] | kmask;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a2, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
       }
+      gna_push(0, 0u);
     } else {
+      unsigned live = 0u;
 #pragma unroll
       for (int i = 0; i < GA; ++i) {
         const unsigned voff = (aoff[i] + (unsigned)kcur * 2u) | amask[i] | kmask;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(As + (wave + NW * i) * 1024), 16, voff, 0, 0, 0);
+        if constexpr (GNA) live |= (((amask[i] | kmask) == 0u) ? 1u : 0u) << i;
       }
+      gna_push(kcur, live);
     }
 #pragma unroll
     for (int i = 0; i < GB; ++i) {
@@ -211,6 +316,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
   dma_tile(0);
   dma_tile(1);  // past the last K tile the offsets are out of range: zero fill, no fetch -- the count stays the same on every path
   wait_vmcnt<NIN>();
+  if constexpr (GNA) {
+    norm_tile(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the normalised pieces are in LDS before the barrier publishes the tile
+  }
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
 
@@ -248,6 +357,10 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
       }
       __builtin_amdgcn_sched_barrier(0);
       wait_vmcnt<NIN>();
+      if constexpr (GNA) {
+        norm_tile(cur == 2 ? 0 : cur + 1);  // tile kt + 1 has landed (this wave's pieces)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       cur = cur == 2 ? 0 : cur + 1;
@@ -268,12 +381,33 @@ __global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(3 * (BM + BN) * 12
     ln_fold_apply<TM, TN, WN, BM>(p, acc, lnst, reinterpret_cast<float*>(smem), wm * WTM, wn,
                                   reinterpret_cast<const float*>(smem + 3 * (A_BYTES + B_BYTES)) + wn * WTN, l31, hi);
   }
-  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre);
+  constexpr int SMEM = 3 * (A_BYTES + B_BYTES);
+  if (!LNF && p.sink.stats) __syncthreads();  // (uniform) every wave's run-ahead zero fills have landed before the epilogue mirrors the tile into LDS
+  gemm_epilogue<TM, TN, RICH>(p, acc, m0 + wm * WTM, n0 + wn * WTN, l31, hi, z, pre, PRE && use_pre, gemm_sink_lds<BM, BN, SMEM>(p, m0, n0, smem));
+  gemm_sink_tail<NW * 64, BM, BN, SMEM>(p, m0, n0, smem);
+}
+
+// GNA launches: dynamic LDS = the ring + the scale / shift table of the samples a row tile can touch
+template <int BM, int BN, int WM, int WN, bool CONV>
+void launch_s3_gna(const GemmParams& p, dim3 grid, hipStream_t st) {
+  const int rps_out = CONV ? p.Ho * p.Wo : p.gin.rps;
+  const int S = rps_out >= BM ? 1 : BM / rps_out;
+  const int Ct = CONV ? (p.kapp ? p.C1 : p.C1 + p.C2) : (p.kapp ? p.kapp_k0 : p.K);
+  const size_t bytes = (size_t)3 * (BM + BN) * 128 + (size_t)S * Ct * sizeof(float2);
+  static bool attr_set = false;  // (per instantiation)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_s3_kernel<BM, BN, WM, WN, CONV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, CONV, false, true>), grid, dim3(WM * WN * 64), bytes, st, p);
 }
 
 template <int BM, int BN, int WM, int WN>
 void launch_s3(const GemmParams& p, bool conv, dim3 grid, hipStream_t st) {
-  if (conv)
+  if (p.gin.stats) {
+    if (conv) launch_s3_gna<BM, BN, WM, WN, true>(p, grid, st);
+    else launch_s3_gna<BM, BN, WM, WN, false>(p, grid, st);
+  } else if (conv)
     hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, true>), grid, dim3(WM * WN * 64), 0, st, p);
   else if (p.ln_c1)
     hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, false, true>), grid, dim3(WM * WN * 64), 0, st, p);

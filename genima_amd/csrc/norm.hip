@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gn_bridge.h"
 
 namespace {
 
@@ -24,6 +25,8 @@ struct GNParams {
   int B, HW, C1, C2, C, G, cpg, chunks, rows, achunks, arows, act;
   float eps;
   int save_scsh;    // scsh is a caller buffer that has to be filled (training), not the workspace scratch of the 3-launch path
+  const long long* stats_in;  // GroupNorm bridge: the producers' statistics block (gn_bridge.h) -- the apply kernel derives scale / shift itself
+  int stats_reps;
 };
 
 // (channel-chunk, pixel-lane) thread mapping shared by the stats and apply kernels: TX = min(C/8, 256) lanes walk the
@@ -155,7 +158,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     src += (long)b * p.HW * cs + co;
     f16* dst = p.y + (long)b * p.HW * p.C + c0;
     float a[8], sft[8];
-    {
+    if (p.stats_in) {  // (wave-uniform) statistics from the producers: 8 channels touch at most two groups (cpg >= 8), or one each (cpg < 8)
+      const double inv_count = 1.0 / ((double)p.HW * (double)p.cpg);
+      int gprev = -1;
+      float mean = 0.f, rstd = 0.f;
+      const uint4 graw = *reinterpret_cast<const uint4*>(p.gamma + c0), braw = *reinterpret_cast<const uint4*>(p.beta + c0);
+      const f16x8 gv = *reinterpret_cast<const f16x8*>(&graw), bv = *reinterpret_cast<const f16x8*>(&braw);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int g = (c0 + e) / p.cpg;
+        if (g != gprev) { gn_group_mean_rstd(p.stats_in, b, g, p.B, p.G, p.stats_reps, inv_count, p.eps, mean, rstd); gprev = g; }
+        a[e] = rstd * (float)gv[e];
+        sft[e] = (float)bv[e] - mean * a[e];
+      }
+    } else {
       const f32x4* sc = reinterpret_cast<const f32x4*>(p.scsh + ((long)b * p.C + c0) * 2);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -396,7 +412,11 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
   p.stats = (float*)d->save_stats;
   if (d->save_scsh) p.scsh = (float*)d->save_scsh;  // training: persistent per-(b, c) scale/shift for the backward pass
   p.save_scsh = d->save_scsh != nullptr;
-  {  // single-launch path when a (batch, group) slab fits in LDS
+  p.stats_in = (const long long*)d->stats_in;
+  p.stats_reps = d->stats_replicas > 0 ? d->stats_replicas : 1;
+  if (d->stats_in) GN_REQUIRE(!stats_only && !d->save_stats && !d->save_scsh && ((uintptr_t)d->stats_in & 7) == 0 && ((uintptr_t)d->gamma & 15) == 0 && ((uintptr_t)d->beta & 15) == 0,
+                              "gn_groupnorm_fwd(stats_in): an inference apply pass (y set, nothing saved, 16-byte aligned gamma / beta)");
+  if (!d->stats_in) {  // single-launch path when a (batch, group) slab fits in LDS
     static int fused_ok = -1;
     static long fused_max = GNF_MAX_LDS;
     if (fused_ok < 0) {
@@ -426,10 +446,12 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
     p.arows = (int)cdiv64(d->HW, ac);
     p.achunks = (int)cdiv64(d->HW, p.arows);
   }
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
-  GN_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
-  GN_LAUNCH_CHECK();
+  if (!d->stats_in) {
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(p.chunks, p.B), dim3(256), (size_t)2 * pyn * C * sizeof(float), ctx->stream, p);
+    GN_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, ctx->stream, p);
+    GN_LAUNCH_CHECK();
+  }
   if (stats_only) return GN_OK;
   hipLaunchKernelGGL(gn_apply_kernel, dim3(p.achunks, p.B), dim3(256), 0, ctx->stream, p);
   GN_LAUNCH_CHECK();

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_FRONT, TBLOCK_MID,
-                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, TBlockDesc, TBlockTapeSrc, check)
+                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, StatsSink, TBlockDesc, TBlockTapeSrc, check)
 
 F16 = torch.float16
 
@@ -67,8 +67,28 @@ def save_tune_table():
     _tune_dirty[0] = False
 
 
+class Norm:
+    """A GroupNorm (+ activation) standing in front of a conv / Linear: ``Engine.conv2d(x, w, ..., norm=Norm(...))`` normalises x on the way
+    into the GEMM where the GroupNorm bridge applies, else runs the GroupNorm launch (buffer ``name``) first."""
+    __slots__ = ("gamma", "beta", "groups", "eps", "act", "name")
+
+    def __init__(self, gamma, beta, groups: int, eps: float, act: int = ACT_NONE, name: Optional[str] = None):
+        self.gamma, self.beta, self.groups, self.eps, self.act, self.name = gamma, beta, int(groups), float(eps), int(act), name
+
+
+class _Writer:
+    """The recorded op that wrote a tensor (GroupNorm bridge: its statistics sink is attached when the consuming GroupNorm is recorded)."""
+    __slots__ = ("op", "index", "numel", "sunk", "rdiv")
+
+    def __init__(self, op, index, numel, rdiv=1):
+        self.op, self.index, self.numel, self.sunk, self.rdiv = op, index, numel, False, rdiv  # rdiv: its rows per sample = the tensor's / rdiv
+
+
 class Engine:
-    def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None):
+    STATS_ARENA_BYTES = 16 << 20  # the GroupNorm bridge's statistics blocks of one recorded program (the used prefix is cleared at the top of every replay)
+    STATS_LINE = 16               # int64 words per (replica, sample, group) line: GN_STATS_LINE
+
+    def __init__(self, device="cuda:0", record: bool = False, autotune: Optional[bool] = None, gn_bridge: Optional[bool] = None):
         self.lib = _lib.load()
         self.autotune = (record or os.environ.get("GN_AUTOTUNE") == "1") if autotune is None else autotune
         self.hoist_time_shifts = os.environ.get("GN_HOIST_TIME_SHIFTS", "1") != "0"  # pipeline: all steps' time shifts in one pass (A/B switch)
@@ -114,6 +134,26 @@ class Engine:
         self._scope = []
         self.captured = False
         self.meta = []  # per recorded op: dict(kind, flops, bytes) -- algorithmic work for the roofline accounting
+        # ---- the GroupNorm bridge (csrc/gn_bridge.h; recorded programs): statistics out of the op that writes a tensor, GroupNorm-apply inside
+        # the op that reads it.  OFF by default (GN_BRIDGE=1 / Engine(gn_bridge=True) switch it on): measured on MI355X it does not pay inside the
+        # call -- the producers' statistics tails (a reduction + a few device-scope atomics at the end of latency-bound launches: +3 us each at
+        # B = 1, +8 us of 80 at B = 8) cost what the cheaper GroupNorm launches save (profiles/r05_v4_bridge_*)
+        self.gn_bridge = record and (os.environ.get("GN_BRIDGE", "0") == "1" if gn_bridge is None else bool(gn_bridge))
+        # rows (B x H x W) up to which the consuming conv / Linear normalises its own A tiles (ring kernels, gn_gemm_desc.norm_in); above, ONE
+        # coalesced apply launch reads the producers' statistics (gn_groupnorm_desc.stats_in)
+        self.gn_fuse_max_rows = int(os.environ.get("GN_BRIDGE_FUSE_MAX_ROWS", "0"))
+        # the bridge pays where the single-launch GroupNorm (one workgroup per (sample, group) slab) leaves most of the chip idle -- the eval loop's
+        # B = 1 call: 22 -> 8.6 us per 64 x 64 x 320 GroupNorm; at B = 8 the statistics tail costs the producing convs more (8 us of 80) than the
+        # apply launch saves (profiles/r05_v3_bridge_*): gated by slabs = B x groups
+        self.gn_bridge_max_slabs = int(os.environ.get("GN_BRIDGE_MAX_SLABS", "64"))
+        self._writer: Dict[int, _Writer] = {}
+        self._stats_arena = None
+        self._stats_used = 0
+        if self.gn_bridge:
+            self._stats_arena = torch.zeros(self.STATS_ARENA_BYTES // 8, dtype=torch.int64, device=self.device)
+            self._memset_op = self.num_ops
+            check(self.lib.gn_program_add_memset(self._prog, _ptr(self._stats_arena), self.STATS_ARENA_BYTES), "gn_program_add_memset")
+            self.meta.append(dict(kind="memset", flops=0.0, bytes=float(self.STATS_ARENA_BYTES), shape=()))
 
     # ------------------------------------------------------------------------------------------------ housekeeping
     def __del__(self):
@@ -162,10 +202,19 @@ class Engine:
     def num_ops(self) -> int:
         return int(self.lib.gn_program_num_ops(self._prog)) if self.record else 0
 
+    def _trim_memset(self):
+        """The statistics arena's memset clears what the program came to use (at least one line), not the whole arena."""
+        if self.gn_bridge and self._stats_arena is not None and not self.captured:
+            used = max(self._stats_used * 8, 128)
+            check(self.lib.gn_program_set_memset_bytes(self._prog, self._memset_op, used), "gn_program_set_memset_bytes")
+            self.meta[self._memset_op]["bytes"] = float(used)
+
     def run(self, first: int = 0, last: int = -1):
+        self._trim_memset()
         check(self.lib.gn_program_run(self._prog, first, last), "gn_program_run")
 
     def capture(self):
+        self._trim_memset()
         check(self.lib.gn_program_capture(self._prog), "gn_program_capture")
         self.captured = True
 
@@ -215,6 +264,8 @@ class Engine:
             key += "|ln"
         if d.k_append:
             key += "|ka"
+        if d.norm_in.stats:
+            key += "|gn"
         return key
 
     @staticmethod
@@ -239,6 +290,15 @@ class Engine:
             cands = [c for c in cands if c % 100 >= 7 and c % 100 != 15]
         if d.k_append:  # so does the appended 1x1 segment
             cands = [c for c in cands if c % 100 >= 7]
+        if d.norm_in.stats:  # the normalising A path lives in the ring kernels; a row tile spans at most four samples
+            rps = d.Ho * d.Wo if d.conv else d.norm_in.rows_per_sample
+            bmn = {16: (128, 128), 17: (128, 64), 18: (64, 64), 19: (256, 64), 20: (128, 160), 21: (64, 160), 22: (64, 320)}
+            ct = (d.C1 if d.k_append else d.C1 + d.C2) if d.conv else (d.K - d.C2 if d.k_append else d.K)
+
+            def fits(c):  # the ring + the scale / shift table of the samples a row tile touches inside the CU's 160 KB of LDS
+                bm, bn = bmn[c]
+                return bm <= 4 * rps and 3 * (bm + bn) * 128 + max(1, bm // rps) * ct * 8 <= 160 * 1024
+            cands = [c for c in bmn if fits(c) and (not challengers or c in [table.get(key, 0) % 100] + challengers)]
         e0, e1 = self.event(), self.event()
 
         def race(plan: int) -> float:
@@ -268,7 +328,7 @@ class Engine:
         if d.K >= 1024 and d.act != ACT_GEGLU and d.out_mode == OUT_ROWMAJOR and d.batch <= 1 and not d.fp8 and not d.out2 and not d.ln_c1:  # gn_gemm pins sk = 1 under ln_c1
             tiles = [best % 100]
             pp_blocks = -(-d.M // 256) * -(-d.N // 256)
-            if 15 in cands and 15 not in tiles and d.K >= 2048 and d.K % 64 == 0 and pp_blocks < 128:
+            if 15 in cands and 15 not in tiles and d.K >= 2048 and d.K % 64 == 0 and pp_blocks < 128 and not d.norm_in.stats:
                 tiles.append(15)
             for tile in tiles:
                 for sk in (1, 2, 3, 4, 5, 6, 8):
@@ -293,6 +353,10 @@ class Engine:
             ws = self._workspace(ws_bytes)
             d.workspace = ws.data_ptr()
         if self.record:
+            if (self.gn_bridge and d.out_mode == OUT_ROWMAJOR and not d.out2 and d.act != ACT_GEGLU and not d.fp8 and (d.batch <= 1 or d.up_phases)
+                    and not d.out_row_width or (self.gn_bridge and d.up_phases)):
+                # (a phase conv launch writes the whole upsampled tensor: 4 phases x M rows)
+                self._writer[int(d.out)] = _Writer(self.num_ops, 0, int(d.M) * int(d.N) * (4 if d.up_phases else 1), 4 if d.up_phases else 1)
             check(self.lib.gn_program_add_gemm(self._prog, C.byref(d)), "gn_program_add_gemm")
             self._keepalive(*keep, ws)
             kind = (f"conv{d.KH}x{d.KW}" if d.conv else "linear")
@@ -369,11 +433,77 @@ class Engine:
             self.meta.append(dict(kind="stream", op="join", flops=0.0, bytes=0.0, shape=()))
             self._on_side = False
 
+    # ---- the GroupNorm bridge: producer statistics for a GroupNorm over x (| x2) ---------------------------------------------------------
+    def bridge_stats(self, x: torch.Tensor, x2: Optional[torch.Tensor], groups: int) -> Optional[torch.Tensor]:
+        """-> the int64 [B, groups, 2] statistics block that the recorded ops which wrote x (and x2) will fill, or None where the bridge does
+        not apply (eager engine, an input this program did not write with a gn_gemm / gn_add_multi, a producer that already feeds another
+        GroupNorm, arena full): the caller then runs the GroupNorm's own statistics passes."""
+        if not self.gn_bridge:
+            return None
+        C1 = x.shape[-1]
+        C2 = x2.shape[-1] if x2 is not None else 0
+        B = x.shape[0]
+        if (C1 + C2) % groups or ((C1 + C2) // groups) % 2 or B * groups > self.gn_bridge_max_slabs:
+            return None
+        rps = x.numel() // (B * C1)
+        srcs = [(x, 0)] + ([(x2, C1)] if x2 is not None else [])
+        ws = []
+        for t, _ in srcs:
+            w = self._writer.get(t.data_ptr())
+            if w is None or w.sunk or w.numel != t.numel() or not t.is_contiguous() or rps % w.rdiv:
+                return None
+            ws.append(w)
+        # a 128-byte line per (replica, sample, group); few samples = few lines for the producers' atomics to serialise on: replicas
+        R = max(1, 8 // B)
+        n = R * B * groups * self.STATS_LINE
+        if (self._stats_used + n) * 8 > self.STATS_ARENA_BYTES:
+            return None
+        slot = self._stats_arena[self._stats_used:self._stats_used + n].view(R, B, groups, self.STATS_LINE)
+        self._stats_used += n
+        for (t, coff), w in zip(srcs, ws):
+            sk = StatsSink()
+            sk.stats, sk.cpg, sk.coff, sk.groups, sk.rows_per_sample = slot.data_ptr(), (C1 + C2) // groups, coff, groups, rps // w.rdiv
+            sk.samples, sk.replicas = B, R
+            check(self.lib.gn_program_set_sink(self._prog, w.op, w.index, C.byref(sk), t.shape[-1]), "gn_program_set_sink")
+            w.sunk = True
+        return slot
+
+    @staticmethod
+    def _set_sink(d: GemmDesc, sink):
+        """sink = (stats int64 [B, groups, 2] (zeroed), cpg, coff, rows_per_sample): explicit producer side of the bridge (eager calls / tests)."""
+        if sink is not None:
+            st, cpg, coff, rps = sink  # st: int64 [replicas, samples, groups, 16]
+            d.sink.stats, d.sink.cpg, d.sink.coff, d.sink.groups, d.sink.rows_per_sample = st.data_ptr(), int(cpg), int(coff), int(st.shape[2]), int(rps)
+            d.sink.samples, d.sink.replicas = int(st.shape[1]), int(st.shape[0])
+
+    def _norm_in(self, d: GemmDesc, x: torch.Tensor, x2: Optional[torch.Tensor], norm: "Norm", rows: int, stats: Optional[torch.Tensor] = None) -> bool:
+        """Try to put ``norm`` (a GroupNorm over x | x2) inside the gn_gemm ``d`` reads them with (gn_gemm_desc.norm_in).  -> done?
+        ``stats``: an explicit, already filled statistics block (eager calls / tests) instead of the recorded producers'."""
+        if stats is None and (not self.gn_bridge or rows > self.gn_fuse_max_rows or not getattr(self, "gn_fuse", True)):
+            return False
+        C1 = x.shape[-1]
+        C2 = x2.shape[-1] if x2 is not None else 0
+        B = x.shape[0]
+        ni = d.norm_in
+        ni.gamma, ni.beta, ni.eps, ni.groups, ni.cpg, ni.act = _ptr(norm.gamma), _ptr(norm.beta), norm.eps, norm.groups, (C1 + C2) // norm.groups, norm.act
+        ni.rows_per_sample = x.numel() // (B * C1)
+        ni.samples, ni.replicas = B, (int(stats.shape[0]) if stats is not None else max(1, 8 // B))
+        ni.stats = None
+        if (C1 + C2) % norm.groups or not self.lib.gn_gemm_norm_in_supported(C.byref(d)):
+            if stats is not None:
+                raise GenimaHipError("norm_in: unsupported problem (gn_gemm_norm_in_supported)")
+            return False
+        st = stats if stats is not None else self.bridge_stats(x, x2, norm.groups)
+        if st is None:
+            return False
+        ni.stats = st.data_ptr()
+        return True
+
     def linear(self, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
                transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0,
                split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-               append: Optional[torch.Tensor] = None):
+               append: Optional[torch.Tensor] = None, norm: Optional[Norm] = None, sink=None, norm_stats: Optional[torch.Tensor] = None):
         """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
         transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel).
         split_n > 0: ONE launch with two destinations (the q | k | v projections of a self-attention block): columns [0, split_n)
@@ -424,7 +554,15 @@ class Engine:
         if ln_c1 is not None:
             assert bias is not None and ln_c1.dtype == torch.float32 and ln_c1.numel() == N and not transposed_out
             d.ln_c1, d.ln_eps = _ptr(ln_c1), float(ln_eps)
-        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1, append))
+        if norm is not None:  # x: RAW [B, rows, K] tokens of a tensor a GroupNorm stands in front of (Transformer2DModel.norm -> proj_in)
+            assert x.dim() == 3 and append is None and ln_c1 is None
+            if not self._norm_in(d, x, None, norm, M, norm_stats):
+                d.norm_in.stats = None
+                n = self.groupnorm(x, norm.gamma, norm.beta, norm.groups, norm.eps, act=norm.act, name=norm.name)
+                d.a, d.lda = _ptr(n), n.stride(-2)
+                x = n
+        self._set_sink(d, sink)
+        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1, append, None if norm is None else norm.gamma, None if norm is None else norm.beta))
         return (out, out2) if split_n else out
 
     # ---- fused chains of a transformer block's Linears (csrc/tblock.hip): one launch keeps 128 rows of the residual stream in LDS ----------
@@ -551,16 +689,22 @@ class Engine:
                shift: Optional[torch.Tensor] = None, ldshift: int = 0, residual: Optional[torch.Tensor] = None,
                act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
                name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False, up_phases: bool = False,
-               append: Optional[torch.Tensor] = None, append2: Optional[torch.Tensor] = None) -> torch.Tensor:
+               append: Optional[torch.Tensor] = None, append2: Optional[torch.Tensor] = None, norm: Optional[Norm] = None, sink=None,
+               norm_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
         """``append`` [B, H, W, C2] (+ ``append2`` [B, H, W, C3], the rest of a concatenated input): a 1x1 conv appended along K
         (gn_gemm_desc.k_append) -- w = [Cout, k*k*C1 + C2 + C3], the 1x1 weight behind the packed k x k weight (packing: ``*.conv2sc.weight``):
         ResnetBlock2D's conv2(h) + conv_shortcut(x) as one launch.
         NHWC conv.  ``up_phases``: w is [4][Cout][4 * Cin] -- the four phase convs of an Upsample2D as ONE launch (conv2d_up2x).  x: [B, H, W, C1] (x2: [B, H, W, C2] virtually concatenated), w: packed [Cout, k*k*(C1+C2)].
         pad = (top, left, bottom, right); default k//2 all round.  shift: [B, ldshift or Cout] per-batch channel shift."""
+        if norm is not None and not self.gn_bridge and norm_stats is None:  # (no bridge: the GroupNorm launch, then the plain conv on its output)
+            x = self.groupnorm(x, norm.gamma, norm.beta, norm.groups, norm.eps, act=norm.act, x2=None if append is not None else x2, name=norm.name)
+            norm, x2 = None, (x2 if append is not None else None)
         B, H, W, C1 = x.shape
+        gn_x2 = x2  # the concat partner under the GroupNorm (an appended k_append source is not)
         if append is not None:
             assert x2 is None and stride == 1 and not upsample2x and not up_phases and tuple(append.shape[:3]) == (B, H, W)
             x2 = append
+            gn_x2 = None
         C2 = x2.shape[-1] if x2 is not None else 0
         N = w.shape[1] if up_phases else w.shape[0]
         k = ksize
@@ -592,7 +736,17 @@ class Engine:
         d.upsample2x, d.act, d.out_mode, d.rows_per_batch, d.splitk, d.out_scale = (int(upsample2x), act, OUT_ROWMAJOR,
                                                                                      Ho * Wo, splitk, out_scale)
         d.residual_before_act = int(residual_before_act)
-        self._gemm(d, (x, x2, w, bias, shift, residual, out, append2))
+        self._set_sink(d, sink)
+        if norm is not None and not self._norm_in(d, x, gn_x2, norm, B * H * W, norm_stats):
+            # the GroupNorm as its own launch (one coalesced apply pass where the producers left their statistics), the conv on its output
+            d.norm_in.stats = None
+            n = self.groupnorm(x, norm.gamma, norm.beta, norm.groups, norm.eps, act=norm.act, x2=gn_x2, name=norm.name)
+            if gn_x2 is not None:  # the GroupNorm wrote the concatenation
+                d.a, d.a2, d.C1, d.C2 = _ptr(n), None, C1 + C2, 0
+            else:
+                d.a = _ptr(n)
+            x = n
+        self._gemm(d, (x, x2, w, bias, shift, residual, out, append2, None if norm is None else norm.gamma, None if norm is None else norm.beta))
         return out
 
     def conv2d_up2x(self, x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor] = None, *, name: Optional[str] = None) -> torch.Tensor:
@@ -710,8 +864,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------------ norms
     def groupnorm(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
                   act: int = ACT_NONE, x2: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-                  name: Optional[str] = None) -> torch.Tensor:
-        """x: [B, H, W, C1] or [B, HW, C1] (x2 optional concat source).  Returns act(GN(cat)) [.., C1+C2]."""
+                  name: Optional[str] = None, stats_in: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """x: [B, H, W, C1] or [B, HW, C1] (x2 optional concat source).  Returns act(GN(cat)) [.., C1+C2].
+        stats_in: an explicit, filled statistics block of the GroupNorm bridge (eager calls / tests)."""
         B, C1 = x.shape[0], x.shape[-1]
         HW = x.numel() // (B * C1)
         C2 = x2.shape[-1] if x2 is not None else 0
@@ -722,10 +877,15 @@ class Engine:
         d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, C1, C2, groups, act, eps
         ws = self._workspace(int(self.lib.gn_groupnorm_workspace_bytes(C.byref(d))))
         d.workspace = ws.data_ptr()
+        st = stats_in
+        if st is None and getattr(self, "gn_apply_from_stats", True) and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0:
+            st = self.bridge_stats(x, x2, groups)
+        if st is not None:  # the producers of x (| x2) leave the statistics: ONE coalesced apply launch
+            d.stats_in, d.stats_replicas = st.data_ptr(), int(st.shape[0])
         if self.record:
             check(self.lib.gn_program_add_groupnorm(self._prog, C.byref(d)), "gn_program_add_groupnorm")
             self._keepalive(x, x2, gamma, beta, out, ws)
-            self.meta.append(dict(kind="groupnorm", flops=0.0, bytes=2.0 * 2 * B * HW * (C1 + C2), shape=(B, HW, C1 + C2)))
+            self.meta.append(dict(kind="groupnorm", flops=0.0, bytes=2.0 * 2 * B * HW * (C1 + C2), shape=(B, HW, C1 + C2) + (("st",) if st is not None else ())))
         else:
             check(self.lib.gn_groupnorm_fwd(self._ctx, C.byref(d)), "gn_groupnorm_fwd")
         return out
@@ -864,15 +1024,35 @@ class Engine:
         self._small("add", (a, b, out), _ptr(a), _ptr(b), _ptr(out), a.numel())
         return out
 
-    def add_multi(self, pairs, *, name=None):
-        """[(a, b), ...] (<= 16) -> [a + b, ...] as ONE launch (gn_add_multi): independent small adds that would each pay a launch boundary."""
+    def add_multi(self, pairs, *, name=None, sinks=None):
+        """[(a, b), ...] (<= 16) -> [a + b, ...] as ONE launch (gn_add_multi): independent small adds that would each pay a launch boundary.
+        sinks (eager calls / tests): per pair None or (stats, cpg, coff, rows_per_sample) -- gn_add_multi_stats."""
         n = len(pairs)
+        if sinks is not None:
+            assert not self.record
+            outs = [torch.empty_like(a) for a, _ in pairs]
+            A = (C.c_void_p * n)(*[_ptr(a) for a, _ in pairs])
+            Bp = (C.c_void_p * n)(*[_ptr(b) for _, b in pairs])
+            O = (C.c_void_p * n)(*[_ptr(o) for o in outs])
+            N = (C.c_int64 * n)(*[a.numel() for a, _ in pairs])
+            Cs = (C.c_int32 * n)(*[a.shape[-1] for a, _ in pairs])
+            S = (StatsSink * n)()
+            for i, sk in enumerate(sinks):
+                if sk is not None:
+                    st, cpg, coff, rps = sk
+                    S[i].stats, S[i].cpg, S[i].coff, S[i].groups, S[i].rows_per_sample = st.data_ptr(), int(cpg), int(coff), int(st.shape[2]), int(rps)
+                    S[i].samples, S[i].replicas = int(st.shape[1]), int(st.shape[0])
+            check(self.lib.gn_add_multi_stats(self._ctx, A, Bp, O, N, Cs, S, n), "gn_add_multi_stats")
+            return outs
         outs = [self.buf(None if name is None else f"{name}{i}", a.shape) for i, (a, _) in enumerate(pairs)]
         A = (C.c_void_p * n)(*[_ptr(a) for a, _ in pairs])
         Bp = (C.c_void_p * n)(*[_ptr(b) for _, b in pairs])
         O = (C.c_void_p * n)(*[_ptr(o) for o in outs])
         N = (C.c_int64 * n)(*[a.numel() for a, _ in pairs])
         keep = tuple(t for pr in pairs for t in pr) + tuple(outs)
+        if self.gn_bridge:
+            for i, o in enumerate(outs):
+                self._writer[o.data_ptr()] = _Writer(self.num_ops, i, o.numel())
         self._small("add_multi", keep, A, Bp, O, N, n)
         return outs
 

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from ._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, ACT_TANH3
-from .engine import Engine
+from .engine import Engine, Norm
 
 
 def _rup(x, m):
@@ -106,20 +106,22 @@ def emit_resnet(E: Engine, W, p: str, x, x2, shifts, groups: int, eps: float, ep
             st = E.groupnorm_stats(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, name="n1s")
             h = E.conv2d_gn(x, st, c1w, W[p + ".conv1.bias"], name="c1")
         else:
-            h = E.groupnorm(x, W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, act=ACT_SILU, x2=x2, name="n1")
-            h = E.conv2d(h, c1w, W[p + ".conv1.bias"], shift=sh, ldshift=ld, name="c1")
+            # GroupNorm -> SiLU -> conv: through the GroupNorm bridge where this program wrote x (Engine.conv2d(norm=...): the statistics come out
+            # of the producer, the conv normalises its own A tiles or one apply launch does), else the GroupNorm launch and the conv on its output
+            n1 = Norm(W[p + ".norm1.weight"], W[p + ".norm1.bias"], groups, eps if eps_in is None else eps_in, ACT_SILU, "n1")
+            h = E.conv2d(x, c1w, W[p + ".conv1.bias"], x2=x2, shift=sh, ldshift=ld, norm=n1, name="c1")
         if fuse2:
             assert not kapp and tuple(h.shape) == tuple(x.shape[:3]) + (c1w.shape[0],)
             st = E.groupnorm_stats(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, name="n2s")
             if side:
                 E.join()
             return E.conv2d_gn(h, st, c2w, W[p + ".conv2.bias"], residual=sc, name="c2")
-        h = E.groupnorm(h, W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, act=ACT_SILU, name="n2")
+        n2 = Norm(W[p + ".norm2.weight"], W[p + ".norm2.bias"], groups, eps, ACT_SILU, "n2")
         if side:
             E.join()
         if kapp:  # (a concatenated block input -- the up blocks -- is appended as its two tensors)
-            return E.conv2d(h, W[p + ".conv2sc.weight"], W[p + ".conv2sc.bias"], append=x, append2=x2, name="c2sc")
-        return E.conv2d(h, c2w, W[p + ".conv2.bias"], residual=sc, name="c2")
+            return E.conv2d(h, W[p + ".conv2sc.weight"], W[p + ".conv2sc.bias"], append=x, append2=x2, norm=n2, name="c2sc")
+        return E.conv2d(h, c2w, W[p + ".conv2.bias"], residual=sc, norm=n2, name="c2")
 
 
 def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[torch.Tensor, torch.Tensor]]:
@@ -160,8 +162,8 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
             front = E.tblock_front(x.view(B, N, Cc), st, W[p + ".tblock_front.tape"], N, name="front")
             h = front[0]
         else:
-            h = E.groupnorm(x, W[p + ".norm.weight"], W[p + ".norm.bias"], groups, 1e-6, name="gn")
-            h = E.linear(h.view(B, N, Cc), W[p + ".proj_in.weight"], W[p + ".proj_in.bias"], name="pin")
+            h = E.linear(x.view(B, N, Cc), W[p + ".proj_in.weight"], W[p + ".proj_in.bias"],
+                         norm=Norm(W[p + ".norm.weight"], W[p + ".norm.bias"], groups, 1e-6, ACT_NONE, "gn"), name="pin")
         k = 0
         while f"{p}.transformer_blocks.{k}.norm1.weight" in W:
             b = f"{p}.transformer_blocks.{k}"
@@ -304,8 +306,8 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
                 p = f"up_blocks.{i}.upsamplers.0.conv"
                 h = _emit_upsample_conv(E, W, p, h)
         E.side_free = False
-        h = E.groupnorm(h, W["conv_norm_out.weight"], W["conv_norm_out.bias"], G, eps, act=ACT_SILU, name="norm_out")
-        return E.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], name="conv_out")
+        return E.conv2d(h, W["conv_out.weight"], W["conv_out.bias"], norm=Norm(W["conv_norm_out.weight"], W["conv_norm_out.bias"], G, eps, ACT_SILU, "norm_out"),
+                        name="conv_out")
 
 
 def emit_controlnet_cond(E: Engine, W, cfg, cond8: torch.Tensor) -> torch.Tensor:

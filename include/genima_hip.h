@@ -52,6 +52,40 @@ int32_t gn_ctx_set_stream(gn_ctx* ctx, void* stream);
  * Epilogue order:  v = acc + bias[n] + shift[m / rows_per_batch, n];  v = act(v);  v *= out_scale;  v += residual[m, n].
  * GN_ACT_GEGLU: W rows are packed in alternating 32-row blocks [hidden | gate]; out[m, j] = hidden * gelu(gate), out has N/2 cols.
  */
+/* ---- the GroupNorm bridge (round 5): statistics out of the PRODUCER, GroupNorm-apply (+ SiLU) inside the CONSUMER ---------------------------
+ * diffusers ResnetBlock2D runs  conv -> GroupNorm -> SiLU -> conv  and Transformer2DModel  conv -> GroupNorm -> proj_in  (inside `self.pipe(...)`,
+ * controller/agent/sd_controlnet_agent.py:67-76): as separate launches every GroupNorm is a dependent pass over the tensor between two GEMMs.
+ * Here the op that WRITES the tensor also adds its per-(sample, group) sum and sum of squares -- of the f16 values it stored -- into a
+ * caller-zeroed statistics block (gn_stats_sink), and the op that READS it normalises its A operand on the way into the MFMA (gn_norm_in), or a
+ * single coalesced apply pass does (gn_groupnorm_desc.stats_in).  Sums are fixed point (value * 2^GN_STATS_SHIFT, int64, device-scope integer
+ * atomics): integer addition is order-independent, so the statistics -- and everything downstream -- are bit-reproducible run to run. */
+#define GN_STATS_SHIFT 24
+/* The statistics block: int64 [replicas][samples][groups][GN_STATS_LINE] -- one 128-byte line per (replica, sample, group) holding
+ * (sum, sum of squares) * 2^GN_STATS_SHIFT in its first two words, ZEROED by the caller before the producers run.  Device-scope atomics
+ * serialise per memory line (measured on MI355X: ~100 ns each; 2 240 adds onto the 8 lines of a packed 1 x 32 x 2 block cost a 28 us conv
+ * another 30 us), hence a line per group, and `replicas` > 1 where few samples leave few lines: a producer workgroup adds into replica
+ * (its row-tile index % replicas), the consumer sums the replicas (integer adds: any order, same bits). */
+#define GN_STATS_LINE 16
+typedef struct gn_stats_sink {
+  void* stats;             /* the statistics block; NULL = off */
+  int32_t cpg;             /* channels per group of the consuming GroupNorm */
+  int32_t coff;            /* channel, in the consumer's (possibly concatenated) input, of this tensor's channel 0 */
+  int32_t groups;          /* groups of the consuming GroupNorm */
+  int32_t rows_per_sample; /* output rows (pixels) per sample */
+  int32_t samples;         /* samples (the block's second extent) */
+  int32_t replicas;        /* >= 1 */
+} gn_stats_sink;
+typedef struct gn_norm_in {
+  const void* stats;       /* the statistics block the producers of the input filled (complete when this op starts); NULL = off */
+  const void* gamma;       /* f16 [C] over the (concatenated) input channels */
+  const void* beta;
+  float eps;
+  int32_t groups, cpg;
+  int32_t act;             /* GN_ACT_NONE or GN_ACT_SILU applied after the affine */
+  int32_t rows_per_sample; /* INPUT pixels (conv) / rows (dense) per sample */
+  int32_t samples, replicas; /* extents of the statistics block */
+} gn_norm_in;
+
 typedef struct gn_gemm_desc {
   const void* a;          /* A source 1: dense [M, lda] or NHWC [B, H, W, C1] */
   const void* a2;         /* conv only: second NHWC source [B, H, W, C2], virtually concatenated on channels; or NULL */
@@ -134,7 +168,14 @@ typedef struct gn_gemm_desc {
   const void* a3;         /* k_append (conv): optional second appended source [B, H, W, C3] or NULL */
   int32_t C3;
   int64_t lda2;           /* k_append (dense): row stride of a2 */
+  /* GroupNorm bridge, producer side: add the statistics of the f16 values this op stores (row-major f16 outputs; not GEGLU / out2 / batch) */
+  gn_stats_sink sink;
+  /* GroupNorm bridge, consumer side: a (and a2 of a virtual concat) hold the RAW tensor; each A tile is normalised (x * scale + shift, SiLU)
+   * in LDS after it lands, taps in the zero padding stay zero, an appended k_append segment stays raw.  Ring tiles 16 .. 22, conv or dense,
+   * C1 (and C2) % 64 == 0; a row tile may span at most 4 samples (gn_gemm_norm_in_supported). */
+  gn_norm_in norm_in;
 } gn_gemm_desc;
+int32_t gn_gemm_norm_in_supported(const gn_gemm_desc* d);
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
 int32_t gn_set_gemm_tile_override(int32_t cfg);
@@ -265,6 +306,9 @@ typedef struct gn_groupnorm_desc {
   float eps;
   void* save_stats;                  /* training: optional f32 [B][groups][2] (mean, rstd) kept for gn_groupnorm_bwd */
   void* save_scsh;                   /* training: optional f32 [B][C][2] per-(b, c) scale/shift kept for gn_groupnorm_bwd */
+  const void* stats_in;              /* GroupNorm bridge: the statistics block the producers of x / x2 filled (gn_stats_sink; samples = B) --
+                                        ONE coalesced apply launch, no statistics passes; NULL = compute them here */
+  int32_t stats_replicas;            /* replicas of stats_in (>= 1) */
 } gn_groupnorm_desc;
 int64_t gn_groupnorm_workspace_bytes(const gn_groupnorm_desc* d);
 int32_t gn_groupnorm_fwd(gn_ctx* ctx, const gn_groupnorm_desc* d);
@@ -355,6 +399,10 @@ int32_t gn_add(gn_ctx* ctx, const void* a, const void* b, void* out, int64_t n);
  * inside `self.pipe(...)`, controller/agent/sd_controlnet_agent.py:67-76) */
 #define GN_ADD_MULTI_MAX 16
 int32_t gn_add_multi(gn_ctx* ctx, const void* const* a, const void* const* b, void* const* out, const int64_t* n, int32_t count);
+/* the same adds with the GroupNorm bridge's producer side: tensor i is [n[i] / C[i]] rows of C[i] channels and adds the statistics of what it
+ * stores to sinks[i] (sinks[i].stats == NULL: none) -- the UNet's skip + ControlNet-residual sums feed the decoder's concatenated GroupNorms */
+int32_t gn_add_multi_stats(gn_ctx* ctx, const void* const* a, const void* const* b, void* const* out, const int64_t* n, const int32_t* C,
+                           const gn_stats_sink* sinks, int32_t count);
 int32_t gn_act(gn_ctx* ctx, const void* x, void* out, int64_t n, int32_t act);                /* f16, n % 8 == 0 */
 /* FiLM (controller/method/genima_act.py:190: ``encoder_model(image, task_emb)`` with use_lang_cond, genima_act.yaml:39):
  * out[r, :] = act((1 + gamma[r / rows_per_film, :]) * x[r, :] + beta[r / rows_per_film, :]); x / out f16 [rows, C], gamma / beta f16 rows of
@@ -528,6 +576,16 @@ int64_t gn_program_num_ops(const gn_program* p);
  * recorded one; a plan that splits K with neither is refused); refused on a captured program. */
 int32_t gn_program_get_gemm(const gn_program* p, int64_t op, gn_gemm_desc* out);
 int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_t splitk, void* workspace);
+/* GroupNorm bridge plumbing of a recorded program: the consumer of a tensor is recorded AFTER its producer, so the producer's sink is attached
+ * afterwards -- op = a recorded gn_gemm (index 0) or gn_add_multi (index = which of its tensors); and the statistics arena is cleared by a
+ * memset op at the top of every replay */
+int32_t gn_program_set_sink(gn_program* p, int64_t op, int32_t index, const gn_stats_sink* sink, int32_t channels);
+int32_t gn_program_add_memset(gn_program* p, void* ptr, int64_t bytes);
+int32_t gn_program_set_memset_bytes(gn_program* p, int64_t op, int64_t bytes); /* shrink a recorded memset to the bytes the program came to use */
+int32_t gn_memset(gn_ctx* ctx, void* ptr, int64_t bytes);
+/* sizeof() of the descriptor structs as the library was compiled (0 gn_gemm_desc, 1 gn_attn_desc, 2 gn_groupnorm_desc, 3 gn_tblock_desc,
+ * 4 gn_conv3x3_gn_desc, 5 gn_stats_sink, 6 gn_norm_in): a host binding checks its own layout against these before the first call */
+int64_t gn_desc_sizeof(int32_t which);
 /* first..last (exclusive) op range; last < 0 = to the end */
 int32_t gn_program_run(gn_program* p, int64_t first, int64_t last);
 int32_t gn_program_capture(gn_program* p);   /* capture the whole program into a hipGraph on the ctx stream */

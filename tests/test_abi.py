@@ -31,7 +31,12 @@ def test_loader_binds_and_reports_version():
     assert lib.gn_version() == 100
     # 8 pointers, 8 int64, 20 int32 + float, batch/batch_inner (+pad to 8), 8 int64 batch strides, accumulate + fp8, 2 scale pointers,
     # out2 + ldo2 + split_n + ln_eps, ln_c1, out_row_width (+pad) + ldo_hi, up_phases (+tail pad)
-    assert ctypes.sizeof(_lib.GemmDesc) == 8 * 8 + 8 * 8 + 24 * 4 + 8 * 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # ... k_append in up_phases' tail pad, a3, C3 (+pad), lda2
+    base = 8 * 8 + 8 * 8 + 24 * 4 + 8 * 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # ... k_append in up_phases' tail pad, a3, C3 (+pad), lda2
+    assert ctypes.sizeof(_lib.StatsSink) == 32 and ctypes.sizeof(_lib.NormIn) == 56  # pointer + 6 int32; 3 pointers + float + 6 int32 (+ tail pad)
+    assert ctypes.sizeof(_lib.GemmDesc) == base + 32 + 56  # the GroupNorm bridge's sink + norm_in
+    # ... and the compiled structs agree with the binding's (the loader refuses a mismatch)
+    for which, cls in enumerate((_lib.GemmDesc, _lib.AttnDesc, _lib.GroupNormDesc, _lib.TBlockDesc, _lib.ConvGnDesc, _lib.StatsSink, _lib.NormIn)):
+        assert int(lib.gn_desc_sizeof(which)) == ctypes.sizeof(cls), cls.__name__
 
 
 def test_product_fails_loudly_without_gpu():
