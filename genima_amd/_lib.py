@@ -34,6 +34,12 @@ class NormIn(C.Structure):
                 ("cpg", C.c_int32), ("act", C.c_int32), ("rows_per_sample", C.c_int32), ("samples", C.c_int32), ("replicas", C.c_int32)]
 
 
+class NormOut(C.Structure):
+    """gn_norm_out: GroupNorm of a split-K launch's output inside its reduce kernel."""
+    _fields_ = [("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("eps", C.c_float), ("groups", C.c_int32), ("act", C.c_int32),
+                ("rows_per_sample", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [
         ("a", C.c_void_p), ("a2", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("shift", C.c_void_p),
@@ -52,7 +58,7 @@ class GemmDesc(C.Structure):
         ("out2", C.c_void_p), ("ldo2", C.c_int64), ("split_n", C.c_int32),
         ("ln_eps", C.c_float), ("ln_c1", C.c_void_p), ("out_row_width", C.c_int32), ("ldo_hi", C.c_int64), ("up_phases", C.c_int32),
         ("k_append", C.c_int32), ("a3", C.c_void_p), ("C3", C.c_int32), ("lda2", C.c_int64),
-        ("sink", StatsSink), ("norm_in", NormIn),
+        ("sink", StatsSink), ("norm_in", NormIn), ("norm_out", NormOut),
     ]
 
 
@@ -130,6 +136,8 @@ SIGNATURES = {
     "gn_gemm_workspace_bytes": (_I64, [C.POINTER(GemmDesc)]),
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
     "gn_gemm_norm_in_supported": (_I32, [C.POINTER(GemmDesc)]),
+    "gn_gemm_norm_out_supported": (_I32, [C.POINTER(GemmDesc)]),
+    "gn_program_set_norm_out": (_I32, [_P, _I64, C.POINTER(NormOut)]),
     "gn_add_multi_stats": (_I32, [_P, _P, _P, _P, _P, _P, _P, _I32]),
     "gn_program_set_sink": (_I32, [_P, _I64, _I32, C.POINTER(StatsSink), _I32]),
     "gn_program_add_memset": (_I32, [_P, _P, _I64]),
@@ -287,7 +295,7 @@ def load() -> C.CDLL:
             raise GenimaHipError(f"{LIB_PATH} does not export {name} (stale build?)") from e
         fn.restype = res
         fn.argtypes = args
-    for which, cls in enumerate((GemmDesc, AttnDesc, GroupNormDesc, TBlockDesc, ConvGnDesc, StatsSink, NormIn)):
+    for which, cls in enumerate((GemmDesc, AttnDesc, GroupNormDesc, TBlockDesc, ConvGnDesc, StatsSink, NormIn, NormOut)):
         if int(lib.gn_desc_sizeof(which)) != C.sizeof(cls):  # a stale .so against newer Python (or the reverse) would read garbage descriptors
             raise GenimaHipError(f"{LIB_PATH}: sizeof({cls.__name__}) is {int(lib.gn_desc_sizeof(which))} in the library, {C.sizeof(cls)} in the "
                                  "binding (stale build? run `python -m genima_amd.build`)")

@@ -351,6 +351,16 @@ int32_t gn_program_set_sink(gn_program* p, int64_t op, int32_t index, const gn_s
   gn_set_error("gn_program_set_sink: op %ld is neither a gn_gemm nor a gn_add_multi", (long)op);
   return GN_ERR_INVALID;
 }
+int32_t gn_program_set_norm_out(gn_program* p, int64_t op, const gn_norm_out* n) {
+  GN_REQUIRE(p && n && n->y && op >= 0 && op < (int64_t)p->ops.size() && p->ops[(size_t)op].type == OP_GEMM, "gn_program_set_norm_out: op %ld is not a gn_gemm", (long)op);
+  GN_REQUIRE(!p->exec, "gn_program_set_norm_out: the program is captured");
+  gn_gemm_desc d = p->ops[(size_t)op].gemm;
+  GN_REQUIRE(!d.norm_out.y, "gn_program_set_norm_out: this gn_gemm already normalises its output");
+  d.norm_out = *n;
+  GN_REQUIRE(gn_gemm_norm_out_supported(&d), "gn_program_set_norm_out: the recorded problem / plan does not take norm_out");
+  p->ops[(size_t)op].gemm = d;
+  return GN_OK;
+}
 int32_t gn_program_set_memset_bytes(gn_program* p, int64_t op, int64_t bytes) {
   GN_REQUIRE(p && op >= 0 && op < (int64_t)p->ops.size() && p->ops[(size_t)op].type == OP_MEMSET && bytes > 0 && bytes <= p->ops[(size_t)op].g.n0,
              "gn_program_set_memset_bytes: op %ld is not a memset of at least %ld bytes", (long)op, (long)bytes);
@@ -367,6 +377,7 @@ int64_t gn_desc_sizeof(int32_t which) {
     case 4: return (int64_t)sizeof(gn_conv3x3_gn_desc);
     case 5: return (int64_t)sizeof(gn_stats_sink);
     case 6: return (int64_t)sizeof(gn_norm_in);
+    case 7: return (int64_t)sizeof(gn_norm_out);
     default: return -1;
   }
 }

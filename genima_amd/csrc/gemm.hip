@@ -626,6 +626,108 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmParams p) 
   epilogue_store4(p, m, nb, s[0], s[1], s[2], s[3]);
 }
 
+// ---- split-K reduce + GroupNorm (+ SiLU) of the result in ONE launch (gn_gemm_desc.norm_out) -----------------------------------------------
+// The small-M convs of the 8x8 .. 32x32 latent levels split K and finish in a reduce kernel; diffusers runs a GroupNorm on most of their outputs
+// next (ResnetBlock2D conv1 -> norm2 -> SiLU, conv2 -> the next block's norm1 / Transformer2DModel.norm; `self.pipe(...)`,
+// controller/agent/sd_controlnet_agent.py:67-76).  Here one 512-thread workgroup owns a (sample, group) slab, as norm.hip's single-launch
+// GroupNorm does: it sums the partial slabs in the fixed z order, applies the fused epilogue, stores the raw f16 rows (the residual stream reads
+// them) and keeps the rounded values in LDS with their f32 statistics, then writes act(GroupNorm) of them -- the arithmetic of
+// splitk_reduce_kernel followed by gn_fused_kernel without the second launch and its read of the tensor.  Deterministic (no atomics).
+constexpr int RGN_THREADS = 512;
+__device__ __forceinline__ void epilogue_pair(const GemmParams& p, int m, int n, float& v0, float& v1) {
+  if (p.bias) { const f16x2 b = *reinterpret_cast<const f16x2*>(p.bias + n); v0 += (float)b[0]; v1 += (float)b[1]; }
+  if (p.shift) { const f16x2 t = *reinterpret_cast<const f16x2*>(p.shift + (long)(m / p.rpb) * p.ldshift + n); v0 += (float)t[0]; v1 += (float)t[1]; }
+  f16x2 r = {(f16)0.0f, (f16)0.0f};
+  if (p.res) r = *reinterpret_cast<const f16x2*>(p.res + (long)m * p.ldr + n);
+  if (p.res && p.res_first) { v0 += (float)r[0]; v1 += (float)r[1]; }
+  if (p.act != GN_ACT_NONE) { v0 = gemm_act(v0, p.act); v1 = gemm_act(v1, p.act); }
+  if (p.out_scale != 1.0f) { v0 *= p.out_scale; v1 *= p.out_scale; }
+  if (p.res && !p.res_first) { v0 += (float)r[0]; v1 += (float)r[1]; }
+}
+__global__ __launch_bounds__(RGN_THREADS) void splitk_reduce_gn_kernel(const GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint2 rgn_slab[];  // [rps][cpg / 4] packed f16 quads
+  __shared__ float red[2 * (RGN_THREADS / 64)];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const int G = p.nout.groups, cpg = p.N / G, hq = cpg >> 2, rps = p.nout.rps;
+  // XCD-aware group order (block x runs on XCD x % 8): an XCD takes CONTIGUOUS groups -- neighbours share the cache lines of every row
+  const int g = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  const int j = tid % hq, p0 = tid / hq, pstep = RGN_THREADS / hq;
+  const int n = g * cpg + 4 * j;
+  float s = 0.f, ss = 0.f;
+  if (p0 < pstep) {
+    // the launch is a pure gather of 16-byte pieces (a row of a slab is cpg x 4 bytes of a partial slab's row): what it needs is loads in
+    // flight -- two rows x eight K slices per trip, predicated (a runtime trip count would serialise the slices: one memory round trip each)
+    for (int r0 = p0; r0 < rps; r0 += 2 * pstep) {
+      f32x4 v[2];
+      v[0] = v[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int z0 = 0; z0 < p.splitk; z0 += 8) {
+        f32x4 t[2][8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int zz = 0; zz < 8; ++zz) {
+            t[u][zz] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int r = r0 + u * pstep;
+            if (r < rps && z0 + zz < p.splitk) t[u][zz] = *reinterpret_cast<const f32x4*>(p.ws + ((long)(z0 + zz) * p.M + (long)b * rps + r) * p.N + n);
+          }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int zz = 0; zz < 8; ++zz) v[u] += t[u][zz];  // (slices in z order, as splitk_reduce_kernel sums them)
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int r = r0 + u * pstep;
+        if (r < rps) {
+          const int m = b * rps + r;
+          float w[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
+          int bidx;
+          epilogue_vals4(p, m, n, w, bidx);
+          f16x4 h;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h[i] = (f16)w[i];
+          *reinterpret_cast<f16x4*>(p.out + (long)m * p.ldo + n) = h;
+          rgn_slab[r * hq + j] = *reinterpret_cast<const uint2*>(&h);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float a = (float)h[i]; s += a; ss += a * a; }
+        }
+      }
+    }
+  }
+  s = wave_sum(s);
+  ss = wave_sum(ss);
+  const int wave = tid >> 6;
+  if ((tid & 63) == 0) { red[wave] = s; red[RGN_THREADS / 64 + wave] = ss; }
+  __syncthreads();
+  float ts = 0.f, tss = 0.f;
+#pragma unroll
+  for (int w = 0; w < RGN_THREADS / 64; ++w) { ts += red[w]; tss += red[RGN_THREADS / 64 + w]; }
+  const float cnt = (float)rps * (float)cpg;
+  const float mean = ts / cnt;
+  const float var = fmaxf(tss / cnt - mean * mean, 0.0f);
+  const float rstd = rsqrtf(var + p.nout.eps);
+  if (p0 < pstep) {
+    const f16x4 gm = *reinterpret_cast<const f16x4*>(p.nout.gamma + n), bt = *reinterpret_cast<const f16x4*>(p.nout.beta + n);
+    float a[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = rstd * (float)gm[i]; sh[i] = (float)bt[i] - mean * a[i]; }
+    f16* dst = p.nout.y + (long)b * rps * p.N + n;
+    for (int r = p0; r < rps; r += pstep) {
+      const uint2 raw = rgn_slab[r * hq + j];
+      const f16x4 v = *reinterpret_cast<const f16x4*>(&raw);
+      f16x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float y = (float)v[i] * a[i] + sh[i];
+        if (p.nout.act == GN_ACT_SILU) y = act_silu(y);
+        o[i] = (f16)y;
+      }
+      *reinterpret_cast<f16x4*>(dst + (long)r * p.N) = o;
+    }
+  }
+}
+constexpr long kRgnMaxSlab = 96 * 1024;
+
 // the same reduce for a producer of the GroupNorm bridge (GemmParams.sink): a block owns an 8-row x 128-column patch of the output (512-byte
 // row pieces of the partial slabs, as many blocks as the plain reduce), so the statistics of what it stores are a column sum through LDS + a
 // handful of atomics per block (gn_bridge.h)
@@ -869,6 +971,19 @@ extern "C" int32_t gn_gemm_norm_in_supported(const gn_gemm_desc* d) {
   return 1;
 }
 
+extern "C" int32_t gn_gemm_norm_out_supported(const gn_gemm_desc* d) {
+  if (!d || !d->norm_out.y || !d->norm_out.gamma || !d->norm_out.beta) return 0;
+  if (d->out_mode != GN_OUT_ROWMAJOR || d->out2 || d->act == GN_ACT_GEGLU || d->fp8 || d->batch > 1 || d->out_row_width || d->sink.stats || d->ln_c1) return 0;
+  const int G = d->norm_out.groups, rps = d->norm_out.rows_per_sample;
+  if (G <= 0 || rps <= 0 || d->N % G != 0 || d->M % rps != 0 || (d->norm_out.act != GN_ACT_NONE && d->norm_out.act != GN_ACT_SILU)) return 0;
+  const int64_t cpg = d->N / G;
+  if (cpg % 4 != 0 || cpg / 4 > RGN_THREADS || (int64_t)rps * cpg * 2 > kRgnMaxSlab || d->N % 4 != 0 || d->ldo % 4 != 0) return 0;
+  if (((uintptr_t)d->norm_out.y & 7) != 0 || ((uintptr_t)d->out & 7) != 0 || ((uintptr_t)d->norm_out.gamma & 7) != 0 || ((uintptr_t)d->norm_out.beta & 7) != 0) return 0;
+  if (d->residual && d->ldr % 4 != 0) return 0;
+  if (d->shift && ((d->ldshift > 0 ? d->ldshift : d->N) % 4 != 0 || d->rows_per_batch <= 0)) return 0;
+  return plan_gemm(d).splitk > 1 ? 1 : 0;  // the plan (d->tile / d->splitk) must split K: the fusion lives in the reduce launch
+}
+
 extern "C" int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d) {
   if (!d) return 0;
   Plan pl = plan_gemm(d);
@@ -987,6 +1102,9 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   p.a3 = d->k_append ? (const f16*)d->a3 : nullptr; p.C3 = d->k_append ? d->C3 : 0;
   p.a3_bytes = p.a3 ? (unsigned)dma_bytes(d).a3 : p.a_bytes;  // (< 0xFFFFFF00: k_append requires dma_eligible)
   if (pl.splitk > 1) GN_REQUIRE(d->workspace, "gn_gemm: split-K (%d) needs a workspace of gn_gemm_workspace_bytes()", pl.splitk);
+  p.nout.y = (f16*)d->norm_out.y; p.nout.gamma = (const f16*)d->norm_out.gamma; p.nout.beta = (const f16*)d->norm_out.beta;
+  p.nout.eps = d->norm_out.eps; p.nout.groups = d->norm_out.groups; p.nout.act = d->norm_out.act; p.nout.rps = d->norm_out.rows_per_sample;
+  if (d->norm_out.y) GN_REQUIRE(gn_gemm_norm_out_supported(d), "gn_gemm(norm_out): unsupported problem, or a plan that does not split K (gn_gemm_norm_out_supported)");
   p.sink = gn_sink_params(d->sink);
   if (d->sink.stats) {
     GN_REQUIRE(d->out_mode == GN_OUT_ROWMAJOR && !d->out2 && !geglu && !d->fp8 && !d->ln_c1 && (d->batch <= 1 || d->up_phases),
@@ -1057,7 +1175,16 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   GN_LAUNCH_CHECK();
   if (pl.splitk > 1) {
     const long total = (long)p.M * (p.N >> 2);
-    if (p.sink.stats)
+    if (p.nout.y) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        GN_HIP(hipFuncSetAttribute((const void*)splitk_reduce_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgnMaxSlab));
+        attr_set = true;
+      }
+      const int cpg = p.N / p.nout.groups;
+      hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((unsigned)p.nout.groups, (unsigned)(p.M / p.nout.rps)), dim3(RGN_THREADS),
+                         (size_t)p.nout.rps * (cpg / 4) * 8, ctx->stream, p);
+    } else if (p.sink.stats)
       hipLaunchKernelGGL(splitk_reduce_sink_kernel, dim3((unsigned)cdiv64(p.N, 128), (unsigned)cdiv64(p.M, 8)), dim3(256), 0, ctx->stream, p);
     else
       hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx->stream, p);

@@ -47,6 +47,7 @@ struct GemmParams {
                                          // the output pixel of the appended sources a2 (C2 channels), then a3 (C3) -- the LDS-DMA kernels' loaders
   const f16* a3; int C3; unsigned a3_bytes;
   long lda2;                             // dense k_append: out = [A | A2] . W^T -- K tiles from kapp_k0 on read A2 (row stride lda2) through a2
+  struct NormOutP { f16* y; const f16* gamma; const f16* beta; float eps; int groups, act, rps; } nout;  // GroupNorm inside the split-K reduce (gemm.hip)
   GnSinkP sink;                          // GroupNorm bridge, producer side (gn_bridge.h): stats == nullptr = off
   GnInP gin;                             // GroupNorm bridge, consumer side (gemm_s3.hip's normalising A path): stats == nullptr = off
 };

@@ -22,7 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, OUT_BATCH_TRANSPOSED, OUT_ROWMAJOR, TBLOCK_FRONT, TBLOCK_MID,
-                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, StatsSink, TBlockDesc, TBlockTapeSrc, check)
+                   TBLOCK_TAIL, AttnDesc, ConvGnDesc, GemmDesc, GenimaHipError, GroupNormDesc, NormOut, StatsSink, TBlockDesc, TBlockTapeSrc, check)
 
 F16 = torch.float16
 
@@ -78,10 +78,10 @@ class Norm:
 
 class _Writer:
     """The recorded op that wrote a tensor (GroupNorm bridge: its statistics sink is attached when the consuming GroupNorm is recorded)."""
-    __slots__ = ("op", "index", "numel", "sunk", "rdiv")
+    __slots__ = ("op", "index", "numel", "sunk", "rdiv", "gemm")
 
-    def __init__(self, op, index, numel, rdiv=1):
-        self.op, self.index, self.numel, self.sunk, self.rdiv = op, index, numel, False, rdiv  # rdiv: its rows per sample = the tensor's / rdiv
+    def __init__(self, op, index, numel, rdiv=1, gemm=False):
+        self.op, self.index, self.numel, self.sunk, self.rdiv, self.gemm = op, index, numel, False, rdiv, gemm  # rdiv: its rows per sample = the tensor's / rdiv
 
 
 class Engine:
@@ -146,6 +146,11 @@ class Engine:
         # B = 1 call: 22 -> 8.6 us per 64 x 64 x 320 GroupNorm; at B = 8 the statistics tail costs the producing convs more (8 us of 80) than the
         # apply launch saves (profiles/r05_v3_bridge_*): gated by slabs = B x groups
         self.gn_bridge_max_slabs = int(os.environ.get("GN_BRIDGE_MAX_SLABS", "64"))
+        # GroupNorm inside the split-K reduce of the launch that wrote its input (gn_gemm_desc.norm_out; recorded programs; GN_REDUCE_FUSE=0: off)
+        self.gn_reduce_fuse = record and os.environ.get("GN_REDUCE_FUSE", "1") != "0"
+        # one workgroup per (sample, group) slab gathers the partial slabs: it needs the slabs to fill the chip (B = 8: 256 workgroups; at B = 1 the
+        # 32 of them lose to the parallel reduce + GroupNorm pair: 1024 x 640 x 5760 49 vs 29 + 12 us, profiles/r05_v7_reduce_gn_ops_*)
+        self.gn_reduce_fuse_min_slabs = int(os.environ.get("GN_REDUCE_FUSE_MIN_SLABS", "128"))
         self._writer: Dict[int, _Writer] = {}
         self._stats_arena = None
         self._stats_used = 0
@@ -353,10 +358,11 @@ class Engine:
             ws = self._workspace(ws_bytes)
             d.workspace = ws.data_ptr()
         if self.record:
-            if (self.gn_bridge and d.out_mode == OUT_ROWMAJOR and not d.out2 and d.act != ACT_GEGLU and not d.fp8 and (d.batch <= 1 or d.up_phases)
-                    and not d.out_row_width or (self.gn_bridge and d.up_phases)):
+            if (d.out_mode == OUT_ROWMAJOR and not d.out2 and d.act != ACT_GEGLU and not d.fp8 and (d.batch <= 1 or d.up_phases)
+                    and not d.out_row_width or d.up_phases):
+                # the op that wrote this tensor: a GroupNorm recorded later may move into its reduce (norm_out) or take its statistics (bridge)
                 # (a phase conv launch writes the whole upsampled tensor: 4 phases x M rows)
-                self._writer[int(d.out)] = _Writer(self.num_ops, 0, int(d.M) * int(d.N) * (4 if d.up_phases else 1), 4 if d.up_phases else 1)
+                self._writer[int(d.out)] = _Writer(self.num_ops, 0, int(d.M) * int(d.N) * (4 if d.up_phases else 1), 4 if d.up_phases else 1, gemm=True)
             check(self.lib.gn_program_add_gemm(self._prog, C.byref(d)), "gn_program_add_gemm")
             self._keepalive(*keep, ws)
             kind = (f"conv{d.KH}x{d.KW}" if d.conv else "linear")
@@ -476,6 +482,15 @@ class Engine:
             d.sink.stats, d.sink.cpg, d.sink.coff, d.sink.groups, d.sink.rows_per_sample = st.data_ptr(), int(cpg), int(coff), int(st.shape[2]), int(rps)
             d.sink.samples, d.sink.replicas = int(st.shape[1]), int(st.shape[0])
 
+    def _set_norm_out(self, d: GemmDesc, norm_out: Optional["Norm"], out: torch.Tensor, rows_per_sample: int):
+        """Explicit gn_gemm_desc.norm_out (eager calls / tests): -> the normalised output tensor, or None.  The plan must split K."""
+        if norm_out is None:
+            return None
+        y = self.buf(norm_out.name, out.shape)
+        n = d.norm_out
+        n.y, n.gamma, n.beta, n.eps, n.groups, n.act, n.rows_per_sample = _ptr(y), _ptr(norm_out.gamma), _ptr(norm_out.beta), norm_out.eps, norm_out.groups, norm_out.act, int(rows_per_sample)
+        return y
+
     def _norm_in(self, d: GemmDesc, x: torch.Tensor, x2: Optional[torch.Tensor], norm: "Norm", rows: int, stats: Optional[torch.Tensor] = None) -> bool:
         """Try to put ``norm`` (a GroupNorm over x | x2) inside the gn_gemm ``d`` reads them with (gn_gemm_desc.norm_in).  -> done?
         ``stats``: an explicit, already filled statistics block (eager calls / tests) instead of the recorded producers'."""
@@ -503,7 +518,8 @@ class Engine:
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, name: Optional[str] = None,
                transposed_out: bool = False, rows_per_batch: int = 0, pad_cols: int = 0, splitk: int = 0,
                split_n: int = 0, out2: Optional[torch.Tensor] = None, ln_c1: Optional[torch.Tensor] = None, ln_eps: float = 1e-5,
-               append: Optional[torch.Tensor] = None, norm: Optional[Norm] = None, sink=None, norm_stats: Optional[torch.Tensor] = None):
+               append: Optional[torch.Tensor] = None, norm: Optional[Norm] = None, sink=None, norm_stats: Optional[torch.Tensor] = None,
+               norm_out: Optional[Norm] = None):
         """y = act(x @ w.T + bias) (+ residual).  x: [..., K] contiguous f16, w: [N, K].
         transposed_out: y[b, n, m_local] with row stride ``pad_cols`` (>= rows_per_batch; V^T for the attention kernel).
         split_n > 0: ONE launch with two destinations (the q | k | v projections of a self-attention block): columns [0, split_n)
@@ -562,7 +578,10 @@ class Engine:
                 d.a, d.lda = _ptr(n), n.stride(-2)
                 x = n
         self._set_sink(d, sink)
-        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1, append, None if norm is None else norm.gamma, None if norm is None else norm.beta))
+        y = self._set_norm_out(d, norm_out, out, rows_per_batch if rows_per_batch else (x.shape[1] if x.dim() == 3 else M))
+        self._gemm(d, (x, w, bias, residual, out, out2, ln_c1, append, None if norm is None else norm.gamma, None if norm is None else norm.beta, y))
+        if y is not None:
+            return out, y
         return (out, out2) if split_n else out
 
     # ---- fused chains of a transformer block's Linears (csrc/tblock.hip): one launch keeps 128 rows of the residual stream in LDS ----------
@@ -690,7 +709,7 @@ class Engine:
                act: int = ACT_NONE, upsample2x: bool = False, out_scale: float = 1.0, out: Optional[torch.Tensor] = None,
                name: Optional[str] = None, splitk: int = 0, residual_before_act: bool = False, up_phases: bool = False,
                append: Optional[torch.Tensor] = None, append2: Optional[torch.Tensor] = None, norm: Optional[Norm] = None, sink=None,
-               norm_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+               norm_stats: Optional[torch.Tensor] = None, norm_out: Optional[Norm] = None) -> torch.Tensor:
         """``append`` [B, H, W, C2] (+ ``append2`` [B, H, W, C3], the rest of a concatenated input): a 1x1 conv appended along K
         (gn_gemm_desc.k_append) -- w = [Cout, k*k*C1 + C2 + C3], the 1x1 weight behind the packed k x k weight (packing: ``*.conv2sc.weight``):
         ResnetBlock2D's conv2(h) + conv_shortcut(x) as one launch.
@@ -746,8 +765,9 @@ class Engine:
             else:
                 d.a = _ptr(n)
             x = n
-        self._gemm(d, (x, x2, w, bias, shift, residual, out, append2, None if norm is None else norm.gamma, None if norm is None else norm.beta))
-        return out
+        y = self._set_norm_out(d, norm_out, out, Ho * Wo)
+        self._gemm(d, (x, x2, w, bias, shift, residual, out, append2, None if norm is None else norm.gamma, None if norm is None else norm.beta, y))
+        return out if y is None else (out, y)
 
     def conv2d_up2x(self, x: torch.Tensor, w4: torch.Tensor, bias: Optional[torch.Tensor] = None, *, name: Optional[str] = None) -> torch.Tensor:
         """conv3x3(nearest_upsample_2x(x)) as its four phase convs (packing.pack_upsample_phases): phase (dy, dx) is a 2x2 conv over the
@@ -877,6 +897,8 @@ class Engine:
         d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, C1, C2, groups, act, eps
         ws = self._workspace(int(self.lib.gn_groupnorm_workspace_bytes(C.byref(d))))
         d.workspace = ws.data_ptr()
+        if stats_in is None and x2 is None and self._norm_out(x, gamma, beta, groups, eps, act, out, B, HW, C1):
+            return out  # the launch that wrote x normalises it in its split-K reduce: no GroupNorm op
         st = stats_in
         if st is None and getattr(self, "gn_apply_from_stats", True) and gamma.data_ptr() % 16 == 0 and beta.data_ptr() % 16 == 0:
             st = self.bridge_stats(x, x2, groups)
@@ -889,6 +911,30 @@ class Engine:
         else:
             check(self.lib.gn_groupnorm_fwd(self._ctx, C.byref(d)), "gn_groupnorm_fwd")
         return out
+
+    def _norm_out(self, x, gamma, beta, groups, eps, act, out, B, HW, Cc) -> bool:
+        """Recorded programs: move this GroupNorm (+ activation) into the split-K reduce of the gn_gemm that wrote x (gn_gemm_desc.norm_out).
+        -> done?  (No: x was not written by a K-split launch of this program, is also being normalised elsewhere, or the slab does not fit.)"""
+        if not (self.record and self.gn_reduce_fuse) or B * groups < self.gn_reduce_fuse_min_slabs:
+            return False
+        w = self._writer.get(x.data_ptr())
+        if w is None or not w.gemm or w.sunk or w.rdiv != 1 or w.numel != x.numel() or not x.is_contiguous() or not out.is_contiguous():
+            return False
+        n = NormOut()
+        n.y, n.gamma, n.beta, n.eps, n.groups, n.act, n.rows_per_sample = _ptr(out), _ptr(gamma), _ptr(beta), float(eps), int(groups), int(act), int(HW)
+        d = GemmDesc()
+        if self.lib.gn_program_get_gemm(self._prog, w.op, C.byref(d)) != 0 or d.norm_out.y:
+            return False
+        d.norm_out = n
+        if not self.lib.gn_gemm_norm_out_supported(C.byref(d)):
+            return False
+        check(self.lib.gn_program_set_norm_out(self._prog, w.op, C.byref(n)), "gn_program_set_norm_out")
+        w.sunk = True
+        self._keepalive(gamma, beta, out)
+        m = self.meta[w.op]
+        m["norm_out"] = (B, HW, Cc)
+        m["bytes"] = m.get("bytes", 0.0) + 2.0 * B * HW * Cc  # the normalised tensor's write joins the launch
+        return True
 
     def groupnorm_stats(self, x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, *,
                         name: Optional[str] = None) -> torch.Tensor:

@@ -86,6 +86,22 @@ typedef struct gn_norm_in {
   int32_t samples, replicas; /* extents of the statistics block */
 } gn_norm_in;
 
+/* GroupNorm fused into a split-K launch's REDUCE (round 5): the small-M convs of the 8x8 .. 32x32 latent levels split K and finish in a reduce
+ * kernel anyway; with norm_out set that kernel owns one (sample, group) slab per workgroup -- it sums the partial slabs, applies the epilogue,
+ * stores the raw f16 tensor to `out` as usual AND GroupNorm(+ SiLU) of it to `y`: diffusers ResnetBlock2D's conv1 -> norm2 -> SiLU and
+ * conv2 -> next block's norm1 / Transformer2DModel.norm without the GroupNorm launch.  Row-major f16 output, rows_per_batch rows per sample,
+ * N % groups == 0, an even group width, a slab (rows_per_batch x N / groups f16) of at most 96 KB; ignored (error) when the plan does not split K
+ * (gn_gemm_workspace_bytes() == 0). */
+typedef struct gn_norm_out {
+  void* y;                 /* [M, N] f16 normalised output (row stride N); NULL = off */
+  const void* gamma;       /* f16 [N] */
+  const void* beta;
+  float eps;
+  int32_t groups;
+  int32_t act;             /* GN_ACT_NONE or GN_ACT_SILU */
+  int32_t rows_per_sample;
+} gn_norm_out;
+
 typedef struct gn_gemm_desc {
   const void* a;          /* A source 1: dense [M, lda] or NHWC [B, H, W, C1] */
   const void* a2;         /* conv only: second NHWC source [B, H, W, C2], virtually concatenated on channels; or NULL */
@@ -174,8 +190,10 @@ typedef struct gn_gemm_desc {
    * in LDS after it lands, taps in the zero padding stay zero, an appended k_append segment stays raw.  Ring tiles 16 .. 22, conv or dense,
    * C1 (and C2) % 64 == 0; a row tile may span at most 4 samples (gn_gemm_norm_in_supported). */
   gn_norm_in norm_in;
+  gn_norm_out norm_out;   /* GroupNorm of the output inside the split-K reduce (above) */
 } gn_gemm_desc;
 int32_t gn_gemm_norm_in_supported(const gn_gemm_desc* d);
+int32_t gn_gemm_norm_out_supported(const gn_gemm_desc* d); /* the problem AND its plan (tile / splitk as set in d) take norm_out */
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
 int32_t gn_set_gemm_tile_override(int32_t cfg);
@@ -580,11 +598,13 @@ int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_
  * afterwards -- op = a recorded gn_gemm (index 0) or gn_add_multi (index = which of its tensors); and the statistics arena is cleared by a
  * memset op at the top of every replay */
 int32_t gn_program_set_sink(gn_program* p, int64_t op, int32_t index, const gn_stats_sink* sink, int32_t channels);
+/* attach norm_out to a recorded gn_gemm (the GroupNorm that reads its output is recorded after it) */
+int32_t gn_program_set_norm_out(gn_program* p, int64_t op, const gn_norm_out* n);
 int32_t gn_program_add_memset(gn_program* p, void* ptr, int64_t bytes);
 int32_t gn_program_set_memset_bytes(gn_program* p, int64_t op, int64_t bytes); /* shrink a recorded memset to the bytes the program came to use */
 int32_t gn_memset(gn_ctx* ctx, void* ptr, int64_t bytes);
 /* sizeof() of the descriptor structs as the library was compiled (0 gn_gemm_desc, 1 gn_attn_desc, 2 gn_groupnorm_desc, 3 gn_tblock_desc,
- * 4 gn_conv3x3_gn_desc, 5 gn_stats_sink, 6 gn_norm_in): a host binding checks its own layout against these before the first call */
+ * 4 gn_conv3x3_gn_desc, 5 gn_stats_sink, 6 gn_norm_in, 7 gn_norm_out): a host binding checks its own layout against these before the first call */
 int64_t gn_desc_sizeof(int32_t which);
 /* first..last (exclusive) op range; last < 0 = to the end */
 int32_t gn_program_run(gn_program* p, int64_t first, int64_t last);

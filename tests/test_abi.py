@@ -33,9 +33,10 @@ def test_loader_binds_and_reports_version():
     # out2 + ldo2 + split_n + ln_eps, ln_c1, out_row_width (+pad) + ldo_hi, up_phases (+tail pad)
     base = 8 * 8 + 8 * 8 + 24 * 4 + 8 * 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # ... k_append in up_phases' tail pad, a3, C3 (+pad), lda2
     assert ctypes.sizeof(_lib.StatsSink) == 32 and ctypes.sizeof(_lib.NormIn) == 56  # pointer + 6 int32; 3 pointers + float + 6 int32 (+ tail pad)
-    assert ctypes.sizeof(_lib.GemmDesc) == base + 32 + 56  # the GroupNorm bridge's sink + norm_in
+    assert ctypes.sizeof(_lib.NormOut) == 40  # 3 pointers + float + 3 int32
+    assert ctypes.sizeof(_lib.GemmDesc) == base + 32 + 56 + 40  # the GroupNorm bridge's sink + norm_in, the reduce-side norm_out
     # ... and the compiled structs agree with the binding's (the loader refuses a mismatch)
-    for which, cls in enumerate((_lib.GemmDesc, _lib.AttnDesc, _lib.GroupNormDesc, _lib.TBlockDesc, _lib.ConvGnDesc, _lib.StatsSink, _lib.NormIn)):
+    for which, cls in enumerate((_lib.GemmDesc, _lib.AttnDesc, _lib.GroupNormDesc, _lib.TBlockDesc, _lib.ConvGnDesc, _lib.StatsSink, _lib.NormIn, _lib.NormOut)):
         assert int(lib.gn_desc_sizeof(which)) == ctypes.sizeof(cls), cls.__name__
 
 

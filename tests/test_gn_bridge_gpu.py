@@ -95,6 +95,7 @@ def test_linear_and_phase_conv_producer_statistics():
     B, H, C = 2, 16, 128
     x, w, b = randn_h(B, H, H, C, seed=5), randn_h(C, C, 3, 3, seed=6, scale=0.04), randn_h(C, seed=7)
     ER = Engine("cuda:0", record=True, autotune=False, gn_bridge=True)
+    ER.gn_reduce_fuse = False
     W = {"u.weight": pack_conv_weight(w.float().cpu()).cuda(), "u.bias": b}
     W["u.up4.weight"] = pack_upsample_phases(w.float().cpu()).cuda()
     up = ER.conv2d_up2x(x, W["u.up4.weight"], b, name="up")
@@ -251,6 +252,7 @@ def test_recorded_resnet_through_the_bridge():
     for bridge in (True, False):
         E = Engine("cuda:0", record=True, autotune=False, gn_bridge=bridge)
         E.gn_fuse_max_rows = 4096  # (the consumer-side normalisation is opt-in by rows: GN_BRIDGE_FUSE_MAX_ROWS)
+        E.gn_reduce_fuse = False   # (the other route of round 5 -- GroupNorm in the split-K reduce, tests/test_norm_out_gpu.py -- would take these)
         x0d = x0.permute(0, 2, 3, 1).contiguous().half().cuda()
         shifts = q16(sh_ref).half().cuda()
         xd = E.conv2d(x0d, W["pre.weight"], W["pre.bias"], name="pre")
@@ -275,6 +277,7 @@ def test_recorded_resnet_through_the_bridge():
     # above the row gate the GroupNorm is ONE apply launch fed by the producer's statistics
     E = Engine("cuda:0", record=True, autotune=False, gn_bridge=True)
     E.gn_fuse_max_rows = 0
+    E.gn_reduce_fuse = False
     xd = E.conv2d(x0.permute(0, 2, 3, 1).contiguous().half().cuda(), W["pre.weight"], W["pre.bias"], name="pre")
     Wm = dict(W)
     Wm["__meta__"] = {"temb_slices": {"r": (0, Cout)}}
