@@ -223,7 +223,8 @@ def single_view_latency(pipe, dev, denoise_steps, rank, calls=10, workload="sing
     B, H, W, desc = WORKLOADS[workload]
     ids, img, lat = synthetic_inputs(pipe, B, H, W, dev, rank)
     res = {}
-    for graph in (False, True):
+    skip = os.environ.get("GN_BENCH_SKIP", "").split(",")  # bisect aid (profiles/r05_v9_train_order.txt): graph / two_calls / single / tiled_b1
+    for graph in ((False,) if "graph" in skip else (False, True)):
         pipe.enable_hip_graph(graph)
         for _ in range(3):
             pipe(prompt_ids=ids, image=img, latents=lat, num_inference_steps=denoise_steps, guidance_scale=0.0, output_type="pt")
@@ -420,6 +421,57 @@ def main():
         out["value"] = B * world * calls / dt
         out["images_per_sec_per_gpu"] = out["value"] / world
 
+    # BASELINE.json's second metric on the same launch: the ControlNet fine-tune step (configs[3], per-GPU batch 8), N ranks data
+    # parallel with the bucketed RCCL reduce-scatter + all-gather of the flat gradient overlapped with the backward.
+    # Measured IN THIS PROCESS.  At N = 1 it runs right behind the headline loop, before the other extras: behind them (two more recorded
+    # programs with their hipGraphs, a second B = 8 buffer set, 2 000 event pairs of the per-op replay) the same step read 3 - 4 ms slower
+    # (66.1 against 61.7 ms, profiles/r04_v7_train_inline_bisect.txt) and round 4 moved it into a process of its own; in front of them it reads what
+    # `python bench_train.py` reads (profiles/r05_v9_train_order.txt).  GN_BENCH_TRAIN=subprocess / last restore the other two methods.
+    def run_train_extra(free_pipeline: bool):
+        nonlocal pipe, act_agent
+        if free_pipeline:
+            del pipe, act_agent
+            pipe = act_agent = None
+            import gc
+
+            gc.collect()  # the recorded programs sit in reference cycles: free them (and their device buffers) now, not inside a timed train step
+            torch.cuda.empty_cache()
+        try:
+            line, method = None, "in this process"
+            if world == 1 and os.environ.get("GN_BENCH_TRAIN") == "subprocess":
+                import subprocess
+
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "3"],
+                                   capture_output=True, text=True, timeout=900)
+                tail = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+                if r.returncode == 0 and tail:
+                    line = json.loads(tail[-1])
+                    method = "bench_train.py in a process of its own"
+                else:
+                    method = f"in this process (subprocess rc {r.returncode}: {(r.stderr or r.stdout).strip()[-200:]})"
+            if line is None:
+                import bench_train
+
+                targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "3"])  # (as `bench_train.py --steps 10 --warmup 3`: the trainer builds its lazily
+                # derived state -- weight copies, their one-launch table, gc.freeze -- in its first steps, and consecutive steps overlap)
+                line = bench_train.run(targs)
+            if rank == 0 and line is not None:
+                line["process"] = method + ("" if free_pipeline else ", right behind the headline loop (inference pipeline resident)")
+                out["train"] = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "samples_per_sec",
+                                                     "dtype", "config", "roofline", "peak_mem_gb", "loss_first", "loss_last", "scaling", "process") if k in line}
+        except Exception as e:
+            if rank == 0:
+                out["train"] = {"error": repr(e)[:300]}
+        import gc
+
+        gc.unfreeze()  # (ControlNetTrainer(gc_freeze=True) parks every live object in the permanent generation)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    train_first = world == 1 and os.environ.get("GN_BENCH_TRAIN", "first") == "first"
+    if not args.no_train and train_first:
+        run_train_extra(free_pipeline=False)
+
     if rank == 0 and world == 1 and not args.no_roofline:
         io = pipe.program(B, H, W, args.denoise_steps)
         if args.graph:
@@ -471,53 +523,14 @@ def main():
             out["tiled_b1"] = single_view_latency(pipe, dev, args.denoise_steps, rank, workload="tiled_b1")
         except Exception as e:
             out["tiled_b1"] = {"error": repr(e)[:300]}
-        if args.workload == "tiled_b8" and args.family == "sd-turbo":
+        if args.workload == "tiled_b8" and args.family == "sd-turbo" and "two_calls" not in os.environ.get("GN_BENCH_SKIP", "").split(","):
             try:
                 out["two_calls_in_flight"] = two_calls_in_flight(pipe, dev, args.denoise_steps, rank)
             except Exception as e:
                 out["two_calls_in_flight"] = {"error": repr(e)[:300]}
 
-    # BASELINE.json's second metric on the same launch: the ControlNet fine-tune step (configs[3], per-GPU batch 8), N ranks data
-    # parallel with the bucketed RCCL reduce-scatter + all-gather of the flat gradient overlapped with the backward
-    if not args.no_train:
-        del pipe, act_agent
-        import gc
-
-        gc.collect()  # the recorded programs sit in reference cycles: free them (and their device buffers) now, not inside a timed train step
-        torch.cuda.empty_cache()
-        try:
-            line, fallback_note = None, ""
-            if world == 1 and os.environ.get("GN_BENCH_TRAIN_INPROC") != "1":
-                # one GPU: the train step is measured as `python bench_train.py --steps K --warmup 3` measures it, in a process of its own.
-                # In THIS process the step reads 3 - 4 ms slower once both inference extras have run (66.1 against 62.7 ms with either one
-                # left out, profiles/r04_v7_train_inline_bisect.txt) -- a property of this script's history (what the extras leave behind in the
-                # process: recorded programs, captured graphs, streams, a large Python heap), not of the trainer; the cause is not located
-                # (not thermal: --warmup 40 reads the same; not the hardware-queue count: GPU_MAX_HW_QUEUES 2 / 4 / 8 read the same).
-                import subprocess
-
-                r = subprocess.run([sys.executable, os.path.join(ROOT, "bench_train.py"), "--steps", str(args.train_steps), "--warmup", "3"],
-                                   capture_output=True, text=True, timeout=900)
-                tail = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
-                if r.returncode == 0 and tail:
-                    line = json.loads(tail[-1])
-                    line["process"] = "bench_train.py in a process of its own"
-                else:  # the fallback below measures in THIS process: say so, and why (the two methods differ by 3 - 4 ms)
-                    fallback_note = f"subprocess rc {r.returncode}: {(r.stderr or r.stdout).strip()[-200:]}"
-            if line is None:
-                import bench_train
-
-                targs = bench_train.parse_args(["--gpus", str(world), "--steps", str(args.train_steps), "--warmup", "3"])  # (as `bench_train.py --steps 10 --warmup 3`: the trainer builds its lazily
-                # derived state -- weight copies, their one-launch table, gc.freeze -- in its first steps, and consecutive steps overlap)
-                line = bench_train.run(targs)
-                if line is not None:
-                    line["process"] = "in this process (after the inference extras)" + (f"; {fallback_note}" if fallback_note else "")
-            if rank == 0 and line is not None:
-                out["train"] = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "samples_per_sec",
-                                                     "dtype", "config", "roofline", "peak_mem_gb", "loss_first", "loss_last", "scaling", "process") if k in line}
-        except Exception as e:
-            if rank == 0:
-                out["train"] = {"error": repr(e)[:300]}
-        torch.cuda.empty_cache()
+    if not args.no_train and not train_first:
+        run_train_extra(free_pipeline=os.environ.get("GN_BENCH_TRAIN") != "last_keep")  # (last_keep: the bisect of what the extras leave behind)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

@@ -174,7 +174,11 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_stream_kernel(const AttnParam
       pc[k >> 2][(2 * k) & 7] = pk[k][0];
       pc[k >> 2][((2 * k) & 7) + 1] = pk[k][1];
     };
+#ifdef GN_ATTN_SUM_F32
+    auto S = [&](int k) { psum += ex[2 * k] + ex[2 * k + 1]; };  // (experiment: the row sum from the f32 exponentials, two v_add_f32 instead of one v_dot2c_f32_f16)
+#else
     auto S = [&](int k) { psum = __builtin_amdgcn_fdot2(pk[k], ones, psum, false); };
+#endif
     auto M = [&](int i) {
       const int n = i >> 1;
       if ((i & 1) == 0) sn = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[i], qf[n], n == 0 ? negm : sn, 0, 0, 0);
