@@ -189,6 +189,7 @@ SIGNATURES = {
     "gn_quantize_fp8_rows": (_I32, [_P, _P, _I64, _I64, _I32, _P, _I64, _P]),
     "gn_maxpool3x3s2": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32]),
     "gn_transpose2d": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
+    "gn_transpose2d_zpad": (_I32, [_P, _P, _P, _I32, _I32, _I64, _I64, _I32, _I64, _I64]),
     "gn_transpose2d_multi": (_I32, [_P, _P, _I32, _I32]),
     "gn_im2col_t": (_I32, [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _I32]),
     "gn_wgrad_workspace_bytes": (_I64, [C.POINTER(WgradDesc)]),

@@ -318,7 +318,7 @@ int32_t gn_program_get_gemm(const gn_program* p, int64_t op, gn_gemm_desc* out) 
 int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_t splitk, void* workspace) {
   GN_REQUIRE(p && op >= 0 && op < (int64_t)p->ops.size() && p->ops[(size_t)op].type == OP_GEMM, "gn_program_set_gemm_plan: op %ld is not a gn_gemm", (long)op);
   GN_REQUIRE(!p->exec, "gn_program_set_gemm_plan: the program is captured (re-capture after tuning)");
-  GN_REQUIRE(tile >= 0 && tile <= 23 && splitk >= 0, "gn_program_set_gemm_plan: tile %d (0 = heuristic, 1 .. 23) / splitk %d out of range", tile, splitk);
+  GN_REQUIRE(tile >= 0 && tile <= 24 && splitk >= 0, "gn_program_set_gemm_plan: tile %d (0 = heuristic, 1 .. 24) / splitk %d out of range", tile, splitk);
   gn_gemm_desc d = p->ops[(size_t)op].gemm;  // validated on a copy: a refused plan leaves the recorded op as it was
   d.tile = tile; d.splitk = splitk;
   if (workspace) d.workspace = workspace;

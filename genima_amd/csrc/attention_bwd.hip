@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(c
   for (int t = 0; t + 1 < ntiles; ++t) tile(std::false_type{});
   if (ntiles > 0) tile(std::true_type{});
 
-  if (klive) {
+  if (key < p.Nk_rows) {  // the padding rows [Nk, Nk_rows) of this 128-key block come out as zeros (no fill launch in front of the kernel)
     f16* okp = p.dk + (long)b * p.dk_bs + (long)key * p.dk_rs + h * D;
     f16* ovp = p.dv + (long)b * p.dv_bs + (long)key * p.dv_rs + h * D;
 #pragma unroll
@@ -378,8 +378,8 @@ __global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(c
         f16x4 a, v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          a[i] = (f16)accK[dt][4 * g + i];
-          v[i] = (f16)accV[dt][4 * g + i];
+          a[i] = klive ? (f16)accK[dt][4 * g + i] : (f16)0.0f;
+          v[i] = klive ? (f16)accV[dt][4 * g + i] : (f16)0.0f;
         }
         *reinterpret_cast<f16x4*>(okp + dt * 32 + 8 * g + 4 * hi) = a;
         *reinterpret_cast<f16x4*>(ovp + dt * 32 + 8 * g + 4 * hi) = v;

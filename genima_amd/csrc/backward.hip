@@ -13,8 +13,10 @@ namespace {
 inline unsigned nblk(long n, int t = 256) { return (unsigned)((n + t - 1) / t); }
 
 // ---- tiled transpose: out[b][c][r] = in[b][r][c] -----------------------------------------------------------------------
+// zrows: output columns [rows, zrows) are written as zeros (gn_transpose2d: zrows = rows -- nothing past the data is touched;
+// gn_transpose2d_zpad: zrows = ld_out <= rup(rows, 64), the GEMM-operand padding without a fill launch in front)
 __global__ __launch_bounds__(256) void transpose2d_kernel(const f16* __restrict__ in, f16* __restrict__ out, int rows, int cols,
-                                                          long ld_in, long ld_out, long in_bs, long out_bs) {
+                                                          long ld_in, long ld_out, long in_bs, long out_bs, int zrows) {
   __shared__ f16 tile[64][66];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const f16* __restrict_
   __syncthreads();
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
-    if (c < cols && r < rows) out[(long)c * ld_out + r] = tile[tx][i];
+    if (c < cols && r < zrows) out[(long)c * ld_out + r] = tile[tx][i];
   }
 }
 
@@ -52,7 +54,8 @@ __device__ __forceinline__ uint4 tile_load_column_chunk(uint32_t (*tile)[33], in
 // (the weight-gradient path transposes dY anyway; reading it a second time for gn_colsum_f32 cost 1.5 ms per train step)
 template <bool SUMS>
 __global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restrict__ in, f16* __restrict__ out, int rows, int cols, long ld_in,
-                                                              long ld_out, long in_bs, long out_bs, float* __restrict__ part, int row_tiles) {
+                                                              long ld_out, long in_bs, long out_bs, float* __restrict__ part, int row_tiles,
+                                                              int zrows) {  // zrows: see transpose2d_kernel (a multiple of 8 or == rows)
   // row_tiles (SUMS only): consecutive 64-row tiles one block walks, so that the partial-sum matrix stays short (<= 128 rows: the
   // second-stage reduction reads all of it)
   __shared__ uint32_t tile[64][33];
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(256) void transpose2d_vec_kernel(const f16* __restr
     for (int it = 0; it < 2; ++it) {
       const int oc = hi + 32 * it, c = c0 + oc, r = r0 + lo * 8;
       const uint4 v = tile_load_column_chunk(tile, lo * 8, oc);  // rows past `rows` were stored as zeros
-      if (c < cols && r < rows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = v;
+      if (c < cols && r < zrows) *reinterpret_cast<uint4*>(out + (long)c * ld_out + r) = v;
       if (SUMS) {
         const f16x8 h = *reinterpret_cast<const f16x8*>(&v);
 #pragma unroll
@@ -796,20 +799,35 @@ __global__ void ema_flat_kernel(float* __restrict__ shadow, const float* __restr
 
 extern "C" {
 
-int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
-                       int64_t in_bs, int64_t out_bs) {
-  GN_REQUIRE(ctx && in && out && rows > 0 && cols > 0 && batch > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d: bad arguments");
+static int32_t transpose2d_launch(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
+                                  int64_t in_bs, int64_t out_bs, int zrows) {
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch);
   const bool vec = cols % 8 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && in_bs % 8 == 0 && out_bs % 8 == 0 && ld_out >= (rows + 7) / 8 * 8 &&
                    ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0;
   if (vec)
     hipLaunchKernelGGL(transpose2d_vec_kernel<false>, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
-                       (long)in_bs, (long)out_bs, (float*)nullptr, 1);
+                       (long)in_bs, (long)out_bs, (float*)nullptr, 1, zrows);
   else
     hipLaunchKernelGGL(transpose2d_kernel, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
-                       (long)in_bs, (long)out_bs);
+                       (long)in_bs, (long)out_bs, zrows);
   GN_LAUNCH_CHECK();
   return GN_OK;
+}
+
+int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
+                       int64_t in_bs, int64_t out_bs) {
+  GN_REQUIRE(ctx && in && out && rows > 0 && cols > 0 && batch > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d: bad arguments");
+  return transpose2d_launch(ctx, in, out, rows, cols, ld_in, ld_out, batch, in_bs, out_bs, rows);
+}
+
+/* gn_transpose2d that also writes the padding: columns [rows, ld_out) of every output row come out as zeros (a GEMM operand whose reduction
+ * length is padded: the cross-attention V^T of 77 tokens in a 128-column matrix).  ld_out <= round_up(rows, 64): the padding lies inside the
+ * last 64-row tile the launch walks anyway. */
+int32_t gn_transpose2d_zpad(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out, int32_t batch,
+                            int64_t in_bs, int64_t out_bs) {
+  GN_REQUIRE(ctx && in && out && rows > 0 && cols > 0 && batch > 0 && ld_in >= cols && ld_out >= rows, "gn_transpose2d_zpad: bad arguments");
+  GN_REQUIRE(ld_out <= ((int64_t)rows + 63) / 64 * 64, "gn_transpose2d_zpad: ld_out (%ld) must not exceed round_up(rows = %d, 64)", (long)ld_out, rows);
+  return transpose2d_launch(ctx, in, out, rows, cols, ld_in, ld_out, batch, in_bs, out_bs, (int)ld_out);
 }
 
 /* n_items gn_transpose2d problems in one launch (csrc comment at transpose2d_multi_kernel): `items` lives in DEVICE memory, every item as
@@ -839,7 +857,7 @@ int32_t gn_transpose2d_colsum(gn_ctx* ctx, const void* in, void* out, int32_t ro
   while (t1 % (rt * 2) == 0 && t2 % (rt * 2) == 0 && (long)rows / 64 / rt > 128) rt *= 2;
   const dim3 grid((cols + 63) / 64, rows / 64 / rt, 1);
   hipLaunchKernelGGL(transpose2d_vec_kernel<true>, grid, dim3(256), 0, ctx->stream, (const f16*)in, (f16*)out, rows, cols, (long)ld_in, (long)ld_out,
-                     0l, 0l, (float*)workspace, rt);
+                     0l, 0l, (float*)workspace, rt, rows);
   GN_LAUNCH_CHECK();
   hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3(nblk((long)groups * cols, 64)), dim3(256), 0, ctx->stream, (const float*)workspace, sums, groups,
                      t1 / rt, cols, 1);

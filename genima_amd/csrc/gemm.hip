@@ -818,8 +818,11 @@ constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, fa
                         // workgroups each (the K loop of those launches is bound by L2 -> LDS bytes per CU: bigger tile, fewer bytes)
                         {128, 160, 0.0, false, true},  {64, 160, 0.0, false, true},   {64, 320, 0.0, false, true},
                         // 2-stage 128x160 (two workgroups per CU)
-                        {128, 160, 0.0, false, true}};
-constexpr int kNumCfg = 23;
+                        {128, 160, 0.0, false, true},
+                        // 2-stage 128x320 on EIGHT waves of 32x160 (round 5): the wave tile of the 128x160 tile with all of N = 320 in one workgroup --
+                        // the A tile is staged once for both column halves (10.9 instead of 14 LDS-DMA bytes per kFLOP), one workgroup per CU
+                        {128, 320, 0.0, false, true}};
+constexpr int kNumCfg = 24;
 constexpr int kCfgS3End = 22;  // one past the last 3-stage configuration
 constexpr int kCfgPP = 14;
 constexpr int kCfgS3 = 15;  // first of the four 3-stage configurations
@@ -891,15 +894,15 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
   if (geglu && !kCfg[best].geglu) best = 1;
   if (d->ln_c1) {  // LayerNorm fold: the LDS-DMA kernels (two-stage and ring) carry it
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22, 23};
     best = to_dma[best];
   }
   if (d->k_append && !kCfg[best].dma) {  // the appended segment lives in the LDS-DMA loaders
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23};
     best = to_dma[best];
   }
   if (d->norm_in.stats) {  // the normalising A path lives in the ring kernels (gemm_s3.hip): 15 .. 21 = {128x128, 128x64, 64x64, 256x64, 128x160, 64x160, 64x320}
-    static const int to_s3[kNumCfg] = {18, 15, 16, 17, 18, 15, 15, 18, 15, 16, 17, 18, 19, 19, 15, 15, 16, 17, 18, 19, 20, 21, 19};
+    static const int to_s3[kNumCfg] = {18, 15, 16, 17, 18, 15, 15, 18, 15, 16, 17, 18, 19, 19, 15, 15, 16, 17, 18, 19, 20, 21, 19, 19};
     best = to_s3[best];
     // a row tile spans whole samples or lies inside one (the kernel's scale / shift table covers <= 4 of them)
     const int64_t rps = d->conv ? (int64_t)d->Ho * d->Wo : d->norm_in.rows_per_sample;
@@ -911,7 +914,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   }
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
-    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1};
+    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1, 1};
     best = fallback[best];
   }
   pl.cfg = best;
@@ -1137,7 +1140,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     p.sa = (const float*)d->scale_a; p.sw = (const float*)d->scale_w;
     p.a_bytes = (unsigned)((uint64_t)d->M * d->lda); p.w_bytes = (unsigned)((uint64_t)d->N * d->ldw);
     p.splitk = 1; p.kper = (int)d->K;
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11, 8, 9, 9, 8};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11, 8, 9, 9, 8, 8};
     const int cfg = to_dma[pl.cfg];
     const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
     p.tiles_m = (int)cdiv64(d->M, bm); p.tiles_n = (int)cdiv64(d->N, bn);
@@ -1170,6 +1173,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 13: launch_dma<256, 320, 4, 2>(p, conv, ctx->stream); break;
     case 14: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, 1, ctx->stream); break;
     case 22: launch_dma<128, 160, 4, 1>(p, conv, ctx->stream); break;
+    case 23: launch_dma<128, 320, 4, 2>(p, conv, ctx->stream); break;
     default: gn_launch_gemm_s3(&p, pl.cfg - kCfgS3, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;
   }
   GN_LAUNCH_CHECK();

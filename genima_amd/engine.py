@@ -13,6 +13,7 @@ Layout conventions: activations NHWC f16 ``[B, H, W, C]`` == token-major ``[B, H
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import json
 import os
@@ -132,6 +133,7 @@ class Engine:
         self.buffers: Dict[str, torch.Tensor] = {}
         self._keep = []  # tensors referenced by recorded ops
         self._scope = []
+        self._zpool = None  # eager: [pre-zeroed slab, next free element] while an emitter holds zero_pool()
         self.captured = False
         self.meta = []  # per recorded op: dict(kind, flops, bytes) -- algorithmic work for the roofline accounting
         # ---- the GroupNorm bridge (csrc/gn_bridge.h; recorded programs): statistics out of the op that writes a tensor, GroupNorm-apply inside
@@ -187,10 +189,35 @@ class Engine:
     def scope(self, name: str):
         return Engine._Scope(self, name)
 
+    @contextlib.contextmanager
+    def zero_pool(self, numel: int):
+        """Eager mode: the zero-padded outputs requested inside the block (``buf(zero=True)``: transposed V^T matrices whose pad columns no
+        kernel writes) are cut from ONE pre-zeroed f16 slab of ``numel`` elements (+ 64 per request) -- one fill launch per emitter instead
+        of one per layer (the fine-tune step ran 39 of them per step in front of its CLIP / cross-attention projections).  Recording engines
+        keep their persistent named buffers and ignore this."""
+        if self.record or numel <= 0:
+            yield
+            return
+        old = self._zpool
+        self._zpool = [torch.zeros(int(numel), dtype=F16, device=self.device), 0]
+        try:
+            yield
+        finally:
+            self._zpool = old
+
     def buf(self, name: Optional[str], shape, dtype=F16, zero: bool = False) -> torch.Tensor:
         """Output buffer.  Eager: a fresh tensor.  Record: a persistent tensor keyed by the scoped name."""
         shape = tuple(int(s) for s in shape)
         if not self.record or name is None:
+            pool = self._zpool
+            if zero and pool is not None and dtype == F16:  # eager: a slice of the emitter's one pre-zeroed slab (zero_pool)
+                n = 1
+                for v in shape:
+                    n *= v
+                off = pool[1]
+                if off + n <= pool[0].numel():
+                    pool[1] = off + (n + 63) // 64 * 64
+                    return pool[0][off:off + n].view(shape)
             return (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
         key = "/".join(self._scope + [name])
         t = self.buffers.get(key)
@@ -251,7 +278,7 @@ class Engine:
     # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
     # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
     _retuned = set()  # shapes already re-raced in this process (GN_RETUNE)
-    N_TILE_CFGS = 23  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..22 3-stage ring, 23 2-stage 128x160 (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip)
+    N_TILE_CFGS = 24  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..22 3-stage ring, 23 2-stage 128x160, 24 2-stage 128x320 on 8 waves (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip)
 
     @staticmethod
     def _tune_key(d: GemmDesc) -> str:

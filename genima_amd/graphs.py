@@ -128,12 +128,13 @@ def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[
     """K / V^T projections of the (constant) prompt states for every cross-attention layer, hoisted out of the step loop."""
     B, L, _ = ctx.shape
     kv = {}
-    for name in W:
-        if name.endswith(".attn2.to_k.weight"):
-            p = name[: -len(".to_k.weight")]
+    sites = [name[: -len(".to_k.weight")] for name in W if name.endswith(".attn2.to_k.weight")]
+    pad = _rup(L, 64)
+    with E.zero_pool(sum(B * W[p + ".to_v.weight"].shape[0] * pad + 64 for p in sites) if pad != L else 0):  # (eager engines: one fill for all V^T)
+        for p in sites:
             with E.scope(tag + "/" + p):
-                k = E.linear(ctx, W[name], name="k")
-                vt = E.linear(ctx, W[p + ".to_v.weight"], transposed_out=True, rows_per_batch=L, pad_cols=_rup(L, 64), name="vt")
+                k = E.linear(ctx, W[p + ".to_k.weight"], name="k")
+                vt = E.linear(ctx, W[p + ".to_v.weight"], transposed_out=True, rows_per_batch=L, pad_cols=pad, name="vt")
             kv[p] = (k, vt)
     return kv
 
@@ -457,7 +458,8 @@ def emit_clip_text(E: Engine, W, cfg, ids: torch.Tensor, hidden: Optional[List[t
     eps = cfg.get("layer_norm_eps", 1e-5)
     D = cfg["hidden_size"]
     act = ACT_QUICK_GELU if cfg["hidden_act"] == "quick_gelu" else ACT_GELU
-    with E.scope("clip"):
+    nz = cfg["num_hidden_layers"] * (B * D * _rup(L, 64) + 64) if _rup(L, 64) != L else 0  # every layer's zero-padded V^T (eager engines: one fill)
+    with E.scope("clip"), E.zero_pool(nz):
         x = E.embedding(ids, W["text_model.embeddings.token_embedding.weight"],
                         W["text_model.embeddings.position_embedding.weight"], name="emb")
         for i in range(cfg["num_hidden_layers"]):

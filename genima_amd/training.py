@@ -495,7 +495,7 @@ class Graph:
 
         def bw_flash(dO):
             # gn_attention_bwd: P recomputed per tile from (q, k, lse); dq / dk / dv in two deterministic MFMA kernels
-            zeros = torch.zeros if Nkr != nk_valid else torch.empty  # padded key rows are not written by the kernel
+            zeros = torch.zeros if Nkr > _rup(nk_valid, 128) else torch.empty  # the kernel writes the padded key rows of its last 128-key block as zeros
             dq = torch.empty_like(q.t)
             dk = dq if fused else zeros(k.t.shape, dtype=F16, device=E.device)
             dv = zeros(v.t.shape, dtype=F16, device=E.device)

@@ -127,7 +127,7 @@ typedef struct gn_gemm_desc {
                              15 = 256x256 ping-pong (8-phase, counted vmcnt; K % 64 == 0, conv C1/C2 % 64 == 0, no GEGLU / batch),
                              16..22 = {128x128, 128x64, 64x64, 256x64, 128x160, 64x160, 64x320} with a 3-stage LDS-DMA ring (two K tiles
                              in flight, counted vmcnt); 20..22 are the exact-fit tiles of the N = 640 / 1280 / 320 launches,
-                             23 = 128x160 two-stage LDS-DMA
+                             23 = 128x160 two-stage LDS-DMA, 24 = 128x320 two-stage LDS-DMA on eight waves of 32x160
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */
@@ -296,8 +296,8 @@ int32_t gn_attention_fp8_fwd(gn_ctx* ctx, const gn_attn_desc* d);
  * deterministic kernels (dQ over key tiles; dK, dV over query tiles), no atomics.  q / k / v / o / d_o and the gradients are
  * row-major [B][rows][ld] with head h at column h*D of the given base pointer; qt / kt / dot (transposed copies of Q, K, dO that
  * round 1's kernels streamed) are IGNORED and may be NULL: the kernels read the transposed operand out of the row-major LDS tile
- * with ds_read_b64_tr_b16.  Rows Nk .. Nk_rows-1 of k / v must be zero padding (their dk / dv rows are left
- * untouched); Nq and Nk_rows are multiples of 8.  delta: f32 [B][heads][Nq] scratch (sum_d dO*O, written here). */
+ * with ds_read_b64_tr_b16.  Rows Nk .. Nk_rows-1 of k / v must be zero padding (their dk / dv rows are
+ * written as zeros up to round_up(Nk, 128), rows past that are left untouched); Nq and Nk_rows are multiples of 8.  delta: f32 [B][heads][Nq] scratch (sum_d dO*O, written here). */
 typedef struct gn_attn_bwd_desc {
   const void* q; const void* k; const void* v; const void* o; const void* d_o;
   const void* qt; const void* kt; const void* dot;
@@ -440,6 +440,10 @@ int32_t gn_maxpool3x3s2(gn_ctx* ctx, const void* x, void* y, int32_t B, int32_t 
  * Parameter gradients are f32 and accumulate; all reductions are deterministic. */
 int32_t gn_transpose2d(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
                        int32_t batch, int64_t in_bs, int64_t out_bs);                 /* out[b][c][r] = in[b][r][c] (f16) */
+/* the same, and columns [rows, ld_out) of every output row are written as zeros (ld_out <= round_up(rows, 64)): the padded reduction length
+ * of a GEMM operand -- the cross-attention V^T of 77 tokens -- without a fill launch in front of the transpose */
+int32_t gn_transpose2d_zpad(gn_ctx* ctx, const void* in, void* out, int32_t rows, int32_t cols, int64_t ld_in, int64_t ld_out,
+                            int32_t batch, int64_t in_bs, int64_t out_bs);
 /* out[(tap*C + c)][m] = x[b, oy*stride - pad + dy, ox*stride - pad + dx, c] (0 in the padding); M = B*Ho*Wo contiguous */
 int32_t gn_im2col_t(gn_ctx* ctx, const void* x, void* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t ksize,
                     int32_t stride, int32_t pad);

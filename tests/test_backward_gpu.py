@@ -188,14 +188,33 @@ def test_flash_attention_backward(engine, N, Nk, fused):
     s = torch.einsum("bnhd,bmhd->bhnm", q.view(B, N, heads, D), k[:, :Nk].view(B, Nk, heads, D)) * D ** -0.5
     assert_close(lse, torch.logsumexp(s, -1) * 1.4426950408889634, what="lse (log2 units)")
     dq = torch.empty_like(qd)
-    dk = dq if fused else torch.zeros_like(kd)
-    dv = torch.zeros_like(vd)
+    # NaN-filled: the kernel itself writes the padding rows [Nk, Nkr) of dk / dv as zeros (no fill launch in front of it)
+    dk = dq if fused else torch.full_like(kd, float("nan"))
+    dv = torch.full_like(vd, float("nan"))
     T.attention_bwd(engine, qd, q_off, kd, k_off, vd, o, h(dO), lse, heads, Nk, dq, dk, dv)
     assert_close(dq[:, :, q_off:q_off + Cc], qr.grad, rel=2e-3, what="dQ")
     assert_close(dk[:, :Nk, k_off:k_off + Cc], kr.grad, rel=2e-3, what="dK")
     assert_close(dv[:, :Nk], vr.grad, rel=2e-3, what="dV")
     if Nkr != Nk:
         assert float(dv[:, Nk:].abs().max()) == 0.0 and float(dk[:, Nk:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,cols,batch,pad_to", [(80, 320, 3, 64), (77, 64, 1, 8), (200, 136, 2, 64), (5, 40, 1, 64), (128, 64, 2, 64)])
+def test_transpose_writes_its_own_padding(engine, rows, cols, batch, pad_to):
+    """gn_transpose2d_zpad: out[b][c][r] = in[b][r][c] with columns [rows, ld_out) zero -- on a NaN-filled pool so that a column the kernel
+    skipped would show (train_ops.transpose2d allocates with torch.empty on this route)."""
+    from genima_amd._lib import check
+
+    x = randn_h(batch, rows, cols, seed=rows + cols)
+    ld = -(-rows // pad_to) * pad_to
+    xt = torch.full((batch, cols, ld), float("nan"), dtype=torch.float16, device="cuda")
+    check(engine.lib.gn_transpose2d_zpad(engine._ctx, x.data_ptr(), xt.data_ptr(), rows, cols, cols, ld, batch, rows * cols, cols * ld), "zpad")
+    assert torch.equal(xt[:, :, :rows], x.transpose(1, 2))
+    assert not bool(torch.isnan(xt).any())
+    if ld > rows:
+        assert float(xt[:, :, rows:].abs().max()) == 0.0
+    via = T.transpose2d(engine, x, rows, cols, batch=batch, in_bs=rows * cols, pad_to=pad_to).view(batch, cols, -1)  # the route the trainer takes
+    assert torch.equal(via, xt)
 
 
 def test_layernorm_backward(engine):

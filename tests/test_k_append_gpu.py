@@ -26,7 +26,7 @@ def _problem(B, H, C, Cx, N, seed=0):
     return h, x, w3, b3, w1, b1, wcat, bcat
 
 
-@pytest.mark.parametrize("tile", [0] + list(range(7, 24)))
+@pytest.mark.parametrize("tile", [0] + list(range(7, 25)))
 def test_appended_shortcut_every_dma_tile(tile):
     E = Engine("cuda:0")
     E.autotune = False
@@ -58,7 +58,7 @@ def test_appended_shortcut_matches_the_two_launches(B, H, C, C2, C3, N, splitk):
     assert e1 <= 1.2 * e2 + 1e-5  # one rounding instead of two: no further from fp32 than the launches it replaces
 
 
-@pytest.mark.parametrize("tile", [0] + list(range(7, 24)))
+@pytest.mark.parametrize("tile", [0] + list(range(7, 25)))
 def test_dense_append_every_dma_tile(tile):
     """y = [g | h] @ w.T + b + x on every LDS-DMA tile (rows not a multiple of any tile, the second operand with its own row stride)."""
     E = Engine("cuda:0")

@@ -33,7 +33,7 @@ def test_recorded_gemm_plan_can_be_read_back_and_replaced():
     g_rec = g.clone()  # (the recorded plan of the conv may split K: its sums differ from the unsplit ones in the last bit)
     # every block tile gives the same bits (no K split: the workspace stays untouched)
     y0 = g0 = None
-    for tile in (10, 9, 11, 17, 18, 23):
+    for tile in (10, 9, 11, 17, 18, 23, 24):
         for i in range(n):
             assert E.lib.gn_program_set_gemm_plan(E._prog, i, tile, 1, None) == 0
         y.zero_(); g.zero_()

@@ -36,7 +36,7 @@ def test_conv2d_up2x_matches_torch_and_the_fused_launch(engine, shape):
     assert rel_l2(y, old.float().cpu()) < 6e-4
 
 
-@pytest.mark.parametrize("tile", range(1, 24))
+@pytest.mark.parametrize("tile", range(1, 25))
 def test_two_level_row_pitch_every_tile(engine, tile):
     """The strided-view output (gn_gemm_desc.out_row_width / ldo_hi) through every block tile, with and without split-K."""
     E = engine

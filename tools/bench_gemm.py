@@ -13,7 +13,7 @@ E = Engine("cuda:0")
 E.no_table = True  # time the configuration forced through gn_set_gemm_tile_override, not the tuned one
 CFG = ["256x128", "128x128", "128x64", "64x64", "256x64", "128x256",
        "D256x256", "D256x128", "D128x128", "D128x64", "D64x64", "D256x64", "D128x320", "D256x320", "PP256x256",
-       "S3_128x128", "S3_128x64", "S3_64x64", "S3_256x64", "S3_128x160", "S3_64x160", "S3_64x320", "D128x160"]
+       "S3_128x128", "S3_128x64", "S3_64x64", "S3_256x64", "S3_128x160", "S3_64x160", "S3_64x320", "D128x160", "D128x320w8"]
 ALL = tuple(int(c) for c in os.environ.get("CFGS", "0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18").split(","))
 
 
