@@ -146,6 +146,7 @@ SIGNATURES = {
     "gn_desc_sizeof": (_I64, [_I32]),
     "gn_set_gemm_tile_override": (_I32, [_I32]),
     "gn_attention_fwd": (_I32, [_P, C.POINTER(AttnDesc)]),
+    "gn_attention_set_variant": (_I32, [_I32]),
     "gn_tblock_tape_bytes": (_I64, [_I32, _I32]),
     "gn_tblock_supported": (_I32, [_I32, _I64, _I32]),
     "gn_tblock": (_I32, [_P, C.POINTER(TBlockDesc)]),

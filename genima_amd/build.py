@@ -16,12 +16,12 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgenima_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_s3.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_bwd.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip", "act_train.hip", "pack.hip", "tblock.hip", "conv_gn.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_s3.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_pwg.hip", "attention_bwd.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip", "act_train.hip", "pack.hip", "tblock.hip", "conv_gn.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950's register file is unified, so keep MFMA accumulators in VGPRs -- the softmax / epilogue VALU
 # then works on them in place instead of through v_accvgpr_read/write copies (400 of them per attention tile otherwise).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
 _VGPR_FORM = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]  # measured: helps attention (+30 %), costs the GEMM 5 %
-EXTRA_FLAGS = {"attention.hip": _VGPR_FORM, "attention_stream.hip": _VGPR_FORM, "attention_bwd.hip": _VGPR_FORM, "attention_fp8.hip": _VGPR_FORM}
+EXTRA_FLAGS = {"attention.hip": _VGPR_FORM, "attention_stream.hip": _VGPR_FORM, "attention_pwg.hip": _VGPR_FORM, "attention_bwd.hip": _VGPR_FORM, "attention_fp8.hip": _VGPR_FORM}
 
 
 def _hipcc() -> str:
@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + os.environ.get("GN_HIPCC_EXTRA", "").split() + ["-c", s, "-o", o]  # GN_HIPCC_EXTRA: probe builds (-DGN_PWG_ABLATIONS)
             if verbose:
                 print("[genima_amd.build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -414,17 +414,31 @@ bool stream_default() {
   return on;
 }
 
+int g_attn_variant = -2;  // -2: not read yet
 int attn_variant_override() {
-  static int v = -2;
-  if (v == -2) {
-    // tuning aid: 0 = this file's 4 waves x 32 rows everywhere, 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows, 4 = attention_stream.hip wherever eligible
+  if (g_attn_variant == -2) {
+    // tuning aid: 0 = this file's 4 waves x 32 rows everywhere, 1 = 4 waves x 64 rows, 2 = 8 waves x 32 rows, 4 = attention_stream.hip wherever
+    // eligible, 5 = attention_pwg.hip wherever eligible (gn_attention_set_variant changes it at run time)
     const char* e = getenv("GN_ATTN_VARIANT");
-    v = e ? atoi(e) : -1;
+    g_attn_variant = e ? atoi(e) : -1;
   }
+  return g_attn_variant;
+}
+
+// attention_pwg.hip (one wave per SIMD, 256-row query blocks) by default: where its grid fills the chip -- at least GN_ATTN_PWG_MIN_BLOCKS
+// blocks of 256 rows (one per CU and round) -- and the key loop is long enough to pay for its prologue
+int pwg_min_blocks() {
+  static const int v = getenv("GN_ATTN_PWG_MIN_BLOCKS") ? atoi(getenv("GN_ATTN_PWG_MIN_BLOCKS")) : 512;
   return v;
 }
 
 }  // namespace
+
+extern "C" int32_t gn_attention_set_variant(int32_t variant) {
+  const int prev = attn_variant_override();
+  g_attn_variant = variant < -1 ? -1 : variant;
+  return prev;
+}
 
 int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
   GN_REQUIRE(d && d->q && d->k && d->vt && d->o, "gn_attention_fwd: null pointer");
@@ -451,6 +465,9 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
     const int ov = attn_variant_override();
     if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
     else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
+    else if (!d->causal && !d->v_rowmajor && d->Nk % 64 == 0 && d->Nk >= 128 &&
+             (ov == 5 || (ov < 0 && pwg_min_blocks() > 0 && d->Nk >= 1024 && (long)((d->Nq + 255) / 256) * d->heads * d->B >= pwg_min_blocks())))
+      gn_launch_attention_pwg(p, d->B, ctx->stream);
     else if ((ov == 4 || (ov < 0 && stream_default())) && !d->causal && !d->v_rowmajor && d->Nk % 64 == 0 && d->Nk >= 128) gn_launch_attention_stream(p, d->B, ctx->stream);
     else if (d->v_rowmajor) launch_attn<64, 4, 1, true>(p, d->B, ctx->stream);
     else launch_attn<64, 4, 1>(p, d->B, ctx->stream);

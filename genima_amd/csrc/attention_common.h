@@ -31,3 +31,5 @@ __device__ __forceinline__ float pair_sum(float v) {
 
 // D = 64, non-causal, Nk a multiple of 64 (>= 128), V^T layout: the software-pipelined, branch-free kernel (attention_stream.hip)
 void gn_launch_attention_stream(const AttnParams& p, int B, hipStream_t stream);
+// D = 64, non-causal, Nk a multiple of 64 (>= 128), V^T layout, large grids: one wave per SIMD, 64 query rows per wave (attention_pwg.hip)
+void gn_launch_attention_pwg(const AttnParams& p, int B, hipStream_t stream);

@@ -275,6 +275,11 @@ typedef struct gn_attn_desc {
                                         q | k | v projection writes); the kernel transposes out of its LDS tile (ds_read_b64_tr_b16) */
 } gn_attn_desc;
 int32_t gn_attention_fwd(gn_ctx* ctx, const gn_attn_desc* d);
+/* Tuning / test aid: pick the D = 64 forward kernel for every later gn_attention_fwd (and recorded attention op) of this process.
+ * -1 = the library's own choice (default; the GN_ATTN_VARIANT environment variable, read once, sets the initial value),
+ * 0 = attention.hip (4 waves x 32 rows), 4 = attention_stream.hip wherever eligible, 5 = attention_pwg.hip wherever eligible
+ * (non-causal, V^T given, Nk % 64 == 0, Nk >= 128).  Returns the previous value. */
+int32_t gn_attention_set_variant(int32_t variant);
 
 /* fp8 (OCP e4m3) attention forward, D = 64 -- the opt-in attention of the fp8 training forward (BASELINE configs[4] "fp8 MFMA";
  * xformers attention under diffusion/train_controlnet_sdxl_genima.py:1448-1471).  Both products run on the K = 64 fp8 MFMA; the
