@@ -425,10 +425,19 @@ int attn_variant_override() {
   return g_attn_variant;
 }
 
-// attention_pwg.hip (one wave per SIMD, 256-row query blocks) by default: where its grid fills the chip -- at least GN_ATTN_PWG_MIN_BLOCKS
-// blocks of 256 rows (one per CU and round) -- and the key loop is long enough to pay for its prologue
+// attention_pwg.hip (one wave per SIMD, 64 rows per wave, split blocks for the last round) by default from GN_ATTN_PWG_MIN_KEYS keys on:
+// measured against attention_stream.hip on one box (tools/probes/attn_pwg_rounds.py, profiles/r05_v12_attn_pwg_rounds.txt), 4 096 keys:
+// 8 x 5 heads 172 vs 183 us, 8 x 10 336 vs 360, 4 x 5 96 vs 101, 2 x 5 53 vs 60, 1 x 5 31.5 vs 37; at 1 024 keys it loses (35.5 vs 31.7)
+// Inside the B = 1 call (two streams of the recorded program run side by side) its all-split grid of 160 blocks -- 31.5 vs 37 us alone -- is
+// no gain (tiled B = 1 28.76 vs 28.58 ms, same box, alternating: a block takes a CU's whole register file and 96 KB of its LDS, the
+// other stream's launches wait), so grids below GN_ATTN_PWG_MIN_BLOCKS 256-row blocks stay with attention_stream.hip; the B = 8 call
+// gets 93.87 vs 94.64 ms (profiles/r05_v12_ab_attn_pwg.txt).
+int pwg_min_keys() {
+  static const int v = getenv("GN_ATTN_PWG_MIN_KEYS") ? atoi(getenv("GN_ATTN_PWG_MIN_KEYS")) : 2048;
+  return v;
+}
 int pwg_min_blocks() {
-  static const int v = getenv("GN_ATTN_PWG_MIN_BLOCKS") ? atoi(getenv("GN_ATTN_PWG_MIN_BLOCKS")) : 512;
+  static const int v = getenv("GN_ATTN_PWG_MIN_BLOCKS") ? atoi(getenv("GN_ATTN_PWG_MIN_BLOCKS")) : 256;
   return v;
 }
 
@@ -466,7 +475,7 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
     if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
     else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
     else if (!d->causal && !d->v_rowmajor && d->Nk % 64 == 0 && d->Nk >= 128 &&
-             (ov == 5 || (ov < 0 && pwg_min_blocks() > 0 && d->Nk >= 1024 && (long)((d->Nq + 255) / 256) * d->heads * d->B >= pwg_min_blocks())))
+             (ov == 5 || (ov < 0 && pwg_min_keys() > 0 && d->Nk >= pwg_min_keys() && (long)((d->Nq + 255) / 256) * d->heads * d->B >= pwg_min_blocks())))
       gn_launch_attention_pwg(p, d->B, ctx->stream);
     else if ((ov == 4 || (ov < 0 && stream_default())) && !d->causal && !d->v_rowmajor && d->Nk % 64 == 0 && d->Nk >= 128) gn_launch_attention_stream(p, d->B, ctx->stream);
     else if (d->v_rowmajor) launch_attn<64, 4, 1, true>(p, d->B, ctx->stream);

@@ -1,5 +1,5 @@
 // Flash-style attention forward for head dim 64 on gfx950, the LARGE self-attention problems of the U-Net / ControlNet (the 64 x 64 latent
-// level at B >= 4: 4 096 keys, >= 256 query blocks): ONE WAVE PER SIMD, 64 query rows per wave, the whole register file per wave.
+// level: 4 096 keys): ONE WAVE PER SIMD, 64 query rows per wave, the whole register file per wave.
 //
 // Why another formulation (round 5).  attention_stream.hip runs 32 query rows per wave at three waves per SIMD: every
 // 32-key step of a wave is 8 MFMAs beside 8 ds_read_b128 fragment reads + the softmax, and three co-resident waves arbitrate for one
@@ -23,6 +23,21 @@
 // the following half-stage.  No fragment read is ever exposed behind a barrier.
 // The reference m per query row comes from the row maxima over the block's own diagonal keys (one 64-key tile per wave), no decision is
 // taken inside the loop (a sticky flag), and a block whose guess failed redoes its rows with the max-tracking loop (as attention_stream.hip).
+//
+// SPLIT blocks (load balance): a 256-row block holds a CU for ~62 us at 4 096 keys, and B x heads x Nq / 256 blocks rarely fill whole rounds of
+// 256 CUs (8 x 5 x 4096: 640 = 2.5 rounds).  When the remainder r of the block count is <= 128, the last heads' r blocks run as 2 r SPLIT blocks:
+// 128 query rows, the two waves of a row block take one HALF of the keys each (their own ring, same reference m, so the partial
+// (O, l) of the halves simply add -- through LDS, at the end).  A split block streams both key halves (twice the LDS-DMA pieces per
+// MFMA) for half as long: the last round takes about half a round.  Small grids (r = the whole problem, e.g. B = 1) run all-split.
+//
+// What the measurements say (profiles/r05_v12_*; tools/probes/attn_pwg_abl.py / attn_pwg_clock.py / mfma_read_price.hip / lds_read_pattern.hip):
+// 50 shader cycles per MFMA at 1.72 - 1.75 GHz in the loop (8 x 10 x 4096^2: 1.04 - 1.10 PF/s against 0.96 - 1.04 for the 32-row kernel on the
+// same boxes); without the fragment reads 35.6 cycles -- a ds_read_b128 beside the MFMAs costs ~29 cycles of issue however it is placed (behind
+// the consuming MFMA or a pair stage ahead into a second register set; bank-conflict free by the LDS pattern probe) -- without the softmax
+// VALU 42.8.  Tried and dropped: fragment reads a pair stage EARLY (neutral, 48 more registers), one lgkmcnt(0) per pair stage instead
+// of counted waits (+1.5 %), v_dot2c_f32_f16 row sums (+4 %), the row sums as two extra MFMAs per unit against a ones fragment (25 % more
+// matrix work for 17 fewer VALU per half-stage: +9 %).  A random-operand MFMA stream alone sustains 1.70 PF/s on this part (19.75 ns per
+// MFMA and SIMD: the power-limited clock), which is the ceiling the fractions of 2.5 PF are quoted against.
 #include <type_traits>
 
 #include "attention_common.h"
@@ -40,10 +55,6 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
   asm volatile("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
   return r;
 }
-__device__ __forceinline__ float dot2_ones(unsigned pk, float acc) {  // acc + lo(pk) + hi(pk), the halves as f16
-  asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(acc) : "v"(pk), "v"(0x3c003c00u));
-  return acc;
-}
 __device__ __forceinline__ float add_f32(float a, float b) {
   float r;
   asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -52,25 +63,26 @@ __device__ __forceinline__ float add_f32(float a, float b) {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16x8 as_f16x8(u32x4 v) { return __builtin_bit_cast(f16x8, v); }
 
+constexpr int PWG_NS = 3;                                   // ring slots
+constexpr int PWG_K_BYTES = KT * 128, PWG_BUF = 2 * PWG_K_BYTES, PWG_RING = PWG_NS * PWG_BUF;
+constexpr int PWG_LDS = 2 * PWG_RING;                       // a split block runs two rings (one per key half)
+
 // ABL: timing-only ablations (wrong results on purpose; tools/probes/attn_pwg_abl.py): 1 no v_exp, 2 no conversions / row sums, 4 no LDS-DMA
-// in the loop, 8 no fragment reads in the loop, 16 no barrier in the loop, 32 no P.V MFMAs, 64 no QK^T MFMAs
-template <int ABL>
-__global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p) {
-  constexpr int NW = 4, QB = 256, NS = 3;
-  constexpr int K_BYTES = KT * 128, V_BYTES = 64 * 128, BUF = K_BYTES + V_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * BUF];
+// in the loop, 8 no fragment reads in the loop, 16 no barrier in the loop, 32 no P.V MFMAs, 64 no QK^T MFMAs; 4096: the block's shader
+// cycles and 100 MHz ticks go to its lse rows (tools/probes/attn_pwg_clock.py)
+template <int ABL, bool SPLIT>
+__device__ __forceinline__ void pwg_block(const AttnParams& p, unsigned char* const smem, const int b, const int h, const int q0) {
+  constexpr int NW = 4, NS = PWG_NS, K_BYTES = PWG_K_BYTES, BUF = PWG_BUF, RING = PWG_RING;
+  constexpr int NH = SPLIT ? 2 : 1;  // key halves the block streams
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   unsigned long long tk0 = 0, tr0 = 0;
   if constexpr ((ABL & 4096) != 0) { tk0 = __builtin_amdgcn_s_memtime(); tr0 = __builtin_amdgcn_s_memrealtime(); }
-  // XCD-aware block order (as attention_stream.hip): the query blocks of one (batch, head) land on ONE XCD, next to each other in dispatch order
-  const int nqb = (p.Nq + QB - 1) / QB, total = gridDim.x;
-  const int slot = (total % 8 == 0) ? (blockIdx.x % 8) * (total / 8) + blockIdx.x / 8 : blockIdx.x;
-  const int bh = __builtin_amdgcn_readfirstlane(slot / nqb);
-  const int b = __builtin_amdgcn_readfirstlane(bh / p.heads), h = bh - b * p.heads;
-  const int q0 = (slot - bh * nqb) * QB;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int rb = SPLIT ? (wv >> 1) : wv;   // the wave's 64-row block
+  const int kh = SPLIT ? (wv & 1) : 0;     // the wave's key half
+  const int rowbase = q0 + rb * 64;
 
   const f16* qp = p.q + (long)b * p.q_bs + (long)h * 64;
   const f16* kp = p.k + (long)b * p.k_bs + (long)h * 64;
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
   f16x8 qf[2][4];  // (c Q)^T fragments of the two query blocks: lane holds Q[qrow][16 ks + 8 hi .. +8] * scale * log2(e)
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
-    const int qrow = q0 + wv * 64 + x * 32 + l31;
+    const int qrow = rowbase + x * 32 + l31;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -93,16 +105,10 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
 
   f32x16 oacc[2][2], negm[2];  // O^T accumulators [query block][d tile], and -m as an MFMA accumulator init (all 16 entries equal)
   float m_run[2] = {0.0f, 0.0f}, l_run[2] = {0.0f, 0.0f};
-  constexpr bool LMFMA = (ABL & 2048) != 0;  // the row sums on the matrix pipe: l^T[*, q] += ones . P^T (2 MFMAs per unit, no VALU adds)
-  f32x16 lacc[2];
-  f16x8 ones8;
-#pragma unroll
-  for (int e = 0; e < 8; ++e) ones8[e] = (f16)1.0f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) lacc[0][r] = lacc[1][r] = 0.0f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) oacc[0][0][r] = oacc[0][1][r] = oacc[1][0][r] = oacc[1][1][r] = negm[0][r] = negm[1][r] = 0.0f;
-  const int ntiles = p.Nk / KT;  // the launcher guarantees Nk % 64 == 0, Nk >= 128, not causal
+  const int ntiles = p.Nk / KT;                 // the launcher guarantees Nk % 64 == 0, Nk >= 128, not causal (split: ntiles even)
+  const int ntl = SPLIT ? ntiles / 2 : ntiles;  // tiles of a key half
 
   // LDS-DMA pieces of this wave: rows 8 (wave + 4 i) .. + 8 of a K tile / a V^T tile.  A DMA instruction fills 8 consecutive
   // 128-byte LDS rows lane-linearly, so K's row permutation (key bits 2 <-> 3) and the XOR chunk swizzle are applied on the source side.
@@ -126,8 +132,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
     for (int i = 0; i < 2; ++i)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (attn_lds_ptr_t)(lds + (wv + NW * i) * 1024), 16, koff[i] + adv, 0, 0, 0);
   };
-  // piece i of the image X(tile) = {K keys 64 tile + 32 .. + 64, V^T keys 64 tile .. + 64}: i < 2 K rows, else V^T rows.  Unconditional:
-  // rows past the end read zeros (beyond the descriptor) or a neighbouring row's bytes (V^T) into LDS bytes nobody consumes.
+  // piece i of the image X(tile) = {K keys 64 tile + 32 .. + 64, V^T keys 64 tile .. + 64} (tile: global index): i < 2 K rows, else V^T
+  // rows.  Unconditional: rows past the end read zeros (beyond the descriptor) or a neighbouring row's bytes (V^T) into LDS bytes nobody consumes.
   auto dma_piece = [&](int tile, unsigned char* X, int i) {
     if (i < 2) {
       const unsigned adv = (unsigned)(tile * KT + 32) * (unsigned)(p.k_rs * 2);
@@ -138,18 +144,24 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
     }
   };
 
-  // fragment i of the 32-key sub-tile u of the tile image at X: i < 4 K rows (k16 step i), i >= 4 V^T (d tile (i - 4) & 1, k16 step (i - 4) >> 1)
-  int offk[4], offv[2][2];
+  // fragment i of the 32-key sub-tile u of the tile image at X: i < 4 K rows (k16 step i), i >= 4 V^T (d tile (i - 4) & 1, k16 step (i - 4) >> 1).
+  // `ring`: the per-lane offsets carry this wave's ring (kh * RING), so the image addresses stay compile-time immediates.
+  struct Offs { int k[4], v[2][2]; };
+  auto make_offs = [&](int base) {
+    Offs o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) offk[i] = lds_swz<128>(l31, i * 2 + hi);
+    for (int i = 0; i < 4; ++i) o.k[i] = base + lds_swz<128>(l31, i * 2 + hi);
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) offv[u][s] = K_BYTES + lds_swz<128>(l31, u * 4 + s * 2 + hi);
-  auto frag = [&](const unsigned char* X, int u, int i) -> f16x8 {
-    if (i < 4) return *reinterpret_cast<const f16x8*>(X + offk[i] + u * 4096);
+      for (int s = 0; s < 2; ++s) o.v[u][s] = base + K_BYTES + lds_swz<128>(l31, u * 4 + s * 2 + hi);
+    return o;
+  };
+  const Offs ring = make_offs(kh * RING);
+  auto frag = [&](const Offs& o, const unsigned char* X, int u, int i) -> f16x8 {
+    if (i < 4) return *reinterpret_cast<const f16x8*>(X + o.k[i] + u * 4096);
     const int n = i - 4;
-    return *reinterpret_cast<const f16x8*>(X + offv[u][n >> 1] + (n & 1) * 4096);
+    return *reinterpret_cast<const f16x8*>(X + o.v[u][n >> 1] + (n & 1) * 4096);
   };
   auto FI = [](int i) { return (i & 1) ? 4 + (i >> 1) : (i >> 1); };  // fragment of MFMA i: even QK^T k16 step, odd V^T (d tile, k16 step)
 
@@ -174,43 +186,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
   };
   unsigned long long sticky = 0;  // some lane sum left the range the optimistic softmax is exact in (wave-uniform, never branched on in the loop)
 
-  // One half-stage = the unit whose softmax runs: exponents sc -> P fragments pc (query block XS); QK^T of the next unit into sn (query
-  // block 1 - XS... the block the NEXT unit belongs to: XN); P.V of the previous unit from pp (query block XP).  f[]: the 8 fragments of
-  // this pair stage.  READ: this is the pair stage's second half -- behind MFMA i, f[i] is re-read for the NEXT pair stage from image Xn,
-  // sub-tile UN (KONLY... VONLY: the drain needs the V^T fragments only).  DMA: the 4 LDS-DMA pieces of X(dma_tile) into Xd ride in the gaps.
+  // One half-stage = the unit whose softmax runs (query block XS): exponents sc -> P fragments pc; QK^T of the NEXT unit (the other query
+  // block) into sn; P.V of the PREVIOUS unit (the other query block) from pp.  f[]: the 8 fragments of this pair stage.  READ: this is
+  // the pair stage's second half -- behind MFMA i, f[i] is re-read for the NEXT pair stage from image Xn, sub-tile UN (2: the V^T
+  // fragments only, for the drain).  DMA: the LDS-DMA pieces of X(dma_tile) (of every key half) into Xd ride in the gaps.
   // Units of the softmax per pair k of scores: E(k) two v_exp_f32, C(k) one v_cvt_pk_f16_f32, S(k) the row-sum adds -- each a group or
   // two behind its producer.
-  auto half = [&](const f32x16& sc, f32x16& sn, u32x4 (&pc)[2], const u32x4 (&pp)[2], auto xs_c, const f16x8 (&f)[8], f16x8 (&g)[8], auto read_c, const unsigned char* Xn,
+  auto half = [&](const f32x16& sc, f32x16& sn, u32x4 (&pc)[2], const u32x4 (&pp)[2], auto xs_c, f16x8 (&f)[8], auto read_c, const unsigned char* Xn,
                   auto un_c, auto dma_c, unsigned char* Xd, int dma_tile) __attribute__((always_inline)) {
-    constexpr int XS = decltype(xs_c)::value;  // the softmax's query block; QK^T goes to the other one's NEXT unit, P.V to the other one's previous
+    constexpr int XS = decltype(xs_c)::value;
     constexpr int XN = 1 - XS, XP = 1 - XS;
     constexpr int READ = decltype(read_c)::value;  // 0: none, 1: all eight, 2: the V^T fragments only
     constexpr int UN = decltype(un_c)::value;
     constexpr bool DMA = decltype(dma_c)::value;
     float ex[16], ps0, ps1;
-    auto D = [&](int i) {
-      if constexpr (DMA && !(ABL & 4)) dma_piece(dma_tile, Xd, i);
+    auto D = [&](int i) {  // pieces 0 .. 3: this block's first (only) key half, 4 .. 7: a split block's second
+      if constexpr (DMA && !(ABL & 4)) {
+        if (i < 4) dma_piece(dma_tile, Xd, i);
+        else if constexpr (SPLIT) dma_piece(ntl + dma_tile, Xd + RING, i - 4);
+      }
     };
     auto R = [&](int i) {
-      if constexpr (ABL & 8) return;
-      if constexpr (READ == 1) g[i] = frag(Xn, UN, FI(i));
-      else if constexpr (READ == 2) { if (i & 1) g[i] = frag(Xn, UN, FI(i)); }
+      if constexpr ((ABL & 8) != 0) return;
+      if constexpr (READ == 1) f[i] = frag(ring, Xn, UN, FI(i));
+      else if constexpr (READ == 2) { if (i & 1) f[i] = frag(ring, Xn, UN, FI(i)); }
     };
     auto E = [&](int k) {
-      if constexpr (ABL & 1) { ex[2 * k] = sc[2 * k]; ex[2 * k + 1] = sc[2 * k + 1]; return; }
+      if constexpr ((ABL & 1) != 0) { ex[2 * k] = sc[2 * k]; ex[2 * k + 1] = sc[2 * k + 1]; return; }
       ex[2 * k] = __builtin_amdgcn_exp2f(sc[2 * k]);
       ex[2 * k + 1] = __builtin_amdgcn_exp2f(sc[2 * k + 1]);
     };
     auto C = [&](int k) {
-      if constexpr (ABL & 2) { if ((k & 3) == 0) pc[k >> 2] = __builtin_bit_cast(u32x4, f32x4{ex[2 * k], ex[2 * k + 1], ex[2 * k + 2], ex[2 * k + 3]}); return; }
+      if constexpr ((ABL & 2) != 0) { if ((k & 3) == 0) pc[k >> 2] = __builtin_bit_cast(u32x4, f32x4{ex[2 * k], ex[2 * k + 1], ex[2 * k + 2], ex[2 * k + 3]}); return; }
       pc[k >> 2][k & 3] = cvt_pk(ex[2 * k], ex[2 * k + 1]);
     };
     auto S = [&](int k) {
-      if constexpr ((ABL & 1024) != 0) {  // row sums from the packed f16 pairs (one v_dot2c_f32_f16 per pair, two chains)
-        if (k == 0) { ps0 = 0.0f; ps1 = 0.0f; }
-        if (k & 1) ps1 = dot2_ones(pc[k >> 2][k & 3], ps1); else ps0 = dot2_ones(pc[k >> 2][k & 3], ps0);
-        return;
-      }
       if (k == 0 || (ABL & 2)) { ps0 = ex[0]; ps1 = ex[1]; }
       else { ps0 = add_f32(ps0, ex[2 * k]); ps1 = add_f32(ps1, ex[2 * k + 1]); }
     };
@@ -219,35 +229,19 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
       if ((i & 1) == 0) { if constexpr (!(ABL & 64)) sn = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[i], qf[XN][n], n == 0 ? negm[XN] : sn, 0, 0, 0); }
       else { if constexpr (!(ABL & 32)) oacc[XP][n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[i], as_f16x8(pp[n >> 1]), oacc[XP][n & 1], 0, 0, 0); }
     };
-    if constexpr ((ABL & 512) != 0 && READ != 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // EARLY: the set f was read a pair stage ago
-    if constexpr (LMFMA) {
-      auto ML = [&](int j) { lacc[XP] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, as_f16x8(pp[j]), lacc[XP], 0, 0, 0); };
-      GN_FENCE; M(0); GN_FENCE; R(0); D(0); E(0);
-      GN_FENCE; M(1); GN_FENCE; R(1); D(1); E(1); C(0);
-      GN_FENCE; M(2); GN_FENCE; R(2); D(2); E(2); C(1);
-      GN_FENCE; M(3); GN_FENCE; R(3); D(3); C(2);
-      GN_FENCE; ML(0); GN_FENCE; R(4); E(3);
-      GN_FENCE; M(4); GN_FENCE; R(5); E(4); C(3);
-      GN_FENCE; M(5); GN_FENCE; R(6); E(5); C(4);
-      GN_FENCE; M(6); GN_FENCE; R(7); E(6); C(5);
-      GN_FENCE; M(7); GN_FENCE; E(7); C(6);
-      GN_FENCE; ML(1); GN_FENCE; C(7);
-      GN_FENCE;
-    } else {
-      GN_FENCE; M(0); GN_FENCE; R(0); D(0); E(0);
-      GN_FENCE; M(1); GN_FENCE; R(1); D(1); E(1); C(0);
-      GN_FENCE; M(2); GN_FENCE; R(2); D(2); E(2); C(1); S(0);
-      GN_FENCE; M(3); GN_FENCE; R(3); D(3); E(3); C(2); S(1);
-      GN_FENCE; M(4); GN_FENCE; R(4); E(4); C(3); S(2);
-      GN_FENCE; M(5); GN_FENCE; R(5); E(5); C(4); S(3);
-      GN_FENCE; M(6); GN_FENCE; R(6); E(6); C(5); S(4);
-      GN_FENCE; M(7); GN_FENCE; R(7); E(7); C(6); S(5);
-      GN_FENCE; S(6); C(7); S(7);
-      GN_FENCE;
-      const float psum = ps0 + ps1;
-      sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));  // v_cmp + s_or: no branch
-      l_run[XS] += psum;
-    }
+    GN_FENCE; M(0); GN_FENCE; R(0); D(0); E(0);
+    GN_FENCE; M(1); GN_FENCE; R(1); D(1); E(1); C(0);
+    GN_FENCE; M(2); GN_FENCE; R(2); D(2); E(2); C(1); S(0);
+    GN_FENCE; M(3); GN_FENCE; R(3); D(3); E(3); C(2); S(1);
+    GN_FENCE; M(4); GN_FENCE; R(4); D(4); E(4); C(3); S(2);
+    GN_FENCE; M(5); GN_FENCE; R(5); D(5); E(5); C(4); S(3);
+    GN_FENCE; M(6); GN_FENCE; R(6); D(6); E(6); C(5); S(4);
+    GN_FENCE; M(7); GN_FENCE; R(7); D(7); E(7); C(6); S(5);
+    GN_FENCE; S(6); C(7); S(7);
+    GN_FENCE;
+    const float psum = ps0 + ps1;
+    sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));  // v_cmp + s_or: no branch
+    l_run[XS] += psum;
   };
   const std::integral_constant<int, 0> c0{};
   const std::integral_constant<int, 1> c1{};
@@ -255,10 +249,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
   const std::true_type yes{};
   const std::false_type no{};
 
-  // ---- the reference: row maxima over the wave's own diagonal keys (K tile q0 / 64 + wave, clamped) --------------------------------------
-  // every wave stages its two pieces of all four reference tiles (4 x 8 KB at the bottom of the ring)
+  // ---- the reference: row maxima over the wave's own diagonal keys (the K tile at its rows, clamped) ---------------------------------------
+  // every wave stages its two pieces of all four reference tiles (4 x 8 KB at the bottom of the LDS; the waves of a split row block share theirs)
+  const Offs plain = make_offs(0);
 #pragma unroll
-  for (int w = 0; w < NW; ++w) dma_krows(min(q0 / KT + w, ntiles - 1) * KT, smem + w * K_BYTES);
+  for (int w = 0; w < NW; ++w) dma_krows(min((q0 + (SPLIT ? (w >> 1) : w) * 64) / KT, ntiles - 1) * KT, smem + w * K_BYTES);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   f32x16 sa, sb;
@@ -267,40 +262,44 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(Kr, 0, ks), qf[x][ks], ks == 0 ? negm[x] : sa, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(plain, Kr, 0, ks), qf[x][ks], ks == 0 ? negm[x] : sa, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(Kr, 1, ks), qf[x][ks], ks == 0 ? negm[x] : sb, 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(plain, Kr, 1, ks), qf[x][ks], ks == 0 ? negm[x] : sb, 0, 0, 0);
       m_run[x] = pair_max(fmaxf(rowmax16(sa), rowmax16(sb)));
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { negm[0][r] = -m_run[0]; negm[1][r] = -m_run[1]; }
   }
-  __syncthreads();  // the ring is free
+  __syncthreads();  // the LDS is free
 
-  // ---- prologue: X(0) -> slot 0, X(1) -> slot 1 (stays in flight); K keys 0 .. 63 -> slot 2: exponents of the units (0,a), (0,b); P of (0,a) ---
+  // ---- prologue (per key half): X(0) -> slot 0, X(1) -> slot 1 (stays in flight); the half's first 64 K rows -> slot 2: exponents of the
+  // units (0,a), (0,b); P of (0,a) ------------------------------------------------------------------------------------------------------
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_piece(0, smem, i);
-  dma_krows(0, smem + 2 * BUF);
+  for (int hf = 0; hf < NH; ++hf)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_piece(1, smem + BUF, i);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    for (int i = 0; i < 4; ++i) dma_piece(hf * ntl, smem + hf * RING, i);
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf) dma_krows(hf * ntl * KT, smem + hf * RING + 2 * BUF);
+#pragma unroll
+  for (int hf = 0; hf < NH; ++hf)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_piece(hf * ntl + 1, smem + hf * RING + BUF, i);
+  if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();
   u32x4 pa[2], pb[2];
-  f16x8 fa[8], fb[8];
-  constexpr bool EARLY = (ABL & 256) != 0;  // fragment reads in the FIRST half of a pair stage, into the other register set
+  f16x8 f[8];
   {
     const unsigned char* K0 = smem + 2 * BUF;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(K0, 0, ks), qf[0][ks], ks == 0 ? negm[0] : sa, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) sa = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(ring, K0, 0, ks), qf[0][ks], ks == 0 ? negm[0] : sa, 0, 0, 0);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(K0, 0, ks), qf[1][ks], ks == 0 ? negm[1] : sb, 0, 0, 0);
+    for (int ks = 0; ks < 4; ++ks) sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(ring, K0, 0, ks), qf[1][ks], ks == 0 ? negm[1] : sb, 0, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) fa[i] = frag(smem, 0, FI(i));  // F(0)
+    for (int i = 0; i < 8; ++i) f[i] = frag(ring, smem, 0, FI(i));  // F(0)
     const float psum = exps(sa, pa);
-    if constexpr (!LMFMA) {
-      sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));
-      l_run[0] += psum;
-    }
+    sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));
+    l_run[0] += psum;
   }
   __syncthreads();  // slot 2 is free
 
@@ -309,26 +308,16 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
   auto iteration = [&](auto cur_c, int t) __attribute__((always_inline)) {
     constexpr int cur = decltype(cur_c)::value, nxt = (cur + 1) % NS, fill = (cur + 2) % NS;
     unsigned char* X = smem + cur * BUF;
-    if constexpr (EARLY) {
-      half(sb, sa, pb, pa, c1, fa, fb, c1, X, c1, no, X, 0);                         // (2t, b):     QK^T (2t+1, a), P.V (2t, a); reads F(2t+1) -> fb
-      half(sa, sb, pa, pb, c0, fa, fb, c0, X, c0, no, X, 0);                         // (2t+1, a):   QK^T (2t+1, b), P.V (2t, b)
-    } else {
-      half(sb, sa, pb, pa, c1, fa, fa, c0, X, c0, no, X, 0);                         // (2t, b):     QK^T (2t+1, a), P.V (2t, a)
-      half(sa, sb, pa, pb, c0, fa, fa, c1, X, c1, no, X, 0);                         // (2t+1, a):   QK^T (2t+1, b), P.V (2t, b); reads F(2t+1)
-    }
+    half(sb, sa, pb, pa, c1, f, c0, X, c0, no, X, 0);                         // (2t, b):     QK^T (2t+1, a), P.V (2t, a)
+    half(sa, sb, pa, pb, c0, f, c1, X, c1, no, X, 0);                         // (2t+1, a):   QK^T (2t+1, b), P.V (2t, b); reads F(2t+1)
     if constexpr (!(ABL & 16)) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // this wave's pieces of X(t+1), issued an iteration ago
       __syncthreads();                                                        // X(t+1) is published, X(t-1) retired
     }
-    if constexpr (EARLY) {
-      half(sb, sa, pb, pa, c1, fb, fa, c1, smem + nxt * BUF, c0, no, X, 0);          // (2t+1, b):   QK^T (2t+2, a), P.V (2t+1, a); reads F(2t+2) -> fa
-      half(sa, sb, pa, pb, c0, fb, fa, c0, X, c0, yes, smem + fill * BUF, t + 2);    // (2t+2, a):   QK^T (2t+2, b), P.V (2t+1, b); fetches X(t+2)
-    } else {
-      half(sb, sa, pb, pa, c1, fa, fa, c0, X, c0, yes, smem + fill * BUF, t + 2);    // (2t+1, b):   QK^T (2t+2, a), P.V (2t+1, a); fetches X(t+2)
-      half(sa, sb, pa, pb, c0, fa, fa, c1, smem + nxt * BUF, c0, no, X, 0);          // (2t+2, a):   QK^T (2t+2, b), P.V (2t+1, b); reads F(2t+2)
-    }
+    half(sb, sa, pb, pa, c1, f, c0, X, c0, yes, smem + fill * BUF, t + 2);    // (2t+1, b):   QK^T (2t+2, a), P.V (2t+1, a); fetches X(t+2)
+    half(sa, sb, pa, pb, c0, f, c1, smem + nxt * BUF, c0, no, X, 0);          // (2t+2, a):   QK^T (2t+2, b), P.V (2t+1, b); reads F(2t+2)
   };
-  const int nit = ntiles - 1;
+  const int nit = ntl - 1;
   int t = 0;
   for (; t + 3 <= nit; t += 3) {
     iteration(c0, t);
@@ -341,44 +330,41 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
   // ---- last tile: pair stage 2 nt - 2, then the drain (softmax of the last unit, P.V of the last two) ---------------------------------------
   {
     unsigned char* X = smem + (nit % NS) * BUF;
-    if constexpr (EARLY) {
-      half(sb, sa, pb, pa, c1, fa, fb, c2, X, c1, no, X, 0);   // (L-1, b): QK^T (L, a), P.V (L-1, a); reads the V^T fragments of sub-tile L -> fb
-      half(sa, sb, pa, pb, c0, fa, fb, c0, X, c0, no, X, 0);   // (L, a):   QK^T (L, b), P.V (L-1, b)
-    } else {
-      half(sb, sa, pb, pa, c1, fa, fa, c0, X, c0, no, X, 0);   // (L-1, b): QK^T (L, a), P.V (L-1, a)
-      half(sa, sb, pa, pb, c0, fa, fa, c2, X, c1, no, X, 0);   // (L, a):   QK^T (L, b), P.V (L-1, b); reads the V^T fragments of sub-tile L
-    }
-    const f16x8 (&f)[8] = EARLY ? fb : fa;
+    half(sb, sa, pb, pa, c1, f, c0, X, c0, no, X, 0);   // (L-1, b): QK^T (L, a), P.V (L-1, a)
+    half(sa, sb, pa, pb, c0, f, c2, X, c1, no, X, 0);   // (L, a):   QK^T (L, b), P.V (L-1, b); reads the V^T fragments of sub-tile L
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the wave
     const float psum = exps(sb, pb);
-    if constexpr (!LMFMA) {
-      sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));
-      l_run[1] += psum;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        lacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, as_f16x8(pa[j]), lacc[0], 0, 0, 0);
-        lacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones8, as_f16x8(pb[j]), lacc[1], 0, 0, 0);
-      }
-    }
+    sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));
+    l_run[1] += psum;
 #pragma unroll
     for (int n = 0; n < 4; ++n) oacc[0][n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * n + 1], as_f16x8(pa[n >> 1]), oacc[0][n & 1], 0, 0, 0);
 #pragma unroll
     for (int n = 0; n < 4; ++n) oacc[1][n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f[2 * n + 1], as_f16x8(pb[n >> 1]), oacc[1][n & 1], 0, 0, 0);
   }
 
-  // ---- the guess failed somewhere in this block (rare): redo its rows with the max-tracking loop ---------------------------------------------
-  if constexpr (LMFMA) {  // every row of l^T holds the column's sum: an exponential that left f16's range made it inf (or NaN)
-    sticky |= __builtin_amdgcn_ballot_w64(!(lacc[0][0] < 3.0e38f) || !(lacc[1][0] < 3.0e38f));
-  }
-  bool redone = false;
-  __syncthreads();  // every wave is done with the ring
+  // ---- flags; a split block's second-half waves hand their partial (O, l) over ------------------------------------------------------------------
+  constexpr int PART = 1024, PART_WAVE = 66 * 256;  // 64 accumulator registers + 2 row sums, one 256-byte line per register
+  __syncthreads();  // every wave is done with the rings
   if (lane == 0) reinterpret_cast<int*>(smem)[wv] = sticky != 0;
+  if constexpr (SPLIT) {
+    if (kh == 1) {
+      float* part = reinterpret_cast<float*>(smem + PART + rb * PART_WAVE) + lane;
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) part[((x * 2 + dt) * 16 + r) * 64] = oacc[x][dt][r];
+        part[(64 + x) * 64] = l_run[x];
+      }
+    }
+  }
   __syncthreads();
   const int4 flags = *reinterpret_cast<const int4*>(smem);
   if (__builtin_amdgcn_readfirstlane(flags.x | flags.y | flags.z | flags.w)) {
-    __syncthreads();  // the flags have been read
-    redone = true;
+    // ---- the guess failed somewhere in this block (rare): redo its rows with the max-tracking loop over ALL keys (in a split block both
+    // waves of a row block compute the same rows; the first one stores) ------------------------------------------------------------------------
+    __syncthreads();  // the flags (and partials) have been read
 #pragma unroll
     for (int x = 0; x < 2; ++x) {
       m_run[x] = 0.0f; l_run[x] = 0.0f;
@@ -397,7 +383,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
         for (int u = 0; u < 2; ++u) {
           f32x16 s;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(smem, u, ks), qf[x][ks], ks == 0 ? negm[x] : s, 0, 0, 0);
+          for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(plain, smem, u, ks), qf[x][ks], ks == 0 ? negm[x] : s, 0, 0, 0);
           float mx = pair_max(rowmax16(s));  // relative to the current reference
           const float delta = (tt == 0 && u == 0) ? mx : fmaxf(mx, 0.0f);  // the reference only grows, except on the first sub-tile, which sets it
           const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -413,25 +399,38 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
           u32x4 pc[2];
           l_run[x] += exps(s, pc);
 #pragma unroll
-          for (int n = 0; n < 4; ++n) oacc[x][n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(smem, u, 4 + n), as_f16x8(pc[n >> 1]), oacc[x][n & 1], 0, 0, 0);
+          for (int n = 0; n < 4; ++n) oacc[x][n & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(frag(plain, smem, u, 4 + n), as_f16x8(pc[n >> 1]), oacc[x][n & 1], 0, 0, 0);
         }
       __syncthreads();
     }
+  } else if constexpr (SPLIT) {
+    if (kh == 0) {  // same reference m in both halves: the partial sums add
+      const float* part = reinterpret_cast<const float*>(smem + PART + rb * PART_WAVE) + lane;
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[x][dt][r] += part[((x * 2 + dt) * 16 + r) * 64];
+        l_run[x] += part[(64 + x) * 64];
+      }
+    }
   }
 
-  if constexpr ((ABL & 4096) != 0) {  // (probe) shader cycles and 100 MHz ticks this block took, in the first floats of its lse rows
+  if constexpr ((ABL & 4096) != 0) {  // (probe) shader cycles and 100 MHz ticks this block took, in two floats of its lse rows
     const unsigned long long tk1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
     if (p.lse && tid == 0) {
       float* dbg = p.lse + ((long)b * p.heads + h) * p.Nq + q0;
-      dbg[128] = (float)(tk1 - tk0);
-      dbg[129] = (float)(tr1 - tr0);
+      dbg[0] = (float)(tk1 - tk0);
+      dbg[1] = (float)(tr1 - tr0);
     }
   }
   // ---- finalize: O[q][d] = O^T[d][q] / l -------------------------------------------------------------------------------------------
+  if (SPLIT && kh != 0) return;
 #pragma unroll
   for (int x = 0; x < 2; ++x) {
-    const int qrow = q0 + wv * 64 + x * 32 + l31;
-    const float l_tot = (LMFMA && !redone) ? lacc[x][0] : pair_sum(l_run[x]);
+    const int qrow = rowbase + x * 32 + l31;
+    const float l_tot = pair_sum(l_run[x]);
     const float inv = l_tot > 0.0f ? 1.0f / l_tot : 0.0f;
     if (p.lse && hi == 0 && qrow < p.Nq && !(ABL & 4096))
       p.lse[((long)b * p.heads + h) * p.Nq + qrow] = l_tot > 0.0f ? m_run[x] + __builtin_amdgcn_logf(l_tot) : INFINITY;
@@ -450,20 +449,59 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p
   }
 }
 
+// blocks 0 .. nfull - 1: 256 query rows each, over heads 0 .. hfull - 1 of every batch element; blocks nfull .. nfull + nsplit - 1: split blocks
+// of 128 rows over the remaining heads.  (Which rows run split depends on the HEAD only, never on the position in the batch: the two block
+// kinds round differently, and permuting the episodes of a call must permute its output bit for bit.)
+// XCD-aware order inside each range (as attention_stream.hip): consecutive block ids go round-robin over the 8 XCDs, so the blocks that
+// share one (batch, head)'s K / V^T get ids that land on ONE XCD, next to each other in dispatch order.
+template <int ABL>
+__global__ __launch_bounds__(256, 1) void attn_fwd_pwg_kernel(const AttnParams p, const int nfull, const int nsplit, const int hfull) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[PWG_LDS];  // ONE LDS object (a second one makes hipcc drain vmcnt around the DMAs)
+  const int nqb = (p.Nq + 255) / 256;
+  const int bid = blockIdx.x;
+  if (bid < nfull) {
+    const int slot = (nfull % 8 == 0) ? (bid % 8) * (nfull / 8) + bid / 8 : bid;
+    const int bh = __builtin_amdgcn_readfirstlane(slot / nqb);
+    const int b = __builtin_amdgcn_readfirstlane(bh / hfull);
+    pwg_block<ABL, false>(p, smem, b, bh - b * hfull, (slot - bh * nqb) * 256);
+  } else {
+    const int j = bid - nfull, hsplit = p.heads - hfull;
+    const int unit = (nsplit % 8 == 0) ? (j % 8) * (nsplit / 8) + j / 8 : j;
+    const int bh = __builtin_amdgcn_readfirstlane(unit / (2 * nqb));
+    const int b = __builtin_amdgcn_readfirstlane(bh / hsplit);
+    pwg_block<ABL, true>(p, smem, b, hfull + bh - b * hsplit, (unit - bh * 2 * nqb) * 128);
+  }
+}
+
 #undef GN_FENCE
+
+// GN_ATTN_PWG_SPLIT=0: no split blocks (every block 256 rows)
+bool split_enabled() {
+  static const bool on = getenv("GN_ATTN_PWG_SPLIT") ? atoi(getenv("GN_ATTN_PWG_SPLIT")) != 0 : true;
+  return on;
+}
 
 }  // namespace
 
 void gn_launch_attention_pwg(const AttnParams& p, int B, hipStream_t stream) {
-  dim3 grid(((p.Nq + 255) / 256) * p.heads * B);
+  const long nqb = (p.Nq + 255) / 256, total = nqb * p.heads * B;
+  const int ntiles = p.Nk / KT;
+  const int r = (int)(total % 256);
+  // the remainder of the last round as split blocks, in whole heads: needs whole 128-row units, an even tile count and key halves long
+  // enough to pipeline
+  const bool split = split_enabled() && r > 0 && r <= 128 && p.Nq % 256 == 0 && ntiles % 2 == 0 && ntiles >= 8;
+  const int hsplit = split ? (int)(r / (B * nqb)) : 0, hfull = p.heads - hsplit;
+  const int nsplit = (int)(2 * hsplit * B * nqb), nfull = (int)(hfull * B * nqb);
+  dim3 grid(nfull + nsplit);
 #ifdef GN_PWG_ABLATIONS
   const char* e = getenv("GN_PWG_ABL");
   switch (e ? atoi(e) : 0) {
-#define ABL_CASE(n) case n: hipLaunchKernelGGL(attn_fwd_pwg_kernel<n>, grid, dim3(256), 0, stream, p); return;
-    ABL_CASE(4096) ABL_CASE(4096 + 8) ABL_CASE(4096 + 3) ABL_CASE(4096 + 31) ABL_CASE(2048) ABL_CASE(2304) ABL_CASE(768) ABL_CASE(1024) ABL_CASE(1792) ABL_CASE(1280) ABL_CASE(256) ABL_CASE(259) ABL_CASE(260) ABL_CASE(272) ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(28) ABL_CASE(31) ABL_CASE(96) ABL_CASE(99) ABL_CASE(124) ABL_CASE(32) ABL_CASE(64)
+#define ABL_CASE(n) case n: hipLaunchKernelGGL(attn_fwd_pwg_kernel<n>, grid, dim3(256), 0, stream, p, nfull, nsplit, hfull); return;
+    ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(28) ABL_CASE(31) ABL_CASE(32) ABL_CASE(64) ABL_CASE(96) ABL_CASE(99) ABL_CASE(124)
+    ABL_CASE(4096) ABL_CASE(4096 + 8) ABL_CASE(4096 + 3)
 #undef ABL_CASE
     default: break;
   }
 #endif
-  hipLaunchKernelGGL(attn_fwd_pwg_kernel<0>, grid, dim3(256), 0, stream, p);
+  hipLaunchKernelGGL(attn_fwd_pwg_kernel<0>, grid, dim3(256), 0, stream, p, nfull, nsplit, hfull);
 }

@@ -188,7 +188,7 @@ def test_attention_strided_qk_and_spike(engine):
 
 
 @pytest.mark.parametrize("where", ["far_tile", "one_row", "every_tile"])
-def test_attention_stream_kernel_fallback(engine, where):
+def test_attention_stream_kernel_fallback(engine, attn_variant, where):
     """attention_stream.hip guesses the softmax reference from the block's diagonal key tile and never looks back inside the loop; scores
     that outgrow the guess by more than 2^8 set a flag and the block redoes its rows with the max-tracking loop.  Force that: keys far
     from the diagonal (or everywhere, growing) that beat every diagonal score by tens of nats."""
@@ -209,6 +209,7 @@ def test_attention_stream_kernel_fallback(engine, where):
     q, k, v = (t.half().cuda() for t in (q, k, v))
     vt = v.transpose(1, 2).contiguous()
     lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
+    attn_variant(4)
     o = engine.attention(q, k, vt, heads, lse=lse)
     assert_attention(o, q, k, v, heads, what=f"stream-kernel fallback ({where})", factor=2.5)
     s = (q.float().view(B, N, heads, D).transpose(1, 2) @ k.float().view(B, N, heads, D).transpose(1, 2).transpose(-1, -2)) * D ** -0.5
@@ -216,6 +217,70 @@ def test_attention_stream_kernel_fallback(engine, where):
     assert float((lse.cpu() - ref_lse).abs().max()) < 2e-2, "lse after the fallback"
     o2 = engine.attention(q, k, v, heads, v_rowmajor=True)  # the generic kernel on the same problem
     assert_close(o, o2.float(), rel=1e-3, what=f"stream kernel vs generic kernel ({where})")
+
+
+@pytest.fixture
+def attn_variant(engine):
+    """gn_attention_set_variant for the duration of a test (0 attention.hip, 4 attention_stream.hip, 5 attention_pwg.hip; -1 the library's choice)."""
+    yield engine.lib.gn_attention_set_variant
+    engine.lib.gn_attention_set_variant(-1)
+
+
+@pytest.mark.parametrize("B,heads,N", [(1, 2, 256), (2, 3, 512), (1, 2, 1024), (1, 2, 320), (1, 1, 128), (1, 3, 4096), (3, 11, 2048), (2, 65, 1024)])
+def test_attention_pwg_kernel(engine, attn_variant, B, heads, N):
+    """attention_pwg.hip (one wave per SIMD, 64 query rows per wave): 256-row blocks (2 x 65 x 1024: 520 blocks = two full rounds + 8 -> 16
+    split blocks), all-split grids (block count <= 128 with >= 8 key tiles: 512 .. 4096 keys), short key loops (128, 256 keys) and ragged
+    row counts (320: masked rows, no split) -- against fp32 at the attention bar, against attention_stream.hip, and the lse output."""
+    C = heads * 64
+    qk, v = randn_h(B, N, 2 * C, seed=41), randn_h(B, N, C, seed=43)
+    q, k = qk[:, :, :C], qk[:, :, C:]  # column slices of one fused projection
+    vt = v.transpose(1, 2).contiguous()
+    attn_variant(5)
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
+    o = engine.attention(q, k, vt, heads, lse=lse).clone()
+    attn_variant(4)
+    o4 = engine.attention(q, k, vt, heads).clone()
+    assert_attention(o, q, k, v, heads, what=f"pwg {B}x{heads}x{N}")
+    assert_close(o, o4.float(), rel=1e-3, what="attention_pwg vs attention_stream")
+    s = (q.float().cpu().view(B, N, heads, 64).transpose(1, 2) @ k.float().cpu().view(B, N, heads, 64).transpose(1, 2).transpose(-1, -2)) * 0.125
+    assert float((lse.cpu() - torch.logsumexp(s, -1) * 1.4426950408889634).abs().max()) < 2e-3, "lse (log2 units)"
+    attn_variant(5)
+    assert torch.equal(o, engine.attention(q, k, vt, heads)), "a second call is bit-identical"
+    if B > 1:  # which rows run in split blocks depends on the head, never on the batch position
+        perm = torch.arange(B - 1, -1, -1, device="cuda")
+        o_p = engine.attention(qk[perm][:, :, :C], qk[perm][:, :, C:], vt[perm].contiguous(), heads)
+        assert torch.equal(o_p, o[perm]), "permuting the batch permutes the output bit for bit"
+
+
+@pytest.mark.parametrize("where,N", [("far_tile", 1024), ("one_row", 1024), ("every_tile", 1024), ("far_tile", 448), ("every_tile", 4096)])
+def test_attention_pwg_kernel_fallback(engine, attn_variant, where, N):
+    """The optimistic softmax's fallback in attention_pwg.hip, in split blocks (1024 / 4096 keys: both waves of a row block redo all keys)
+    and in 256-row blocks (448 keys: seven tiles): the cases of test_attention_stream_kernel_fallback."""
+    B, heads, D = 2, 3, 64
+    C = heads * D
+    g = torch.Generator().manual_seed(7)
+    q, k, v = (torch.randn(B, N, C, generator=g) for _ in range(3))
+    if where == "far_tile":
+        d = torch.randn(D, generator=g); d = d / d.norm()
+        q[:, :, :D] += 6.0 * d
+        k[:, N - 40, :D] = 50.0 * d
+    elif where == "one_row":
+        k[0, 37, D:2 * D] = 12.0 * q[0, 900, D:2 * D]
+    else:
+        d = torch.randn(D, generator=g); d = d / d.norm()
+        q[:, :, 2 * D:] = 0.3 * q[:, :, 2 * D:] + 8.0 * d
+        k[:, :, 2 * D:] = 0.3 * k[:, :, 2 * D:] + torch.linspace(-4.0, 4.0, N)[None, :, None] * d * 3.0
+    q, k, v = (t.half().cuda() for t in (q, k, v))
+    vt = v.transpose(1, 2).contiguous()
+    lse = torch.empty(B, heads, N, dtype=torch.float32, device="cuda")
+    attn_variant(5)
+    o = engine.attention(q, k, vt, heads, lse=lse)
+    assert_attention(o, q, k, v, heads, what=f"pwg fallback ({where}, {N})", factor=2.5)
+    s = (q.float().view(B, N, heads, D).transpose(1, 2) @ k.float().view(B, N, heads, D).transpose(1, 2).transpose(-1, -2)) * D ** -0.5
+    ref_lse = (torch.logsumexp(s, -1) * 1.4426950408889634).cpu()
+    assert float((lse.cpu() - ref_lse).abs().max()) < 2e-2, "lse after the fallback"
+    o2 = engine.attention(q, k, v, heads, v_rowmajor=True)  # the generic kernel on the same problem
+    assert_close(o, o2.float(), rel=1e-3, what=f"pwg kernel vs generic kernel ({where})")
 
 
 @pytest.mark.parametrize("B,heads,Nq,Nk", [(2, 5, 4096, 77), (1, 10, 1000, 77), (2, 5, 16421, 77), (1, 3, 37, 65), (2, 2, 300, 96), (1, 20, 64, 80)])

@@ -36,7 +36,7 @@ def timeit(fn, iters=20):
 
 
 ok = True
-for B, heads, N, spike in [(1, 2, 256, 0), (2, 3, 512, 0), (1, 2, 1024, 0), (2, 5, 4096, 0), (1, 3, 1024, 1), (1, 2, 320, 0), (1, 1, 128, 0), (2, 2, 1024, 2)]:
+for B, heads, N, spike in [(1, 2, 256, 0), (2, 3, 512, 0), (1, 2, 1024, 0), (2, 5, 4096, 0), (1, 3, 1024, 1), (1, 2, 320, 0), (1, 1, 128, 0), (2, 2, 1024, 2), (1, 3, 4096, 0), (3, 11, 2048, 0), (1, 2, 4096, 1)]:
     C = heads * 64
     g = torch.Generator().manual_seed(N + heads)
     qk = torch.randn(B, N, 2 * C, generator=g)
@@ -44,7 +44,7 @@ for B, heads, N, spike in [(1, 2, 256, 0), (2, 3, 512, 0), (1, 2, 1024, 0), (2, 
     if spike == 1:  # one far key far above every diagonal score for head 0: forces the fallback
         d = torch.randn(64, generator=g); d = d / d.norm()
         qk[:, :, :64] += 6.0 * d
-        qk[:, 600, C:C + 64] = 50.0 * d
+        qk[:, min(600, N - 7), C:C + 64] = 50.0 * d
     if spike == 2:  # maximum grows along the keys for head 1
         d = torch.randn(64, generator=g); d = d / d.norm()
         qk[:, :, 64:128] = 0.3 * qk[:, :, 64:128] + 8.0 * d
@@ -68,7 +68,7 @@ for B, heads, N, spike in [(1, 2, 256, 0), (2, 3, 512, 0), (1, 2, 1024, 0), (2, 
     print(f"B={B} heads={heads} N={N} spike={spike}: stream {e4:.3e}  pwg {e5:.3e}  pwg-vs-stream {rel(outs[5][0], outs[4][0]):.3e}  lse err {l5:.2e}  {'ok' if good else 'FAIL'}", flush=True)
 print("PARITY", "OK" if ok else "FAILED", flush=True)
 
-for B, heads, N in [(8, 5, 4096), (8, 10, 4096), (8, 10, 1024), (4, 5, 4096), (1, 5, 4096), (8, 20, 1024)]:
+for B, heads, N in [(8, 5, 4096), (8, 10, 4096), (8, 10, 1024), (4, 5, 4096), (2, 5, 4096), (1, 5, 4096), (8, 20, 1024), (1, 10, 1024)]:
     C = heads * 64
     qk = torch.randn(B, N, 2 * C, device="cuda").half()
     vt = torch.randn(B, C, N, device="cuda").half()
