@@ -206,8 +206,13 @@ __device__ __forceinline__ void pwg_block(const AttnParams& p, unsigned char* co
         else if constexpr (SPLIT) dma_piece(ntl + dma_tile, Xd + RING, i - 4);
       }
     };
+    f16x8 dummy[8];
     auto R = [&](int i) {
       if constexpr ((ABL & 8) != 0) return;
+      if constexpr ((ABL & 128) != 0) {  // (probe) the reads are issued but no MFMA consumes them
+        if constexpr (READ != 0) dummy[i] = frag(ring, Xn, UN, FI(i));
+        return;
+      }
       if constexpr (READ == 1) f[i] = frag(ring, Xn, UN, FI(i));
       else if constexpr (READ == 2) { if (i & 1) f[i] = frag(ring, Xn, UN, FI(i)); }
     };
@@ -239,6 +244,10 @@ __device__ __forceinline__ void pwg_block(const AttnParams& p, unsigned char* co
     GN_FENCE; M(7); GN_FENCE; R(7); D(7); E(7); C(6); S(5);
     GN_FENCE; S(6); C(7); S(7);
     GN_FENCE;
+    if constexpr ((ABL & 128) != 0 && READ != 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" ::"v"(dummy[i]));
+    }
     const float psum = ps0 + ps1;
     sticky |= __builtin_amdgcn_ballot_w64(!(psum <= PLIM));  // v_cmp + s_or: no branch
     l_run[XS] += psum;
@@ -498,7 +507,7 @@ void gn_launch_attention_pwg(const AttnParams& p, int B, hipStream_t stream) {
   switch (e ? atoi(e) : 0) {
 #define ABL_CASE(n) case n: hipLaunchKernelGGL(attn_fwd_pwg_kernel<n>, grid, dim3(256), 0, stream, p, nfull, nsplit, hfull); return;
     ABL_CASE(1) ABL_CASE(2) ABL_CASE(3) ABL_CASE(4) ABL_CASE(8) ABL_CASE(16) ABL_CASE(28) ABL_CASE(31) ABL_CASE(32) ABL_CASE(64) ABL_CASE(96) ABL_CASE(99) ABL_CASE(124)
-    ABL_CASE(4096) ABL_CASE(4096 + 8) ABL_CASE(4096 + 3)
+    ABL_CASE(4096) ABL_CASE(4096 + 8) ABL_CASE(4096 + 3) ABL_CASE(4096 + 128) ABL_CASE(128)
 #undef ABL_CASE
     default: break;
   }

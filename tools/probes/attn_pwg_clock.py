@@ -15,7 +15,7 @@ qk = torch.randn(B, N, 2 * C, device="cuda").half()
 vt = torch.randn(B, C, N, device="cuda").half()
 o = torch.empty(B, N, C, device="cuda", dtype=torch.float16)
 lse = torch.zeros(B, heads, N, dtype=torch.float32, device="cuda")
-for abl, name in [(4096, "whole kernel"), (4096 + 8, "no fragment reads"), (4096 + 3, "no softmax VALU"), (4096 + 31, "MFMAs only"), (4096, "whole kernel")]:
+for abl, name in [(4096, "whole kernel"), (4096 + 8, "no fragment reads"), (4096 + 128, "reads issued, not consumed"), (4096 + 3, "no softmax VALU"), (4096, "whole kernel")]:
     os.environ["GN_PWG_ABL"] = str(abl)
     for _ in range(60):
         E.attention(qk[:, :, :C], qk[:, :, C:], vt, heads, out=o, lse=lse)
