@@ -829,7 +829,7 @@ constexpr int kCfgS3 = 15;  // first of the four 3-stage configurations
 
 // the ping-pong kernel's extra restrictions on top of dma_eligible (gemm_pp.hip header)
 bool pp_eligible(const gn_gemm_desc* d) {
-  if (d->act == GN_ACT_GEGLU || d->batch > 1 || d->fp8 || d->K % 64 != 0) return false;
+  if (d->act == GN_ACT_GEGLU || (d->batch > 1 && !d->up_phases) || d->fp8 || d->K % 64 != 0) return false;
   if (d->conv && (d->C1 % 64 != 0 || d->C2 % 64 != 0)) return false;
   return true;
 }
@@ -1171,7 +1171,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 11: launch_dma<256, 64, 4, 1>(p, conv, ctx->stream); break;
     case 12: launch_dma<128, 320, 2, 2>(p, conv, ctx->stream); break;
     case 13: launch_dma<256, 320, 4, 2>(p, conv, ctx->stream); break;
-    case 14: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, 1, ctx->stream); break;
+    case 14: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;
     case 22: launch_dma<128, 160, 4, 1>(p, conv, ctx->stream); break;
     case 23: launch_dma<128, 320, 4, 2>(p, conv, ctx->stream); break;
     default: gn_launch_gemm_s3(&p, pl.cfg - kCfgS3, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;

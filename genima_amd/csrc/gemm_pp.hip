@@ -27,7 +27,8 @@ constexpr int PP_HALF = 16384;   // one half-tile (128 rows)
 // ABL (tools/bench_gemm_pp.py, env GN_PP_ABL): 0 = the kernel; ablations that say what bounds the K loop (results are wrong):
 //   1 no DMA, 2 no fragment reads, 3 no MFMA, 4 no s_setprio, 5 no barriers
 template <bool CONV, int ABL>
-__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams p) {
+__global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams pin) {
+  const GemmParams p = batch_offset(pin);  // blockIdx.z: the four phase convs of an upsampling conv (round 5) -- weights, padding, output offset
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PP_STAGE];
 
   const int tid = threadIdx.x;
