@@ -252,6 +252,22 @@ def test_attention_pwg_kernel(engine, attn_variant, B, heads, N):
         assert torch.equal(o_p, o[perm]), "permuting the batch permutes the output bit for bit"
 
 
+def test_attention_default_routing_takes_the_pwg_kernel_for_large_grids(engine, attn_variant):
+    """gn_attention_fwd's own choice: >= 2048 keys and >= 256 row blocks of 256 (the 64 x 64 latent level at B >= 4) run attention_pwg.hip --
+    bit-identical to variant 5 -- smaller grids and shorter key sets stay with attention_stream.hip (variant 4)."""
+    def run(B, heads, N, variant):
+        C = heads * 64
+        qk, v = randn_h(B, N, 2 * C, seed=51), randn_h(B, N, C, seed=52)
+        attn_variant(variant)
+        return engine.attention(qk[:, :, :C], qk[:, :, C:], v.transpose(1, 2).contiguous(), heads).clone()
+    big = (4, 5, 4096)   # 320 blocks: 256 full + 128 split
+    assert torch.equal(run(*big, -1), run(*big, 5))
+    small = (1, 5, 4096)  # 80 blocks: below the block threshold
+    assert torch.equal(run(*small, -1), run(*small, 4))
+    short = (8, 10, 1024)  # 320 blocks, 1024 keys: below the key threshold
+    assert torch.equal(run(*short, -1), run(*short, 4))
+
+
 @pytest.mark.parametrize("where,N", [("far_tile", 1024), ("one_row", 1024), ("every_tile", 1024), ("far_tile", 448), ("every_tile", 4096)])
 def test_attention_pwg_kernel_fallback(engine, attn_variant, where, N):
     """The optimistic softmax's fallback in attention_pwg.hip, in split blocks (1024 / 4096 keys: both waves of a row block redo all keys)

@@ -46,8 +46,8 @@ def gemm_ops(E):
         d = GemmDesc()
         if E.lib.gn_program_get_gemm(E._prog, i, C.byref(d)) != 0:
             continue
-        if d.fp8 or d.up_phases or d.accumulate:
-            continue
+        if d.fp8 or d.up_phases or d.accumulate or d.norm_out.y or d.norm_in.stats or d.sink.stats:  # (round 5: the reduce-side GroupNorm needs a K split,
+            continue                                                                            #  the bridge's tails / A path their own tiles: not raced here)
         out.setdefault(Engine._tune_key(d), []).append((i, d, side))
     return out
 
