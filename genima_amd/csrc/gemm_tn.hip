@@ -27,14 +27,18 @@ struct TnParams {
   float* sums_ws;  // optional [splitk][M]: column sums of dY over each row slice (bias / time-shift gradients ride on the A operand)
 };
 
-// chunk swizzle of a row of CPR 16-byte chunks: XOR on the 32-byte pair index so that rows r..r+3 and r+8..r+11 (one transpose read
-// of a wave) land on different banks
+// chunk swizzle of a row of CPR 16-byte chunks.  A transpose read is served in two halves of 32 lanes, and one half is FOUR rows x 64
+// contiguous bytes (rows 8 hb + 0 .. 3, the 32 columns of a fragment): conflict-free when the four 64-byte segments fall into the four
+// 64-byte quarters of the 256 bytes the 64 banks span.  So the XOR moves whole quarters (chunk bits 2, 3), never pieces inside one.
+// (Round 5: the first version XORed the 32-byte pair index -- rows r, r + 1 stayed in one quarter: SQ_LDS_BANK_CONFLICT = 50 % of
+//  SQ_LDS_IDX_ACTIVE on both tiles, profiles/r05_v14_wgrad_pmc.txt; with four LDS instructions per MFMA on the 64 x 64 tile the LDS, not
+//  the matrix pipe, was what the kernel waited for.)
 template <int CPR>
 __device__ __forceinline__ int tn_swz(int row) {
-  // (only row bits 0, 1 and 3 may enter: a fragment's second read is 4 rows further, the next k16 step 16 rows further, and both
-  //  must keep the swizzle so that one base address + immediates walks the tile)
-  if constexpr (CPR >= 16) return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-byte rows: every row starts at bank 0
-  else return (((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 1;              // 128-byte rows: odd rows already sit on the other bank half
+  // (only row bits 0 and 1 may enter: a fragment's second read is 4 rows further, the other half-wave 8, the next k16 step 16 rows
+  //  further, and all must keep the swizzle so that one base address + immediates walks the tile)
+  if constexpr (CPR >= 16) return (row & 3) << 2;   // 256-byte rows: every row starts at bank 0 -> row r's segment goes to quarter q ^ (r & 3)
+  else return ((row >> 1) & 1) << 2;              // 128-byte rows: odd rows already sit on the other half of the banks
 }
 
 template <int BM, int BN, bool CONV>
