@@ -45,9 +45,21 @@ struct AttnBwdParams {
 __device__ __forceinline__ int swap23(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
 __device__ __forceinline__ int perm_row(int r) { return (r & 32) | swap23(r & 31); }
 
+// Chunk swizzle of the streamed [rows][128 B] tiles: the three bits of (row >> 1) & 7 as the forward kernels' lds_swz<128> uses them, ROTATED so
+// that row bit 1 lands on chunk bit 2.  The tiles are read two ways: ds_read_b128 MFMA fragments (rows = lane & 31, one chunk column: any
+// bijection of the three bits is conflict-free) and ds_read_b64_tr_b16 transposed fragments, whose half-wave is FOUR consecutive rows x 64
+// contiguous bytes -- rows r and r + 2 sit on the same half of the banks and must differ in the 64-byte quarter (chunk bit 2).  With the
+// forward swizzle they differed in chunk bit 0 only: SQ_LDS_BANK_CONFLICT was 25 % of both kernels' LDS cycles (round 5,
+// tools/probes/lds_conflict_pmc.sh), with the LDS array as busy as the matrix pipe in the dK / dV kernel.
+__device__ __forceinline__ int bwd_swz(int row) {
+  const int s = (row >> 1) & 7;
+  return ((s & 1) << 2) | (s >> 1);
+}
+__device__ __forceinline__ int bwd_lds(int row, int chunk) { return row * 128 + ((chunk ^ bwd_swz(row)) << 4); }
+
 // ---- LDS-DMA staging of the streamed [64 rows][128 B] tiles (same scheme as attention.hip / gemm_dma_kernel): a DMA instruction fills
 // 8 consecutive LDS rows lane-linearly (16 B per lane), so the lane that owns LDS (row, physical chunk) fetches source row
-// perm(row) (row-major operands) or row (transposed operands), logical chunk = chunk ^ ((row >> 1) & 7).  Anything past a
+// perm(row) (row-major operands) or row (transposed operands), logical chunk = chunk ^ bwd_swz(row).  Anything past a
 // descriptor's extent reads as zero (rows >= the valid count of Q / dO / K / V).  4 waves: wave w issues groups w and w + 4.
 typedef __attribute__((address_space(3))) void* bwd_lds_ptr_t;
 struct TileStream {
@@ -59,7 +71,7 @@ __device__ __forceinline__ TileStream make_stream(int wave, int lane, long row_s
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int row = 8 * (wave + 4 * i) + (lane >> 3);
-    const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    const int chunk = (lane & 7) ^ bwd_swz(row);
     const int src = permute ? perm_row(row) : row;
     s.off[i] = (unsigned)(((long)src * row_stride_elems + chunk * 8) * 2);
   }
@@ -111,7 +123,7 @@ __device__ __forceinline__ void attn_bwd_block(int nblk, int heads, int& blk, in
 // per operand in LDS): gfx950's ds_read_b64_tr_b16 hands lane c of a 16-lane group column c of a 4-row x 16-column block whose rows
 // the group's lanes address themselves.  Wanted: the MFMA A fragment of X^T -- d = 32 dt + (lane & 31), streamed rows
 // 32 u + 16 g + 8 hi + (0..7).  Logical row 16 g + 8 hi + 4 half + j sits at physical row 16 g + 8 half + 4 hi + j (rows are stored
-// with index bits 2 and 3 swapped), and the tile's chunk swizzle (row >> 1) & 7 = (half, hi, j >> 1) does not depend on u or g: one
+// with index bits 2 and 3 swapped), and the tile's chunk swizzle bwd_swz(row) (row bits 1 .. 3) does not depend on u or g: one
 // byte offset per (dt, half) and lane, immediates for u and g.
 typedef __fp16 bwd_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 typedef __attribute__((address_space(3))) bwd_h4* bwd_lds_h4_ptr;
@@ -126,7 +138,7 @@ __device__ __forceinline__ TrOffsets make_tr_offsets(int lane) {
     for (int half = 0; half < 2; ++half) {
       const int prow = 8 * half + 4 * hb + (ti >> 2);
       const int col = dt * 32 + 16 * g2 + 4 * (ti & 3);
-      t.off[dt][half] = prow * 128 + ((((col >> 3) ^ ((prow >> 1) & 7))) << 4) + ((col & 7) << 1);
+      t.off[dt][half] = prow * 128 + ((((col >> 3) ^ bwd_swz(prow))) << 4) + ((col & 7) << 1);
     }
   return t;
 }
@@ -200,8 +212,8 @@ __global__ __launch_bounds__(256, GN_ATTNB_DQ_WAVES) void attn_bwd_dq_kernel(con
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
-        const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
+        const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + bwd_lds(u * 32 + l31, ks * 2 + hi));
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(Vs + bwd_lds(u * 32 + l31, ks * 2 + hi));
         s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], ks == 0 ? zero16 : s[u], 0, 0, 0);
         dp[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, gf[ks], ks == 0 ? zero16 : dp[u], 0, 0, 0);
       }
@@ -325,8 +337,8 @@ __global__ __launch_bounds__(256, GN_ATTNB_DKV_WAVES) void attn_bwd_dkv_kernel(c
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const f16x8 qfr = *reinterpret_cast<const f16x8*>(Qs + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
-        const f16x8 gfr = *reinterpret_cast<const f16x8*>(Gs + lds_swz<128>(u * 32 + l31, ks * 2 + hi));
+        const f16x8 qfr = *reinterpret_cast<const f16x8*>(Qs + bwd_lds(u * 32 + l31, ks * 2 + hi));
+        const f16x8 gfr = *reinterpret_cast<const f16x8*>(Gs + bwd_lds(u * 32 + l31, ks * 2 + hi));
         s[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(qfr, kf[ks], ks == 0 ? zero16 : s[u], 0, 0, 0);
         dp[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(gfr, vf[ks], ks == 0 ? zero16 : dp[u], 0, 0, 0);
       }

@@ -8,7 +8,7 @@
 // input: 0.54 GB per conv at the VAE's 512^2 x 128-channel level) and the implicit-GEMM conv stages every input pixel nine times.  Here:
 //   * a workgroup owns an 8 x 16 tile of output pixels (128 GEMM rows) x 128 output channels;
 //   * its 10 x 18 input patch (halo included) of a 128-channel group is DMA'd into LDS ONCE (`buffer_load ... lds`, 256-byte pixels, the
-//     sixteen 16-byte channel chunks of a pixel XOR-swizzled by the pixel's patch index so that the MFMA fragment reads of 16 neighbouring
+//     sixteen 16-byte channel chunks of a pixel XOR-swizzled by the pixel's patch column so that the MFMA fragment reads of 16 neighbouring
 //     pixels are conflict-free; pixels outside the image land as zeros = the conv's zero padding);
 //   * the GroupNorm's per-(sample, channel) scale / shift (gn_groupnorm_fwd with y == NULL: statistics only) and the SiLU are applied to the
 //     patch IN LDS, once per staged element (1.4x the tile's pixels instead of 9x), in f32 as gn_apply_kernel (norm.hip) does and rounded
@@ -133,7 +133,10 @@ __device__ __forceinline__ void conv3x3_gn_body(const CgParams& p, unsigned char
       __builtin_amdgcn_s_barrier();
     }
     // ---- the patch: 45 instructions of 4 pixels x 256 bytes; lane q of one lands at physical chunk q & 15 of pixel 4 t + (q >> 4) and
-    // therefore fetches logical chunk (q & 15) ^ (pixel index & 15)
+    // therefore fetches logical chunk (q & 15) ^ (patch column & 15).  The key is the pixel's COLUMN, not its linear index: a fragment
+    // read's 16-lane group is pixels x = 0..3, 12..15 of one tile row and x = 4..11 of the next, whose linear indices (row pitch 18)
+    // collide mod 16 at two lanes -- SQ_LDS_BANK_CONFLICT was 31 % of the kernel's LDS cycles (round 5, tools/probes/lds_conflict_pmc.sh);
+    // by column the group's keys are 16 consecutive values for every tap
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
       const int tt = wave + 4 * i;
@@ -142,7 +145,7 @@ __device__ __forceinline__ void conv3x3_gn_body(const CgParams& p, unsigned char
         const int pr = idx / CG_PW, pc = idx - pr * CG_PW;
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pc;
         const bool ok = (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        const int lc = (lane & 15) ^ (idx & 15);
+        const int lc = (lane & 15) ^ (pc & 15);
         unsigned voff = ok ? (unsigned)(((((long)b * p.H + gy) * p.W + gx) * p.Cin + cg * CG_CG + lc * 8) * 2) : kOOB;
         GN_PIN(voff);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(smem + tt * 1024), 16, voff, 0, 0, 0);
@@ -172,7 +175,7 @@ __device__ __forceinline__ void conv3x3_gn_body(const CgParams& p, unsigned char
         const int pr = idx / CG_PW, pcx = idx - pr * CG_PW;
         const int gy = y0 - 1 + pr, gx = x0 - 1 + pcx;
         if ((unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
-          unsigned char* q = smem + idx * 256 + ((lcn ^ (idx & 15)) << 4);
+          unsigned char* q = smem + idx * 256 + ((lcn ^ (pcx & 15)) << 4);
           const f16x8 v = *reinterpret_cast<const f16x8*>(q);
           f16x8 o;
 #pragma unroll
@@ -197,6 +200,7 @@ __device__ __forceinline__ void conv3x3_gn_body(const CgParams& p, unsigned char
       if (kt + 1 < 18) dma_w((kt + 1) & 1, ((kt + 1) >> 1) * p.Cin + cg * CG_CG + ((kt + 1) & 1) * 64);
       const int dy = tap / 3, dx = tap - dy * 3;
       const int toff = dy * CG_PW + dx;
+      const int key = ((l31 & 15) + dx) & 15;  // swizzle key of the tapped pixel = its patch COLUMN (below)
       const unsigned char* Ws = smem + CG_W_OFF + (kt & 1) * CG_WT;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
@@ -205,7 +209,7 @@ __device__ __forceinline__ void conv3x3_gn_body(const CgParams& p, unsigned char
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int idx = pidx0[i] + toff;
-          fa[i] = *reinterpret_cast<const f16x8*>(smem + idx * 256 + ((cl ^ (idx & 15)) << 4));
+          fa[i] = *reinterpret_cast<const f16x8*>(smem + idx * 256 + ((cl ^ key) << 4));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) fw[j] = *reinterpret_cast<const f16x8*>(Ws + lds_swz<128>(wn * (32 * TN) + j * 32 + l31, kk * 2 + hi));
