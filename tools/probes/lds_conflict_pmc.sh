@@ -15,8 +15,8 @@ for f in sorted(glob.glob(O+"/**/*counter_collection.csv", recursive=True)):
         a=v.get("SQ_LDS_IDX_ACTIVE",0.0)
         if a<=0: continue
         rows.append((a, k, v))
-    for a,k,v in sorted(rows, reverse=True)[:40]:
+    for a,k,v in sorted(rows, key=lambda r: -r[2].get('GRBM_GUI_ACTIVE',0))[:45]:
         c=v.get("SQ_LDS_BANK_CONFLICT",0.0); l=n[(k,"SQ_LDS_IDX_ACTIVE")]
-        print(f"{k:72s} launches {l:5d}  LDS active {a/l:12.0f}  conflict {c/max(a,1)*100:5.1f} %  LDS/MFMA {v.get('SQ_INSTS_LDS',0)/max(v.get('SQ_INSTS_MFMA',1),1):5.2f}  LDS-active/(4 x MFMA-busy) {a/256/max(v.get('SQ_VALU_MFMA_BUSY_CYCLES',1)/1024,1):5.2f}")
+        print(f"{k:72s} launches {l:5d}  LDS active {a/l:12.0f}  conflict {c/max(a,1)*100:5.1f} %  LDS/MFMA {v.get('SQ_INSTS_LDS',0)/max(v.get('SQ_INSTS_MFMA',1),1):5.2f}  LDS-active/(4 x MFMA-busy) {a/256/max(v.get('SQ_VALU_MFMA_BUSY_CYCLES',1)/1024,1):5.2f}  pipe busy {v.get('SQ_VALU_MFMA_BUSY_CYCLES',0)/1024/max(v.get('GRBM_GUI_ACTIVE',1)/8,1)*100:5.1f} %  cycles/launch {v.get('GRBM_GUI_ACTIVE',0)/8/l:10.0f}  total Mcyc {v.get('GRBM_GUI_ACTIVE',0)/8/1e6:8.2f}")
 PY
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -size +8M -delete
