@@ -1,5 +1,5 @@
 # Round-5 (second session) evidence run: as profile_round5.sh (bench line, rocprofv3 kernel stats + exact-N-call window, per-shape op tables,
-# train step, attention micro-benchmark, PMC traffic stamped with GIT_COMMIT); summaries are copied to profiles/r05_v13_*.
+# train step, attention micro-benchmark, PMC traffic stamped with GIT_COMMIT); summaries are copied to profiles/r05_v16_*.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_r05b; rm -rf $O; mkdir -p $O
 cd $R
