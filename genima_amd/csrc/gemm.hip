@@ -917,6 +917,12 @@ Plan plan_gemm(const gn_gemm_desc* d) {
     static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1, 1};
     best = fallback[best];
   }
+  {  // audit aid: GN_GEMM_LOG_FALLBACK=1 reports every launch whose requested tile (the tune table's) is not the tile that runs
+    static const bool log_fb = getenv("GN_GEMM_LOG_FALLBACK") && atoi(getenv("GN_GEMM_LOG_FALLBACK")) != 0;
+    if (log_fb && d->tile >= 1 && d->tile <= kNumCfg && best != d->tile - 1)
+      fprintf(stderr, "[gn_gemm] tile %d requested, %d runs: conv %d M %ld N %ld K %ld act %d batch %d up_phases %d ln %d k_append %d fp8 %d C1 %d C2 %d\n", d->tile,
+              best + 1, d->conv, (long)M, (long)N, (long)K, d->act, d->batch, d->up_phases, d->ln_c1 != nullptr, d->k_append, d->fp8, d->C1, d->C2);
+  }
   pl.cfg = best;
   pl.bm = kCfg[best].bm; pl.bn = kCfg[best].bn;
   const int64_t blocks = cdiv64(M, pl.bm) * cdiv64(N, pl.bn);
