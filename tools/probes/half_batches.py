@@ -29,10 +29,10 @@ def build(pipe, dev, B, n, steps):
     return progs, streams
 
 
-def timed(progs, streams, dev, calls, join):
+def timed(progs, streams, dev, calls, join, graph=False):
     def one():
         for io in progs:
-            io.engine.run()
+            io.engine.launch() if graph else io.engine.run()
         if join and len(progs) > 1:  # the call ends when every sub-batch has: nobody starts the next call before that
             evs = []
             for st in streams:
@@ -55,6 +55,7 @@ def timed(progs, streams, dev, calls, join):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--calls", type=int, default=6)
+    ap.add_argument("--graph", action="store_true", help="replay each program as one captured hipGraph")
     ap.add_argument("--configs", default="8x1,4x1,4x2,2x1,2x4,8x2", help="B x programs, comma separated")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -71,11 +72,17 @@ def main():
     rows = []
     for B, n in [tuple(int(v) for v in c.split("x")) for c in args.configs.split(",")]:
         progs, streams = build(pipe, dev, B, n, 5)
+        if args.graph:
+            for io, st in zip(progs, streams):
+                with torch.cuda.stream(st):
+                    io.engine.run()
+                    st.synchronize()
+                    io.engine.capture()
         for rep in range(2):
-            j = timed(progs, streams, dev, args.calls, True)
-            f = timed(progs, streams, dev, args.calls, False) if n > 1 else float("nan")
+            j = timed(progs, streams, dev, args.calls, True, args.graph)
+            f = timed(progs, streams, dev, args.calls, False, args.graph) if n > 1 else float("nan")
             rows.append((B, n, rep, j, f))
-            print(f"{n} x B = {B}: joined {j:8.2f} ms per round of {n * B} episodes ({j / (n * B):6.2f} ms / episode)   free-running {f:8.2f}", flush=True)
+            print(f"{'graph ' if args.graph else ''}{n} x B = {B}: joined {j:8.2f} ms per round of {n * B} episodes ({j / (n * B):6.2f} ms / episode)   free-running {f:8.2f}", flush=True)
         del progs, streams
         torch.cuda.empty_cache()
     pipe._progs.clear()
