@@ -370,25 +370,35 @@ def main():
 
     for _ in range(args.warmup):
         call()
+    # The timed region: K calls, each one the reference's own bracket -- prompt + images in HBM -> denoise ->
+    # VAE -> uint8 images AND the controller's actions on the HOST (gen_time + control_time of controller/eval_genima.py:202-247) -- i.e. every call ends in
+    # its D->H copy and is therefore individually synchronised.  `value` = units / the whole bracket (barrier + synchronize on both sides, max over ranks);
+    # the median call and the back-to-back rate without the D->H (rounds 1 - 5's `value`) ride along as extras.
     barrier()
+    per_call = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        call()
+        tc = time.perf_counter()
+        call("np")
+        per_call.append(time.perf_counter() - tc)
     barrier()
     dt = time.perf_counter() - t0
     from genima_amd.dist import max_over_ranks
 
     dt = max_over_ranks(dt, dev)  # the slowest rank defines the job's time
     calls = args.steps
-    value = 4.0 * B * world * calls / dt
+    units = 4.0 if H == 512 else 1.0
+    value = units * B * world * calls / dt
+    per_call.sort()
+    median_call = per_call[len(per_call) // 2] if len(per_call) % 2 else 0.5 * (per_call[len(per_call) // 2 - 1] + per_call[len(per_call) // 2])
 
-    # D->H-inclusive bracket (the reference's gen_time: ... -> uint8 -> host PIL), rank-local, informational
+    # back-to-back bracket: the same K calls queued without waiting for their outputs (no D->H), rank-local, informational
     barrier()
     t1 = time.perf_counter()
-    for _ in range(max(1, min(3, calls))):
-        call("np")
+    for _ in range(calls):
+        call()
     torch.cuda.synchronize(dev)
-    dt_host = (time.perf_counter() - t1) / max(1, min(3, calls))
+    dt_b2b = (time.perf_counter() - t1) / calls
 
     act_ms = None
     if act_agent is not None:  # controller forward alone (the reference's control_time bracket minus the D->H copy)
@@ -414,12 +424,12 @@ def main():
                    "two_streams": bool(pipe.two_streams)},
         "images_per_sec_per_gpu": value / world,
         "act_controller_ms_per_call": act_ms,
-        "value_incl_d2h_to_host": (4.0 if H == 512 else 1.0) * B / dt_host,
+        "ms_per_call_median": 1000.0 * median_call,
+        "value_from_median_call": units * B * world / median_call,
+        "value_back_to_back_no_d2h": units * B * world / dt_b2b,
+        "timed_region": "K individually synchronised calls, each incl. the uint8 image + action D->H copies (SURVEY 8(d))",
         "algorithmic_tflops_per_gpu": GFLOP_PER_CALL.get(H, 0.0) * B * calls / dt / 1000.0,
     }
-    if H != 512:
-        out["value"] = B * world * calls / dt
-        out["images_per_sec_per_gpu"] = out["value"] / world
 
     # BASELINE.json's second metric on the same launch: the ControlNet fine-tune step (configs[3], per-GPU batch 8), N ranks data
     # parallel with the bucketed RCCL reduce-scatter + all-gather of the flat gradient overlapped with the backward.

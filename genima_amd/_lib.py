@@ -134,6 +134,9 @@ SIGNATURES = {
     "gn_ctx_destroy": (_I32, [_P]),
     "gn_ctx_set_stream": (_I32, [_P, _P]),
     "gn_gemm_workspace_bytes": (_I64, [C.POINTER(GemmDesc)]),
+    "gn_gemm_plan_valid": (_I32, [C.POINTER(GemmDesc)]),
+    "gn_ppp_timeouts": (_I64, []),
+    "gn_ppp_profile_read": (_I32, [C.POINTER(C.c_uint32), _I32]),
     "gn_gemm": (_I32, [_P, C.POINTER(GemmDesc)]),
     "gn_gemm_norm_in_supported": (_I32, [C.POINTER(GemmDesc)]),
     "gn_gemm_norm_out_supported": (_I32, [C.POINTER(GemmDesc)]),

@@ -16,7 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libgenima_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_s3.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_pwg.hip", "attention_bwd.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip", "act_train.hip", "pack.hip", "tblock.hip", "conv_gn.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_pp.hip", "gemm_ppp.hip", "gemm_s3.hip", "gemm_tn.hip", "attention.hip", "attention_stream.hip", "attention_pwg.hip", "attention_bwd.hip", "attention_fp8.hip", "norm.hip", "elementwise.hip", "backward.hip", "augment.hip", "fp8.hip", "comm.hip", "act_train.hip", "pack.hip", "tblock.hip", "conv_gn.hip"]
 # -amdgpu-mfma-vgpr-form: gfx950's register file is unified, so keep MFMA accumulators in VGPRs -- the softmax / epilogue VALU
 # then works on them in place instead of through v_accvgpr_read/write copies (400 of them per attention tile otherwise).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function"]
@@ -43,6 +43,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("common.h", "gemm_common.h", "attention_common.h", "gn_bridge.h")] + [os.path.join(HERE, "..", "include", "genima_hip.h")]
+    # the objects are only as good as the flags they were built with: a probe build (GN_HIPCC_EXTRA=-DGN_PP_ABLATIONS ..., some of which give wrong
+    # results on purpose) must never be reused by the next normal build, nor the other way round -- the flag set is stamped beside the objects
+    stamp = os.path.join(objdir, ".flags")
+    flagset = " ".join(FLAGS + [f"{k}:{' '.join(v)}" for k, v in sorted(EXTRA_FLAGS.items())] + ["extra:" + os.environ.get("GN_HIPCC_EXTRA", "").strip()])
+    try:
+        with open(stamp) as f:
+            have = f.read()
+    except OSError:
+        have = None
+    if have != flagset:
+        if have is not None or os.environ.get("GN_HIPCC_EXTRA", "").strip():
+            force = True
+        elif os.path.exists(OUT) and verbose:
+            print("[genima_amd.build] no flag stamp yet: trusting the existing objects once", flush=True)
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
@@ -61,6 +75,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if verbose:
             print("[genima_amd.build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
+    with open(stamp, "w") as f:
+        f.write(flagset)
     return OUT
 
 

@@ -112,7 +112,7 @@ static int32_t push_generic(gn_program* p, int type, const void* p0, const void*
 
 extern "C" {
 
-int32_t gn_version(void) { return 100; }
+int32_t gn_version(void) { return 101; }  // 101: gn_gemm_desc grew (sink, norm_in, norm_out; round 5) + tile 25, gn_gemm_plan_valid, GN_STATS_SHIFT_SQ (round 6)
 const char* gn_last_error(void) { return g_err; }
 
 int32_t gn_ctx_create(int32_t device, void* stream, gn_ctx** out) {
@@ -121,6 +121,7 @@ int32_t gn_ctx_create(int32_t device, void* stream, gn_ctx** out) {
   GN_HIP(hipGetDeviceCount(&n));
   GN_REQUIRE(device >= 0 && device < n, "gn_ctx_create: device %d out of range (%d visible)", device, n);
   GN_HIP(hipSetDevice(device));
+  if (gn_ppp_pool_init(device) != GN_OK) return GN_ERR_HIP;  // the persistent GEMM's hand-off flags (2 MB, zeroed once; never allocated inside a capture)
   gn_ctx* c = new gn_ctx();
   c->device = device;
   c->stream = (hipStream_t)stream;
@@ -318,11 +319,14 @@ int32_t gn_program_get_gemm(const gn_program* p, int64_t op, gn_gemm_desc* out) 
 int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_t splitk, void* workspace) {
   GN_REQUIRE(p && op >= 0 && op < (int64_t)p->ops.size() && p->ops[(size_t)op].type == OP_GEMM, "gn_program_set_gemm_plan: op %ld is not a gn_gemm", (long)op);
   GN_REQUIRE(!p->exec, "gn_program_set_gemm_plan: the program is captured (re-capture after tuning)");
-  GN_REQUIRE(tile >= 0 && tile <= 24 && splitk >= 0, "gn_program_set_gemm_plan: tile %d (0 = heuristic, 1 .. 24) / splitk %d out of range", tile, splitk);
+  GN_REQUIRE(tile >= 0 && tile <= GN_NUM_GEMM_TILES && splitk >= 0, "gn_program_set_gemm_plan: tile %d (0 = heuristic, 1 .. %d) / splitk %d out of range", tile, GN_NUM_GEMM_TILES, splitk);
   gn_gemm_desc d = p->ops[(size_t)op].gemm;  // validated on a copy: a refused plan leaves the recorded op as it was
   d.tile = tile; d.splitk = splitk;
   if (workspace) d.workspace = workspace;
   GN_REQUIRE(gn_gemm_workspace_bytes(&d) == 0 || d.workspace, "gn_program_set_gemm_plan: this plan splits K and needs a workspace");
+  // the fusions attached to the op must survive the new plan (gn_launch_gemm would refuse it at replay, possibly in the middle of a hipGraph capture):
+  // norm_out lives in the split-K reduce, norm_in in the ring tiles, the plan must name the tile that will run
+  GN_REQUIRE(gn_gemm_plan_valid(&d), "gn_program_set_gemm_plan: tile %d / splitk %d refused for op %ld: %s", tile, splitk, (long)op, gn_last_error());
   p->ops[(size_t)op].gemm = d;
   return GN_OK;
 }

@@ -48,6 +48,19 @@ void gn_set_error(const char* fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// "done once per DEVICE" flags for per-function attributes (hipFuncSetAttribute applies to the current device's copy of the code object: a
+// process-wide bool would leave a second device without the attribute -- ADVICE r5).  One slot array per call site.
+struct GnOncePerDevice {
+  bool done[64] = {};
+  bool first() {  // true the first time the current device asks
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    if (done[dev]) return false;
+    done[dev] = true;
+    return true;
+  }
+};
+
 // ---- device math ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -106,6 +119,7 @@ __device__ __forceinline__ int lds_swz(int row, int chunk) {
 
 // internal launchers (defined in the .hip files; take validated public descriptors)
 int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d);
+int32_t gn_ppp_pool_init(int device);  // gemm_ppp.hip: the zero-initialised hand-off flag pool of a device (allocated with the first context)
 int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d);
 int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d);
 int32_t gn_launch_tblock(gn_ctx* ctx, const gn_tblock_desc* d);

@@ -821,8 +821,12 @@ constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, fa
                         {128, 160, 0.0, false, true},
                         // 2-stage 128x320 on EIGHT waves of 32x160 (round 5): the wave tile of the 128x160 tile with all of N = 320 in one workgroup --
                         // the A tile is staged once for both column halves (10.9 instead of 14 LDS-DMA bytes per kFLOP), one workgroup per CU
-                        {128, 320, 0.0, false, true}};
-constexpr int kNumCfg = 24;
+                        {128, 320, 0.0, false, true},
+                        // persistent skewed ping-pong 256x256 (gemm_ppp.hip, round 6): one workgroup per CU walks the tile list; the next tile's ring is
+                        // requested before the finished tile's epilogue, tile boundaries are skewed over the chip, the last partial round is split along K
+                        {256, 256, 0.0, false, true}};
+constexpr int kNumCfg = 25;
+constexpr int kCfgPPP = 24;
 constexpr int kCfgS3End = 22;  // one past the last 3-stage configuration
 constexpr int kCfgPP = 14;
 constexpr int kCfgS3 = 15;  // first of the four 3-stage configurations
@@ -832,6 +836,39 @@ bool pp_eligible(const gn_gemm_desc* d) {
   if (d->act == GN_ACT_GEGLU || (d->batch > 1 && !d->up_phases) || d->fp8 || d->K % 64 != 0) return false;
   if (d->conv && (d->C1 % 64 != 0 || d->C2 % 64 != 0)) return false;
   return true;
+}
+
+// workgroups of the persistent kernel = CUs of the current device (256 on MI355X; also the answer where no device is visible: cross-compiling hosts)
+int ppp_workgroups() {
+  static int ncu[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!ncu[dev]) {
+    int v = 0;
+    ncu[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? (v > 256 ? 256 : v) : 256;
+  }
+  return ncu[dev];
+}
+int64_t ppp_tiles(const gn_gemm_desc* d) { return cdiv64(d->M, 256) * cdiv64(d->N, 256) * (d->up_phases ? 4 : 1); }
+// the persistent skewed ping-pong kernel's restrictions on top of pp_eligible (gemm_ppp.hip header)
+bool ppp_eligible(const gn_gemm_desc* d) {
+  if (!pp_eligible(d) || d->out_mode != GN_OUT_ROWMAJOR || d->out2 || d->ln_c1 || d->sink.stats || d->norm_in.stats || d->norm_out.y) return false;
+  if (d->splitk > 1 || (d->shift && d->residual) || d->k_append || d->a2) return false;
+  // whole tiles only: no row mask in the loaders, the R part of an address is the buffer instruction's scalar offset
+  if (d->M % 256 != 0 || d->N % 256 != 0 || d->K < 4 * 64) return false;
+  if (d->ldo % 8 != 0 || ((uintptr_t)d->out & 15) != 0 || (d->out_row_width && d->ldo_hi % 8 != 0)) return false;
+  if (d->residual && (d->ldr % 8 != 0 || ((uintptr_t)d->residual & 15) != 0)) return false;
+  if (d->shift && ((d->ldshift > 0 ? d->ldshift : d->N) % 8 != 0 || ((uintptr_t)d->shift & 15) != 0 || d->rows_per_batch <= 0)) return false;
+  if (d->bias && ((uintptr_t)d->bias & 7) != 0) return false;
+  if (d->ldw >= (1 << 22) || (!d->conv && d->lda >= (1 << 22))) return false;  // 192 rows x the row pitch in bytes as a 32-bit scalar offset
+  if (d->conv) {
+    // a tile lies inside one sample and a lane's four rows are (oy_s + r0 / Wo, ox_s + r0 % Wo) with scalar (oy_s, ox_s) -- gemm_ppp.hip
+    const int64_t hw = (int64_t)d->Ho * d->Wo;
+    if (hw % 256 != 0 || !(d->Wo % 64 == 0 || 64 % d->Wo == 0)) return false;
+    if (d->Ho * d->stride + 4 >= (1 << 15) || d->Wo * d->stride + 4 >= (1 << 15)) return false;  // packed 16-bit tap origins
+  }
+  const int64_t tiles = ppp_tiles(d);
+  return tiles >= ppp_workgroups() && tiles < (1 << 24);
 }
 
 // buffer-descriptor extents of the LDS-DMA variant (32-bit byte offsets; kOOB must stay out of range)
@@ -894,15 +931,15 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
   if (geglu && !kCfg[best].geglu) best = 1;
   if (d->ln_c1) {  // LayerNorm fold: the LDS-DMA kernels (two-stage and ring) carry it
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22, 23};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22, 23, 6};
     best = to_dma[best];
   }
   if (d->k_append && !kCfg[best].dma) {  // the appended segment lives in the LDS-DMA loaders
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
     best = to_dma[best];
   }
   if (d->norm_in.stats) {  // the normalising A path lives in the ring kernels (gemm_s3.hip): 15 .. 21 = {128x128, 128x64, 64x64, 256x64, 128x160, 64x160, 64x320}
-    static const int to_s3[kNumCfg] = {18, 15, 16, 17, 18, 15, 15, 18, 15, 16, 17, 18, 19, 19, 15, 15, 16, 17, 18, 19, 20, 21, 19, 19};
+    static const int to_s3[kNumCfg] = {18, 15, 16, 17, 18, 15, 15, 18, 15, 16, 17, 18, 19, 19, 15, 15, 16, 17, 18, 19, 20, 21, 19, 19, 15};
     best = to_s3[best];
     // a row tile spans whole samples or lies inside one (the kernel's scale / shift table covers <= 4 of them)
     const int64_t rps = d->conv ? (int64_t)d->Ho * d->Wo : d->norm_in.rows_per_sample;
@@ -912,9 +949,10 @@ Plan plan_gemm(const gn_gemm_desc* d) {
     auto lds_bytes = [&](int c) { return (int64_t)3 * (kCfg[c].bm + kCfg[c].bn) * 128 + (rps >= kCfg[c].bm ? 1 : kCfg[c].bm / (rps > 0 ? rps : 1)) * ct * 8; };
     if (lds_bytes(best) > 160 * 1024) best = 17;
   }
+  if (best == kCfgPPP && !ppp_eligible(d)) best = kCfgPP;
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
-    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1, 1};
+    static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1, 1, 0};
     best = fallback[best];
   }
   {  // audit aid: GN_GEMM_LOG_FALLBACK=1 reports every launch whose requested tile (the tune table's) is not the tile that runs
@@ -942,7 +980,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
       if (sk < 1) sk = 1;
     }
   }
-  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8 || d->out2 || d->ln_c1) sk = 1;
+  if (d->act == GN_ACT_GEGLU || d->out_mode == GN_OUT_BATCH_TRANSPOSED || d->batch > 1 || d->fp8 || d->out2 || d->ln_c1 || best == kCfgPPP) sk = 1;
   int kper = (int)(cdiv64(cdiv64(K, sk), BK) * BK);
   sk = (int)cdiv64(K, kper);
   pl.splitk = sk;
@@ -993,9 +1031,32 @@ extern "C" int32_t gn_gemm_norm_out_supported(const gn_gemm_desc* d) {
   return plan_gemm(d).splitk > 1 ? 1 : 0;  // the plan (d->tile / d->splitk) must split K: the fusion lives in the reduce launch
 }
 
+// Does the plan named in d (tile / splitk) carry the fusions attached to d?  gn_launch_gemm refuses such a launch with the same tests; callers that
+// CHANGE a recorded op's plan (gn_program_set_gemm_plan, the in-call tuner) ask here first.  0 = no (gn_last_error says why).
+extern "C" int32_t gn_gemm_plan_valid(const gn_gemm_desc* d) {
+  if (!d) { gn_set_error("gn_gemm_plan_valid: null descriptor"); return 0; }
+  const Plan pl = plan_gemm(d);
+  if (d->norm_out.y && !gn_gemm_norm_out_supported(d)) {
+    gn_set_error("norm_out lives in the split-K reduce: the plan (tile %d -> %d, splitk %d -> %d) does not split K or the problem is unsupported", d->tile, pl.cfg + 1, d->splitk, pl.splitk);
+    return 0;
+  }
+  if (d->norm_in.stats) {
+    if (!gn_gemm_norm_in_supported(d) || !d->norm_in.gamma || !d->norm_in.beta) { gn_set_error("norm_in: unsupported problem (gn_gemm_norm_in_supported) or missing gamma / beta"); return 0; }
+    if (!(pl.cfg >= kCfgS3 && pl.cfg < kCfgS3End)) { gn_set_error("norm_in: the plan must be a ring tile (16 .. 22), tile %d runs", pl.cfg + 1); return 0; }
+    const int64_t rps = d->conv ? (int64_t)d->Ho * d->Wo : d->norm_in.rows_per_sample;
+    if (pl.bm > 4 * rps) { gn_set_error("norm_in: a %d-row tile would span more than 4 samples of %ld rows", pl.bm, (long)rps); return 0; }
+  }
+  return 1;
+}
+
 extern "C" int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d) {
   if (!d) return 0;
   Plan pl = plan_gemm(d);
+  if (pl.cfg == kCfgPPP) {  // hand-off slabs of the tiles whose K range several workgroups share (gemm_ppp.hip)
+    GemmParams p = {};
+    p.K = (int)d->K;
+    return (int64_t)gn_ppp_plan(&p, (int)ppp_tiles(d), ppp_workgroups()) * 256 * 256 * (int64_t)sizeof(float);
+  }
   if (pl.splitk <= 1) return 0;
   return (int64_t)pl.splitk * d->M * d->N * (int64_t)sizeof(float);
 }
@@ -1146,7 +1207,7 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     p.sa = (const float*)d->scale_a; p.sw = (const float*)d->scale_w;
     p.a_bytes = (unsigned)((uint64_t)d->M * d->lda); p.w_bytes = (unsigned)((uint64_t)d->N * d->ldw);
     p.splitk = 1; p.kper = (int)d->K;
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11, 8, 9, 9, 8, 8};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 8, 7, 6, 8, 9, 10, 11, 8, 9, 9, 8, 8, 6};
     const int cfg = to_dma[pl.cfg];
     const int bm = kCfg[cfg].bm, bn = kCfg[cfg].bn;
     p.tiles_m = (int)cdiv64(d->M, bm); p.tiles_n = (int)cdiv64(d->N, bn);
@@ -1178,6 +1239,13 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
     case 12: launch_dma<128, 320, 2, 2>(p, conv, ctx->stream); break;
     case 13: launch_dma<256, 320, 4, 2>(p, conv, ctx->stream); break;
     case 14: gn_launch_gemm_pp(&p, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;
+    case kCfgPPP: {
+      GN_REQUIRE(d->workspace, "gn_gemm: tile 25 (persistent ping-pong) needs a workspace of gn_gemm_workspace_bytes()");
+      (void)gn_ppp_plan(&p, (int)ppp_tiles(d), ppp_workgroups());
+      GN_REQUIRE(gn_ppp_pool_init(ctx->device) == GN_OK, "gn_gemm: tile 25 could not allocate its flag pool (first use inside a stream capture?): %s", gn_last_error());
+      gn_launch_gemm_ppp(&p, conv, ctx->stream);
+      break;
+    }
     case 22: launch_dma<128, 160, 4, 1>(p, conv, ctx->stream); break;
     case 23: launch_dma<128, 320, 4, 2>(p, conv, ctx->stream); break;
     default: gn_launch_gemm_s3(&p, pl.cfg - kCfgS3, conv, p.tiles_m * p.tiles_n, p.splitk, p.nbatch > 0 ? p.nbatch : 1, ctx->stream); break;
@@ -1186,11 +1254,8 @@ int32_t gn_launch_gemm(gn_ctx* ctx, const gn_gemm_desc* d) {
   if (pl.splitk > 1) {
     const long total = (long)p.M * (p.N >> 2);
     if (p.nout.y) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        GN_HIP(hipFuncSetAttribute((const void*)splitk_reduce_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgnMaxSlab));
-        attr_set = true;
-      }
+      static GnOncePerDevice attr_set;
+      if (attr_set.first()) GN_HIP(hipFuncSetAttribute((const void*)splitk_reduce_gn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRgnMaxSlab));
       const int cpg = p.N / p.nout.groups;
       hipLaunchKernelGGL(splitk_reduce_gn_kernel, dim3((unsigned)p.nout.groups, (unsigned)(p.M / p.nout.rps)), dim3(RGN_THREADS),
                          (size_t)p.nout.rps * (cpg / 4) * 8, ctx->stream, p);

@@ -50,6 +50,11 @@ struct GemmParams {
   struct NormOutP { f16* y; const f16* gamma; const f16* beta; float eps; int groups, act, rps; } nout;  // GroupNorm inside the split-K reduce (gemm.hip)
   GnSinkP sink;                          // GroupNorm bridge, producer side (gn_bridge.h): stats == nullptr = off
   GnInP gin;                             // GroupNorm bridge, consumer side (gemm_s3.hip's normalising A path): stats == nullptr = off
+  // persistent skewed ping-pong kernel (gemm_ppp.hip, tile 25): the grid is ppG workgroups (one per CU) that walk the tile list; `ws` holds the f32
+  // hand-off slabs of the tiles whose K range two (or more) workgroups share, ppflags their ready words (zero between launches: the consumer resets them)
+  unsigned* ppflags;
+  unsigned* pptmo;                       // counts bounded hand-off waits that gave up (gn_ppp_timeouts)
+  int ppG, ppR, ppTail, ppS, ppNz, ppSkew;  // workgroups, full rounds, tiles of the last partial round, workgroups per such tile, blockIdx.z extent folded in, skew on
 };
 
 // GroupNorm bridge, producer side (gn_bridge.h).  Where the workgroup's LDS can hold its f16 output tile, the epilogue's 16-byte row stores
@@ -704,5 +709,8 @@ constexpr unsigned kOOB = 0xFFFFFFF0u;  // out-of-range buffer offset: the hardw
 
 // the ping-pong 256x256 kernel lives in its own translation unit (gemm_pp.hip); `params` is a GemmParams
 void gn_launch_gemm_pp(const void* params, bool conv, int grid_x, int grid_y, int grid_z, hipStream_t st);
+// the persistent skewed ping-pong kernel (gemm_ppp.hip); the plan fields pp* of `params` are filled by gn_ppp_plan
+void gn_launch_gemm_ppp(const void* params, bool conv, hipStream_t st);
+int gn_ppp_plan(void* params, int tiles, int G);  // fills the pp* plan fields -> hand-off slabs (of 256 KB) the launch may use
 // the 3-stage ring variants (gemm_s3.hip); cfg 0..3 = {128x128, 128x64, 64x64, 256x64}
 void gn_launch_gemm_s3(const void* params, int cfg, bool conv, int grid_x, int grid_y, int grid_z, hipStream_t st);

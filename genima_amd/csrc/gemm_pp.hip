@@ -24,7 +24,8 @@ namespace {
 constexpr int PP_STAGE = 65536;  // bytes per LDS stage: A tile 256 x 128 B, then W tile 256 x 128 B
 constexpr int PP_HALF = 16384;   // one half-tile (128 rows)
 
-// ABL (tools/bench_gemm_pp.py, env GN_PP_ABL): 0 = the kernel; ablations that say what bounds the K loop (results are wrong):
+// ABL: 0 = the kernel (the only instantiation of a normal build).  Probe builds (-DGN_PP_ABLATIONS, env GN_PP_ABL, tools/probes/gemm_pp_abl.py)
+// add ablations that say what bounds the K loop (results are wrong):
 //   1 no DMA, 2 no fragment reads, 3 no MFMA, 4 no s_setprio, 5 no barriers, 6 no epilogue
 template <bool CONV, int ABL>
 __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams pin) {
@@ -351,15 +352,19 @@ __global__ __launch_bounds__(512) void gemm_pp_kernel(const GemmParams pin) {
 void gn_launch_gemm_pp(const void* params, bool conv, int grid_x, int grid_y, int grid_z, hipStream_t st) {
   const GemmParams& p = *static_cast<const GemmParams*>(params);
   const dim3 grid(grid_x, grid_y, grid_z);
-  static const int abl = [] { const char* e = getenv("GN_PP_ABL"); return e ? atoi(e) : 0; }();  // ablation builds (timing only)
+#ifdef GN_PP_ABLATIONS  // probe builds only (GN_HIPCC_EXTRA=-DGN_PP_ABLATIONS, tools/probes/gemm_pp_abl.py): the ablated variants give wrong results
+  static const int abl = [] { const char* e = getenv("GN_PP_ABL"); return e ? atoi(e) : 0; }();
   switch (abl) {
 #define GN_PP_CASE(A)                                                                                  \
   case A:                                                                                              \
     if (conv) hipLaunchKernelGGL((gemm_pp_kernel<true, A>), grid, dim3(512), 0, st, p);               \
     else hipLaunchKernelGGL((gemm_pp_kernel<false, A>), grid, dim3(512), 0, st, p);                    \
-    break;
+    return;
     GN_PP_CASE(1) GN_PP_CASE(2) GN_PP_CASE(3) GN_PP_CASE(4) GN_PP_CASE(5) GN_PP_CASE(6)
-    default: GN_PP_CASE(0)
+    default: break;
 #undef GN_PP_CASE
   }
+#endif
+  if (conv) hipLaunchKernelGGL((gemm_pp_kernel<true, 0>), grid, dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((gemm_pp_kernel<false, 0>), grid, dim3(512), 0, st, p);
 }

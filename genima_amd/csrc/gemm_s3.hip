@@ -394,11 +394,9 @@ void launch_s3_gna(const GemmParams& p, dim3 grid, hipStream_t st) {
   const int S = rps_out >= BM ? 1 : BM / rps_out;
   const int Ct = CONV ? (p.kapp ? p.C1 : p.C1 + p.C2) : (p.kapp ? p.kapp_k0 : p.K);
   const size_t bytes = (size_t)3 * (BM + BN) * 128 + (size_t)S * Ct * sizeof(float2);
-  static bool attr_set = false;  // (per instantiation)
-  if (!attr_set) {
+  static GnOncePerDevice attr_set;  // (per instantiation and device)
+  if (attr_set.first())
     (void)hipFuncSetAttribute((const void*)gemm_s3_kernel<BM, BN, WM, WN, CONV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
   hipLaunchKernelGGL((gemm_s3_kernel<BM, BN, WM, WN, CONV, false, true>), grid, dim3(WM * WN * 64), bytes, st, p);
 }
 

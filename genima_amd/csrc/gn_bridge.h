@@ -27,8 +27,11 @@ __host__ __device__ __forceinline__ GnSinkP gn_sink_params(const gn_stats_sink& 
 // the 128-byte line of (replica, sample, group)
 __device__ __forceinline__ long gn_stats_line(int rep, int b, int g, int nb, int groups) { return (((long)rep * nb + b) * groups + g) * GN_STATS_LINE; }
 
-__device__ __forceinline__ unsigned long long gn_fixed(float s) {
-  double d = (double)s * 16777216.0;  // 2^GN_STATS_SHIFT
+// Fixed point: the SUM word carries 2^GN_STATS_SHIFT (24), the SUM-OF-SQUARES word 2^GN_STATS_SHIFT_SQ (12).  The coarser scale of the second word is its
+// range: a (sample, group) slab's sum of squares may reach 2.2e15 before the int64 wraps (2^24 wrapped silently at 5.5e11 -- a few hundred f16 values near
+// 65504); its quantum of 2.4e-4 per contribution is far below a variance's resolution.  Each contribution is clamped as well.
+__device__ __forceinline__ unsigned long long gn_fixed(float s, double scale) {
+  double d = (double)s * scale;
   d = fmin(fmax(d, -4.6e18), 4.6e18);
   return (unsigned long long)__double2ll_rn(d);  // two's complement: the unsigned atomic add IS the signed add
 }
@@ -36,8 +39,8 @@ __device__ __forceinline__ void gn_stats_add(unsigned long long* slot, float sum
 #ifdef GN_SINK_NO_ATOMICS
   return;
 #endif
-  (void)__hip_atomic_fetch_add(slot, gn_fixed(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  (void)__hip_atomic_fetch_add(slot + 1, gn_fixed(sumsq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_fetch_add(slot, gn_fixed(sum, (double)(1ll << GN_STATS_SHIFT)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  (void)__hip_atomic_fetch_add(slot + 1, gn_fixed(sumsq, (double)(1ll << GN_STATS_SHIFT_SQ)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // (mean, rstd) of group g of sample b; inv_count = 1 / (elements of a (sample, group) slab).  f64 like gn_finalize_kernel (norm.hip).
@@ -58,8 +61,8 @@ __device__ __forceinline__ void gn_group_mean_rstd(const long long* stats, int b
 #pragma unroll
     for (int u = 0; u < 8; ++u) { s0 += v0[u]; s1 += v1[u]; }  // integer adds: the replicas' order does not matter
   }
-  const double m = (double)s0 * (1.0 / 16777216.0) * inv_count;
-  double var = (double)s1 * (1.0 / 16777216.0) * inv_count - m * m;
+  const double m = (double)s0 * (1.0 / (double)(1ll << GN_STATS_SHIFT)) * inv_count;
+  double var = (double)s1 * (1.0 / (double)(1ll << GN_STATS_SHIFT_SQ)) * inv_count - m * m;
   if (var < 0.0) var = 0.0;
   mean = (float)m;
   rstd = (float)(1.0 / sqrt(var + (double)eps));

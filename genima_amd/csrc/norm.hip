@@ -423,9 +423,9 @@ int32_t gn_launch_groupnorm(gn_ctx* ctx, const gn_groupnorm_desc* d) {
       const char* e = getenv("GN_GROUPNORM_FUSED");  // 0 = off; N > 1 = slab limit in KB (tuning aid)
       fused_ok = (e && e[0] == '0') ? 0 : 1;
       if (e && atoi(e) > 1) fused_max = (long)atoi(e) * 1024;
-      if (fused_ok)
-        GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_max));
     }
+    static GnOncePerDevice fused_attr;  // the attribute is per device
+    if (fused_ok && fused_attr.first()) GN_HIP(hipFuncSetAttribute((const void*)gn_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused_max));
     const long slab = (long)d->HW * p.cpg * 2;
     // few (batch, group) slabs leave most CUs idle -- unless the whole tensor is so small that the call is latency-bound anyway
     // (batch 1: 32 slabs; one launch of ~6 us instead of three)

@@ -224,7 +224,17 @@ class Engine:
         if t is None or tuple(t.shape) != shape or t.dtype != dtype:
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self.buffers[key] = t
+        self._wrote(t)  # whoever asks for an output buffer is about to write it
         return t
+
+    def _wrote(self, *ts):
+        """A recorded op is about to (over)write these tensors: forget who wrote them before -- a GroupNorm recorded later must not fuse into (or take
+        statistics from) a producer whose output has been replaced since.  buf() calls it for every buffer it hands out; ops that take an
+        explicit ``out=`` / work in place call it themselves."""
+        if self._writer:
+            for t in ts:
+                if t is not None:
+                    self._writer.pop(t.data_ptr(), None)
 
     def _keepalive(self, *ts):
         if self.record:
@@ -278,7 +288,7 @@ class Engine:
     # change the per-element summation order (K is walked identically), only split-K does, and split-K is a deterministic
     # function of (shape, tile).  The table measured on MI355X ships as genima_amd/gemm_tune_gfx950.json.
     _retuned = set()  # shapes already re-raced in this process (GN_RETUNE)
-    N_TILE_CFGS = 24  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..22 3-stage ring, 23 2-stage 128x160, 24 2-stage 128x320 on 8 waves (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip)
+    N_TILE_CFGS = 25  # 1..6 register-staged, 7..14 LDS-DMA, 15 ping-pong 256x256, 16..22 3-stage ring, 23 2-stage 128x160, 24 2-stage 128x320 on 8 waves, 25 persistent skewed ping-pong (csrc/gemm.hip kCfg, gemm_pp.hip, gemm_s3.hip, gemm_ppp.hip)
 
     @staticmethod
     def _tune_key(d: GemmDesc) -> str:
@@ -301,6 +311,16 @@ class Engine:
         return key
 
     @staticmethod
+    def _ppp_candidate(d: GemmDesc) -> bool:
+        """Is the persistent skewed ping-pong tile (25, csrc/gemm_ppp.hip) worth racing?  (The library decides eligibility; this only keeps shapes it
+        would map back onto tile 15 out of the race.)"""
+        if d.M % 256 or d.N % 256 or d.K % 64 or d.K < 256 or d.act == ACT_GEGLU or d.out_mode != OUT_ROWMAJOR or d.out2 or d.ln_c1 or d.fp8 or d.k_append or d.a2:
+            return False
+        if d.batch > 1 and not d.up_phases:
+            return False
+        return (d.M // 256) * (d.N // 256) * (4 if d.up_phases else 1) >= 256
+
+    @staticmethod
     def apply_plan(d: GemmDesc, plan: int):
         """A tune-table value is ``tile + 100 * splitk`` (splitk 0 = the library's heuristic for that tile)."""
         d.tile, d.splitk = int(plan) % 100, int(plan) // 100
@@ -316,10 +336,12 @@ class Engine:
         if key in table:
             self._retuned.add(key)
             cands = [table[key]] + [c for c in challengers if c != table[key] % 100 and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19))]
+        if not self._ppp_candidate(d):  # tile 25 needs whole 256 x 256 tiles, at least one per CU (the library would run tile 15 instead: no second race of it)
+            cands = [c for c in cands if c % 100 != 25]
         if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         if d.ln_c1:  # the LayerNorm fold lives in the LDS-DMA kernels (the library maps the other tiles onto them)
-            cands = [c for c in cands if c % 100 >= 7 and c % 100 != 15]
+            cands = [c for c in cands if c % 100 >= 7 and c % 100 not in (15, 25)]
         if d.k_append:  # so does the appended 1x1 segment
             cands = [c for c in cands if c % 100 >= 7]
         if d.norm_in.stats:  # the normalising A path lives in the ring kernels; a row tile spans at most four samples
@@ -389,7 +411,8 @@ class Engine:
                     and not d.out_row_width or d.up_phases):
                 # the op that wrote this tensor: a GroupNorm recorded later may move into its reduce (norm_out) or take its statistics (bridge)
                 # (a phase conv launch writes the whole upsampled tensor: 4 phases x M rows)
-                self._writer[int(d.out)] = _Writer(self.num_ops, 0, int(d.M) * int(d.N) * (4 if d.up_phases else 1), 4 if d.up_phases else 1, gemm=True)
+                if d.up_phases or int(d.ldo) == int(d.N):  # a dense tensor (a slice of a wider buffer is not what a GroupNorm reads)
+                    self._writer[int(d.out)] = _Writer(self.num_ops, 0, int(d.M) * int(d.N) * (4 if d.up_phases else 1), 4 if d.up_phases else 1, gemm=True)
             check(self.lib.gn_program_add_gemm(self._prog, C.byref(d)), "gn_program_add_gemm")
             self._keepalive(*keep, ws)
             kind = (f"conv{d.KH}x{d.KW}" if d.conv else "linear")
@@ -719,6 +742,8 @@ class Engine:
         n_out = N // 2 if act == ACT_GEGLU else N
         if out is None:
             out = self.buf(name, tuple(xq.shape[:-1]) + (n_out,))
+        else:
+            self._wrote(out)
         d = GemmDesc()
         d.a, d.w, d.bias, d.residual, d.out = _ptr(xq), _ptr(wq), _ptr(bias), _ptr(residual), _ptr(out)
         d.M, d.N, d.K = M, N, Kp
@@ -761,6 +786,8 @@ class Engine:
         Wo = (Win + pad[1] + pad[3] - k) // stride + 1
         if out is None:
             out = self.buf(name, (B, Ho, Wo, N))
+        else:
+            self._wrote(out)
         d = GemmDesc()
         d.a, d.a2, d.w, d.bias, d.shift, d.residual, d.out = (_ptr(x), _ptr(x2), _ptr(w), _ptr(bias), _ptr(shift),
                                                               _ptr(residual), _ptr(out))
@@ -860,6 +887,8 @@ class Engine:
         Nk = k.shape[1] if Nk is None else Nk
         if out is None:
             out = self.buf(name, (B, Nq, Cq))
+        else:
+            self._wrote(out)
         d = AttnDesc()
         d.q, d.k, d.vt, d.o = _ptr(q), _ptr(k), _ptr(vt), _ptr(out)
         d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q.stride(0), k.stride(0), vt.stride(0), out.stride(0)
@@ -898,6 +927,8 @@ class Engine:
               "gn_attention_fp8_quantize")
         if out is None:
             out = self.buf(name, (B, Nq, Cq))
+        else:
+            self._wrote(out)
         d = AttnDesc()
         d.q, d.k, d.vt, d.o = _ptr(q8), _ptr(k8), _ptr(v8t), _ptr(out)
         d.q_bs, d.k_bs, d.vt_bs, d.o_bs = q8.stride(0), k8.stride(0), v8t.stride(0), out.stride(0)
@@ -919,6 +950,8 @@ class Engine:
         C2 = x2.shape[-1] if x2 is not None else 0
         if out is None:
             out = self.buf(name, tuple(x.shape[:-1]) + (C1 + C2,))
+        else:
+            self._wrote(out)
         d = GroupNormDesc()
         d.x, d.x2, d.gamma, d.beta, d.y = _ptr(x), _ptr(x2), _ptr(gamma), _ptr(beta), _ptr(out)
         d.B, d.HW, d.C1, d.C2, d.groups, d.act, d.eps = B, HW, C1, C2, groups, act, eps
@@ -997,6 +1030,8 @@ class Engine:
         assert w.shape[1] == 9 * Cin, (tuple(w.shape), Cin)
         if out is None:
             out = self.buf(name, (B, H, W, N))
+        else:
+            self._wrote(out)
         d = ConvGnDesc()
         d.x, d.scsh, d.w, d.bias, d.residual, d.out = _ptr(x), _ptr(scsh), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out)
         d.ldr, d.ldo = (residual.stride(-2) if residual is not None else 0), out.stride(-2)
@@ -1016,6 +1051,8 @@ class Engine:
         M = x.numel() // Cc
         if out is None:
             out = self.buf(name, x.shape)
+        else:
+            self._wrote(out)
         args = (_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), M, Cc, eps)
         if self.record:
             check(self.lib.gn_program_add_layernorm(self._prog, *args), "gn_program_add_layernorm")
@@ -1048,6 +1085,8 @@ class Engine:
         Cc = x.shape[-1]
         if out is None:
             out = self.buf(name, tuple(x.shape[:-1]) + (cpad,))
+        else:
+            self._wrote(out)
         self._small("scale_pad", (x, out), _ptr(x), _ptr(out), x.numel() // Cc, Cc, cpad, float(scale))
         return out
 
@@ -1058,6 +1097,8 @@ class Engine:
         pixels = x.numel() // x.shape[-1]
         if out is None:
             out = self.buf(name, tuple(x.shape[:-1]) + (cpad,))
+        else:
+            self._wrote(out)
         self._small("scale_cat_pad", (x, x2, out), _ptr(x), _ptr(x2), _ptr(out), pixels, c1, x.stride(-2), c2, x2.stride(-2), cpad,
                     float(scale), float(scale2))
         return out
@@ -1065,6 +1106,7 @@ class Engine:
     def euler_step(self, x: torch.Tensor, eps: torch.Tensor, sigma: float, sigma_next: float):
         """In place: x[..., C] <- x + eps[..., :C] * (sigma_next - sigma)."""
         Cc = x.shape[-1]
+        self._wrote(x)
         self._small("euler_step", (x, eps), _ptr(x), _ptr(eps), x.numel() // Cc, Cc, eps.stride(-2), float(sigma), float(sigma_next))
         return x
 
@@ -1073,6 +1115,8 @@ class Engine:
         out may alias x0."""
         if out is None:
             out = self.buf(name, x0.shape)
+        else:
+            self._wrote(out)
         B = x0.shape[0]
         self._small("add_noise", (x0, noise, sqrt_ac, sqrt_1mac, out), _ptr(x0), _ptr(noise), _ptr(sqrt_ac), _ptr(sqrt_1mac), _ptr(out), B, x0.numel() // B)
         return out
@@ -1081,6 +1125,8 @@ class Engine:
         """uint8 [B, H, W, 3] -> f16 [B, H, W, cpad] = v/255*mul + add (channels >= 3 zero)."""
         if out is None:
             out = self.buf(name, tuple(img.shape[:-1]) + (cpad,))
+        else:
+            self._wrote(out)
         self._small("image_u8_to_f16", (img, out), _ptr(img), _ptr(out), img.numel() // 3, cpad, float(mul), float(add))
         return out
 
@@ -1088,12 +1134,16 @@ class Engine:
         """f16 [B, H, W, ld>=3] -> uint8 [B, H, W, 3] (VaeImageProcessor.postprocess numerics)."""
         if out is None:
             out = self.buf(name, tuple(x.shape[:-1]) + (3,), dtype=torch.uint8)
+        else:
+            self._wrote(out)
         self._small("image_f16_to_u8", (x, out), _ptr(x), _ptr(out), x.numel() // x.shape[-1], x.stride(-2))
         return out
 
     def add(self, a: torch.Tensor, b: torch.Tensor, *, out=None, name=None):
         if out is None:
             out = self.buf(name, a.shape)
+        else:
+            self._wrote(out)
         self._small("add", (a, b, out), _ptr(a), _ptr(b), _ptr(out), a.numel())
         return out
 
@@ -1132,6 +1182,8 @@ class Engine:
     def act(self, x: torch.Tensor, act: int, *, out=None, name=None):
         if out is None:
             out = self.buf(name, x.shape)
+        else:
+            self._wrote(out)
         self._small("act", (x, out), _ptr(x), _ptr(out), x.numel(), act)
         return out
 
@@ -1143,6 +1195,8 @@ class Engine:
         assert gamma.stride(0) == beta.stride(0) and gamma.stride(-1) == 1 and rows % rows_per_film == 0
         if out is None:
             out = self.buf(name, x.shape)
+        else:
+            self._wrote(out)
         self._small("film", (x, gamma, beta, out), _ptr(x), _ptr(out), _ptr(gamma), _ptr(beta), gamma.stride(0), rows_per_film, rows, Cc, act)
         return out
 
@@ -1188,6 +1242,7 @@ class Engine:
         """dst[i0*os0 + i1*os1 + i2*os2 + i3*os3 + :L] = src[i0*is0 + ... + :L] over the 4-D index space ``sizes`` (f16 elements)."""
         arr = (C.c_int64 * 4)
         s, i, o = arr(*sizes), arr(*in_strides), arr(*out_strides)
+        self._wrote(dst)
         self._small("copy4d", (src, dst), _ptr(src), _ptr(dst), s, i, o, L)
         return dst
 

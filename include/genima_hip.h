@@ -57,11 +57,13 @@ int32_t gn_ctx_set_stream(gn_ctx* ctx, void* stream);
  * controller/agent/sd_controlnet_agent.py:67-76): as separate launches every GroupNorm is a dependent pass over the tensor between two GEMMs.
  * Here the op that WRITES the tensor also adds its per-(sample, group) sum and sum of squares -- of the f16 values it stored -- into a
  * caller-zeroed statistics block (gn_stats_sink), and the op that READS it normalises its A operand on the way into the MFMA (gn_norm_in), or a
- * single coalesced apply pass does (gn_groupnorm_desc.stats_in).  Sums are fixed point (value * 2^GN_STATS_SHIFT, int64, device-scope integer
- * atomics): integer addition is order-independent, so the statistics -- and everything downstream -- are bit-reproducible run to run. */
+ * single coalesced apply pass does (gn_groupnorm_desc.stats_in).  Sums are fixed point (sum * 2^GN_STATS_SHIFT, sum of squares * 2^GN_STATS_SHIFT_SQ,
+ * int64, device-scope integer atomics): integer addition is order-independent, so the statistics -- and everything downstream -- are
+ * bit-reproducible run to run.  The second word's coarser scale is range: a slab's sum of squares may reach 2.2e15 before the word wraps. */
 #define GN_STATS_SHIFT 24
+#define GN_STATS_SHIFT_SQ 12
 /* The statistics block: int64 [replicas][samples][groups][GN_STATS_LINE] -- one 128-byte line per (replica, sample, group) holding
- * (sum, sum of squares) * 2^GN_STATS_SHIFT in its first two words, ZEROED by the caller before the producers run.  Device-scope atomics
+ * (sum * 2^GN_STATS_SHIFT, sum of squares * 2^GN_STATS_SHIFT_SQ) in its first two words, ZEROED by the caller before the producers run.  Device-scope atomics
  * serialise per memory line (measured on MI355X: ~100 ns each; 2 240 adds onto the 8 lines of a packed 1 x 32 x 2 block cost a 28 us conv
  * another 30 us), hence a line per group, and `replicas` > 1 where few samples leave few lines: a producer workgroup adds into replica
  * (its row-tile index % replicas), the consumer sums the replicas (integer adds: any order, same bits). */
@@ -127,7 +129,12 @@ typedef struct gn_gemm_desc {
                              15 = 256x256 ping-pong (8-phase, counted vmcnt; K % 64 == 0, conv C1/C2 % 64 == 0, no GEGLU / batch),
                              16..22 = {128x128, 128x64, 64x64, 256x64, 128x160, 64x160, 64x320} with a 3-stage LDS-DMA ring (two K tiles
                              in flight, counted vmcnt); 20..22 are the exact-fit tiles of the N = 640 / 1280 / 320 launches,
-                             23 = 128x160 two-stage LDS-DMA, 24 = 128x320 two-stage LDS-DMA on eight waves of 32x160
+                             23 = 128x160 two-stage LDS-DMA, 24 = 128x320 two-stage LDS-DMA on eight waves of 32x160,
+                             25 = PERSISTENT skewed ping-pong 256x256 (round 6, csrc/gemm_ppp.hip): one workgroup per CU walks the tile list, the next
+                             tile's LDS ring is requested before the finished tile's epilogue, tile boundaries are skewed over the chip, the last
+                             partial round is split along K; needs >= one 256x256 tile per CU, a row-major f16 output with N, ldo % 8 == 0, no
+                             split-K / out2 / ln_c1 / GEGLU / shift + residual together (else tile 15 runs), and a workspace of
+                             gn_gemm_workspace_bytes() for the f32 hand-off slabs of the tiles two workgroups share
                              (the host autotunes this per shape: genima_amd/engine.py) */
   int32_t residual_before_act; /* 1: v = act(acc + bias + shift + residual) (ResNet basic block); 0: residual added last */
   float out_scale;        /* 1.0f = none */
@@ -195,6 +202,16 @@ typedef struct gn_gemm_desc {
 int32_t gn_gemm_norm_in_supported(const gn_gemm_desc* d);
 int32_t gn_gemm_norm_out_supported(const gn_gemm_desc* d); /* the problem AND its plan (tile / splitk as set in d) take norm_out */
 int64_t gn_gemm_workspace_bytes(const gn_gemm_desc* d);
+/* 1 when the plan named in d (tile / splitk) carries the fusions attached to d -- norm_out needs a plan that splits K, norm_in a ring tile whose
+ * rows span at most 4 samples -- i.e. when gn_gemm would not refuse the launch for its plan; 0 otherwise (gn_last_error says why).
+ * gn_program_set_gemm_plan asks here before it patches a recorded op. */
+int32_t gn_gemm_plan_valid(const gn_gemm_desc* d);
+#define GN_NUM_GEMM_TILES 25
+/* tile 25's in-launch hand-offs wait with a bound; -> how many waits have given up on the current device since the library was loaded (0 in a
+ * healthy process; tests assert it). */
+int64_t gn_ppp_timeouts(void);
+/* probe aid (a library built with -DGN_PPP_PROFILE): per-workgroup cycle sums of the last tile-25 launch, 8 words per workgroup; zeros otherwise */
+int32_t gn_ppp_profile_read(uint32_t* out, int32_t words);
 /* tuning hook: force tile configuration 0..3 = {256x128, 128x128, 128x64, 64x64} for every following gn_gemm; -1 = heuristic */
 int32_t gn_set_gemm_tile_override(int32_t cfg);
 int32_t gn_gemm(gn_ctx* ctx, const gn_gemm_desc* d);

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_loader_binds_and_reports_version():
     lib = _lib.load()
-    assert lib.gn_version() == 100
+    assert lib.gn_version() == 101
     # 8 pointers, 8 int64, 20 int32 + float, batch/batch_inner (+pad to 8), 8 int64 batch strides, accumulate + fp8, 2 scale pointers,
     # out2 + ldo2 + split_n + ln_eps, ln_c1, out_row_width (+pad) + ldo_hi, up_phases (+tail pad)
     base = 8 * 8 + 8 * 8 + 24 * 4 + 8 * 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # ... k_append in up_phases' tail pad, a3, C3 (+pad), lda2

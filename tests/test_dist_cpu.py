@@ -176,7 +176,8 @@ def test_bench_self_launches_its_ranks():
         assert "launching 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr, r.stderr[-2000:]
         assert "AssertionError: --gpus" not in r.stderr
         if script == "bench.py":
-            assert "rank 0 of 2 needs ROCm device 0" in r.stderr and "rank 1 of 2 needs ROCm device 1" in r.stderr, r.stderr[-2000:]
+            # (torchrun tears the sibling down as soon as the first rank exits, so only ONE of the two messages is guaranteed to reach stderr)
+            assert "rank 0 of 2 needs ROCm device 0" in r.stderr or "rank 1 of 2 needs ROCm device 1" in r.stderr, r.stderr[-2000:]
         assert r.returncode != 0
     cmd = gd.self_launch_command("bench.py", ["--gpus", "4"], 4, port=1234)
     assert cmd[1:9] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=4", "--master-addr", "127.0.0.1", "--master-port", "1234"]

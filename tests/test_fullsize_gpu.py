@@ -135,7 +135,46 @@ def test_tiled_sample_through_the_routes_configs2_selects_vs_oracle():
     assert torch.isfinite(eps).all() and max(errs) < 2e-3 and e < 2e-3
     assert e <= 1.2 * er16 + 2e-4 and max(errs) <= 1.2 * max(ref16) + 2e-4
     assert eh16 <= 1.15 * (e ** 2 + er16 ** 2) ** 0.5 and eh16 < 2.5e-3
-    del unet, cn
+    # ---- the same step as a RECORDED program with the two B >= 4 gates of the headline's route opened: GroupNorm inside the split-K
+    # reduce (engine.gn_reduce_fuse_min_slabs: 128 slabs in production = B >= 4, 0 here) and the one-wave-per-SIMD self-attention kernel
+    # (csrc/attention_pwg.hip: >= 256 row blocks in production, forced here) -- both asserted on the route, then held to the same oracle bars
+    from genima_amd import graphs
+    from genima_amd.engine import Engine
+    from genima_amd.host import nchw_to_nhwc, nhwc_to_nchw
+
+    E = Engine("cuda:0", record=True)
+    E.tblock_min_rows = 0
+    E.gn_reduce_fuse_min_slabs = 0
+    assert E.gn_reduce_fuse, "GN_REDUCE_FUSE=0 in the environment: this test needs the default"
+    t_dev = torch.full((1,), 799.0, dtype=torch.float32, device="cuda")
+    x8, cond8 = nchw_to_nhwc(x.half().cuda(), 8), nchw_to_nhwc(cond.half().cuda(), 8)
+    ctx_d = ctx.half().cuda().contiguous()
+    E.lib.gn_attention_set_variant(5)
+    try:
+        with E.scope("cn"):
+            kv_cn = graphs.emit_cross_kv(E, cn.W, ctx_d, "cn")
+            cemb = graphs.emit_controlnet_cond(E, cn.W, cn.config, cond8)
+            down_r, mid_r = graphs.emit_controlnet(E, cn.W, cn.config, x8, t_dev, kv_cn, cemb, 1.0)
+        with E.scope("un"):
+            kv_un = graphs.emit_cross_kv(E, unet.W, ctx_d, "unet")
+            eps_r = graphs.emit_unet(E, unet.W, unet.config, x8, t_dev, kv_un, down_r, mid_r)
+        n_norm_out = sum(1 for m in E.meta if m.get("norm_out"))
+        n_gn = sum(1 for m in E.meta if m.get("kind") == "groupnorm")
+        n_attn = sum(1 for m in E.meta if m.get("kind") == "attention" and tuple(m.get("shape", ()))[2:4] == (4096, 4096))
+        assert n_norm_out >= 20, f"only {n_norm_out} GroupNorms moved into a split-K reduce ({n_gn} stayed launches)"
+        assert n_attn == 7, [m.get("shape") for m in E.meta if m.get("kind") == "attention"]
+        E.run()
+        E.synchronize()
+    finally:
+        E.lib.gn_attention_set_variant(-1)
+    errs_r = [rel_l2(nhwc_to_nchw(a).float().cpu(), b) for a, b in zip(down_r, d32)] + [rel_l2(nhwc_to_nchw(mid_r).float().cpu(), m32)]
+    eps_rc = nhwc_to_nchw(eps_r, unet.config["out_channels"]).float().cpu()
+    e_r = rel_l2(eps_rc, e32)
+    print(f"  recorded program, norm_out x{n_norm_out} + pwg attention x{n_attn}: controlnet residuals rel-L2 max {max(errs_r):.2e}, unet eps {e_r:.2e} vs the "
+          f"fp32 oracle; {rel_l2(eps_rc, eps):.2e} from the eager route")
+    assert torch.isfinite(eps_rc).all() and max(errs_r) < 2e-3 and e_r < 2e-3
+    assert e_r <= 1.2 * er16 + 2e-4 and max(errs_r) <= 1.2 * max(ref16) + 2e-4
+    del unet, cn, E
     torch.cuda.empty_cache()
     # ---- the VAE decode of the tiled latent to 512 x 512: conv3x3_gn (128-channel 512^2 convs + conv_out) and the shortcut blocks
     vsd = weights.round_to(weights.synth_state_dict(schema.vae_schema(vcfg), 23, device="cuda"), torch.float16)

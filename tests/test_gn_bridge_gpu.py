@@ -21,7 +21,7 @@ from util import assert_close, q16, randn_h, rel_l2
 
 pytestmark = pytest.mark.gpu
 
-FIX = float(1 << 24)
+FIX, FIXSQ = float(1 << 24), float(1 << 12)  # GN_STATS_SHIFT / GN_STATS_SHIFT_SQ
 
 
 def _nchw(t):
@@ -35,7 +35,7 @@ def _host_stats(tensors, groups):
     xg = x.reshape(B, -1, groups, C // groups)
     s, q = xg.sum(dim=(1, 3)), (xg * xg).sum(dim=(1, 3))
     out = torch.zeros(1, B, groups, 16, dtype=torch.int64)  # one replica; a 128-byte line per (sample, group): GN_STATS_LINE
-    out[0, :, :, 0], out[0, :, :, 1] = s.mul(FIX).round().to(torch.int64), q.mul(FIX).round().to(torch.int64)
+    out[0, :, :, 0], out[0, :, :, 1] = s.mul(FIX).round().to(torch.int64), q.mul(FIXSQ).round().to(torch.int64)
     return out.cuda()
 
 
@@ -47,10 +47,11 @@ def _stats_close(st, ref, what, n):
     """n = elements of a (sample, group) slab.  The producers sum f32 partials per tile (then exact integer adds): 1e-5 of the slab's sum of
     squares; the plain sums can cancel to ~0, so they are judged against sqrt(n * sumsq) >= |sum|."""
     assert int(st[..., 2:].abs().max()) == 0, "only the first two words of a line are written"
-    a, b = st[..., :2].sum(0).double().cpu() / FIX, ref[..., :2].sum(0).double().cpu() / FIX  # (replicas summed: integer adds)
+    scale = torch.tensor([FIX, FIXSQ], dtype=torch.float64)
+    a, b = st[..., :2].sum(0).double().cpu() / scale, ref[..., :2].sum(0).double().cpu() / scale  # (replicas summed: integer adds)
     tol_s = 1e-5 * (n * b[..., 1].abs()).sqrt() + 1e-3
     assert ((a[..., 0] - b[..., 0]).abs() <= tol_s).all(), (what, float((a[..., 0] - b[..., 0]).abs().max()))
-    assert ((a[..., 1] - b[..., 1]).abs() <= 1e-5 * b[..., 1].abs() + 1e-3).all(), (what, float(((a[..., 1] - b[..., 1]).abs() / b[..., 1].abs().clamp_min(1e-9)).max()))
+    assert ((a[..., 1] - b[..., 1]).abs() <= 1e-5 * b[..., 1].abs() + 5e-2).all(), (what, float(((a[..., 1] - b[..., 1]).abs() / b[..., 1].abs().clamp_min(1e-9)).max()))
 
 
 @pytest.mark.parametrize("tile,splitk", [(0, 0), (2, 1), (8, 1), (9, 1), (10, 1), (13, 1), (15, 1), (16, 1), (17, 1), (18, 1), (21, 1), (22, 1), (23, 1),

@@ -53,6 +53,35 @@ def test_recorded_gemm_plan_can_be_read_back_and_replaced():
     assert E.lib.gn_program_get_gemm(E._prog, n, C.byref(GemmDesc())) != 0           # out of range
 
 
+def test_plan_that_drops_an_attached_fusion_is_refused_and_leaves_the_op_untouched():
+    """gn_program_set_gemm_plan validates the NEW plan against the fusions attached to the op (norm_out lives in the split-K reduce): a
+    plan that no longer splits K is refused with an error text, the recorded op keeps its plan, and the program still replays."""
+    from genima_amd._lib import ACT_SILU
+    from genima_amd.engine import Norm
+    E = Engine("cuda:0", record=True)
+    E.autotune = False
+    x, w, b = randn_h(4, 8, 8, 1280, seed=1), randn_h(1280, 9 * 1280, seed=2, scale=0.01), randn_h(1280, seed=3)
+    gamma, beta = randn_h(1280, seed=4), randn_h(1280, seed=5)
+    h, y = E.conv2d(x, w, b, splitk=4, norm_out=Norm(gamma, beta, 32, 1e-5, ACT_SILU), name="c")
+    ops = [i for i in range(E.num_ops) if E.lib.gn_program_get_gemm(E._prog, i, C.byref(GemmDesc())) == 0]
+    assert len(ops) == 1
+    d0 = GemmDesc()
+    assert E.lib.gn_program_get_gemm(E._prog, ops[0], C.byref(d0)) == 0 and d0.norm_out.y
+    assert E.lib.gn_gemm_plan_valid(C.byref(d0)) == 1
+    E.run(); E.synchronize()
+    y_ref = y.clone()
+    ws = torch.empty(8 * 256 * 1280, dtype=torch.float32, device="cuda")
+    assert E.lib.gn_program_set_gemm_plan(E._prog, ops[0], 9, 1, None) != 0, "a plan without a K split cannot carry norm_out"
+    assert b"norm_out" in E.lib.gn_last_error()
+    d1 = GemmDesc()
+    assert E.lib.gn_program_get_gemm(E._prog, ops[0], C.byref(d1)) == 0
+    assert (d1.tile, d1.splitk) == (d0.tile, d0.splitk), "a refused plan leaves the op as it was"
+    assert E.lib.gn_program_set_gemm_plan(E._prog, ops[0], 18, 8, C.c_void_p(ws.data_ptr())) == 0   # another split plan is fine
+    y.zero_()
+    E.run(); E.synchronize()
+    assert_close(y, y_ref.float(), 1e-3)
+
+
 def test_add_multi_equals_the_single_adds():
     """gn_add_multi: up to 16 independent f16 adds in one launch (the UNet's skip + ControlNet-residual additions), eager and recorded."""
     for record in (False, True):

@@ -1,4 +1,4 @@
-"""Ablation timing of the ping-pong GEMM (env GN_PP_ABL=0..5, csrc/gemm_pp.hip): what bounds the K loop.  Results of ablated
+"""Ablation timing of the ping-pong GEMM (env GN_PP_ABL=0..6, csrc/gemm_pp.hip; needs a probe build: GN_HIPCC_EXTRA=-DGN_PP_ABLATIONS python -m genima_amd.build --force): what bounds the K loop.  Results of ablated
 builds are wrong by construction; only the time is read."""
 import os
 import sys
