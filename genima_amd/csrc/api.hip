@@ -326,7 +326,12 @@ int32_t gn_program_set_gemm_plan(gn_program* p, int64_t op, int32_t tile, int32_
   GN_REQUIRE(gn_gemm_workspace_bytes(&d) == 0 || d.workspace, "gn_program_set_gemm_plan: this plan splits K and needs a workspace");
   // the fusions attached to the op must survive the new plan (gn_launch_gemm would refuse it at replay, possibly in the middle of a hipGraph capture):
   // norm_out lives in the split-K reduce, norm_in in the ring tiles, the plan must name the tile that will run
-  GN_REQUIRE(gn_gemm_plan_valid(&d), "gn_program_set_gemm_plan: tile %d / splitk %d refused for op %ld: %s", tile, splitk, (long)op, gn_last_error());
+  if (!gn_gemm_plan_valid(&d)) {
+    char why[600];
+    snprintf(why, sizeof(why), "%s", g_err);  // (gn_set_error formats into g_err itself)
+    gn_set_error("gn_program_set_gemm_plan: tile %d / splitk %d refused for op %ld: %s", tile, splitk, (long)op, why);
+    return GN_ERR_INVALID;
+  }
   p->ops[(size_t)op].gemm = d;
   return GN_OK;
 }

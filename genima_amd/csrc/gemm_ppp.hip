@@ -70,6 +70,12 @@ __device__ __forceinline__ KArgs* ppp_kargs() {
   return (KArgs*)kp;
 }
 
+// n / d by the host's magic pair: three scalar instructions instead of the ~30 (32-bit) or ~300 (64-bit) of a division the compiler expands
+__device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned shift) {
+  return (int)(((unsigned long long)__umulhi((unsigned)n, mul) + (unsigned)n) >> shift);
+}
+#define PPP_DIV(n, fd) fdiv((n), q->fd.mul, q->fd.shift)
+
 template <bool CONV>
 __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PP_STAGE];
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     int c = blockIdx.x;
     asm volatile("" : "+s"(c));
     const int G = q->ppG, nk = q->K / BK;
-    const int kc1 = (q->ppSkew && c + 1 < G) ? (int)(((long)(c + 1) * nk) / G) : 0;
+    const int kc1 = (q->ppSkew && c + 1 < G) ? PPP_DIV((c + 1) * nk, dG) : 0;
     return q->ppR + (kc1 > 0 ? 1 : 0) + ((q->ppTail > 0 && c < q->ppTail * q->ppS) ? 1 : 0);
   };
   auto get_seg = [&](int i) __attribute__((always_inline)) {
@@ -104,8 +110,8 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       const int qq = G >> 3, r = G & 7, xcd = b & 7, idx = b >> 3;
       return (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
     };
-    const int kc0 = skew ? (int)(((long)c * nk) / G) : 0;
-    const int kc1 = (skew && c + 1 < G) ? (int)(((long)(c + 1) * nk) / G) : 0;
+    const int kc0 = skew ? PPP_DIV(c * nk, dG) : 0;  // (c * nk < 2^31: the planner keeps nk < 2^20)
+    const int kc1 = (skew && c + 1 < G) ? PPP_DIV((c + 1) * nk, dG) : 0;
     Seg s;
     s.slot = 0; s.nslot = 0;
     if (i == 0) {  // round 0: the K suffix from this workgroup's skew offset
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     } else if (i == R && kc1 > 0) {  // the K prefix of the next workgroup's round-0 tile: this workgroup writes that tile
       s.tile = vid(c + 1); s.k0 = 0; s.k1 = kc1; s.role = ROLE_OWNER; s.slot = c + 1; s.nslot = 1;
     } else {  // a tile of the last partial round, split along K over ppS workgroups
-      const int j = c / S, part = c - j * S;
+      const int j = PPP_DIV(c, dS), part = c - j * S;
       s.tile = R * G + j;
-      s.k0 = (int)(((long)part * nk) / S); s.k1 = (int)(((long)(part + 1) * nk) / S);
+      s.k0 = PPP_DIV(part * nk, dS); s.k1 = PPP_DIV((part + 1) * nk, dS);
       if (S == 1) s.role = ROLE_FULL;
       else if (part == 0) { s.role = ROLE_OWNER; s.slot = 256 + j * (S - 1); s.nslot = S - 1; }
       else { s.role = ROLE_PRODUCER; s.slot = 256 + j * (S - 1) + part - 1; }
@@ -131,9 +137,10 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     const int tm = q->tiles_m, tn = q->tiles_n;
     int rem = tile;
     z = 0;
-    if (q->ppNz > 1) { z = tile / (tm * tn); rem = tile - z * (tm * tn); }
-    const bool cm = q->cm_tiles != 0;
-    const int tile_n = cm ? rem / tm : rem % tn, tile_m = cm ? rem % tm : rem / tn;
+    if (q->ppNz > 1) { z = PPP_DIV(tile, dTmn); rem = tile - z * (tm * tn); }
+    int tile_n, tile_m;
+    if (q->cm_tiles) { tile_n = PPP_DIV(rem, dTm); tile_m = rem - tile_n * tm; }
+    else { tile_m = PPP_DIV(rem, dTn); tile_n = rem - tile_m * tn; }
     tm0 = tile_m * 256; tn0 = tile_n * 256;
   };
 
@@ -187,20 +194,20 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       int pad_t = q->pad_t, pad_l = q->pad_l;
       if (q->up_ph) { pad_t = 1 - (z >> 1); pad_l = 1 - (z & 1); }
       const int Wo = q->Wo, hw = q->Ho * Wo, stride = q->stride;
-      const int b = m0 / hw, rem0 = m0 - b * hw;
+      const int b = PPP_DIV(m0, dHw), rem0 = m0 - b * hw;
       pbase_s = b * q->H * q->W;
-      iyl = (r0 / Wo) * stride; ixl = (r0 % Wo) * stride;
+      { const int ry = r0 / Wo; iyl = ry * stride; ixl = (r0 - ry * Wo) * stride; }
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int rr = rem0 + 128 * h + 64 * i;
-          const int oy = rr / Wo, ox = rr - oy * Wo;
+          const int oy = PPP_DIV(rr, dWo), ox = rr - oy * Wo;
           tap_s[h][i] = ((oy * stride - pad_t) & 0xFFFF) | ((ox * stride - pad_l) << 16);
         }
-        const int tap = kbeg / Cin;
+        const int tap = PPP_DIV(kbeg, dCin);
         ccA[h] = kbeg - tap * Cin;
-        dyA[h] = tap / q->KW;
+        dyA[h] = PPP_DIV(tap, dKW);
         dxA[h] = tap - dyA[h] * q->KW;
         set_tap(h);
       }
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     const long ldo = q->ldo, ldo_hi = q->ldo_hi;
     const int orw = q->orw;
     if (q->up_ph) outb += (long)(tz >> 1) * (ldo_hi >> 1) + (long)(tz & 1) * (ldo >> 1);
-    outb += tn0 + 32 * wc + 8 * hi;
+    const int mrow = tm0 + 64 * wr + l31, colb = tn0 + 32 * wc + 8 * hi;
     const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)q->ws, 0, (int)0x7FFFFFF0, 0x00020000);
     const unsigned pbase = ((unsigned)slot * PPP_SLAB + (unsigned)(wave * 32) * 256 + (unsigned)lane * 4) * 4u;  // the hand-off slabs' register order (publish)
 
@@ -375,7 +382,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       }
     };
     // one quadrant: bias / pre-activation operand / activation / scale / post operand, f16, 16-byte stores
-    auto convert_store = [&](auto Q, auto AUX, const f16x4 (&bv)[4], const uint4 (&axr)[2][2]) __attribute__((always_inline)) {
+    auto convert_store = [&](auto Q, auto AUX, const float (&bf)[16], const uint4 (&axr)[2][2]) __attribute__((always_inline)) {
       constexpr int qd = decltype(Q)::value;
       constexpr bool aux = decltype(AUX)::value;
       constexpr int rowh = qd >= 2 ? 128 : 0, cs = (qd == 1 || qd == 2) ? 1 : 0;
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
         }
         if (bias) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += (float)bv[e >> 2][e & 3];
+          for (int e = 0; e < 16; ++e) v[e] += bf[e];
         }
         f16x4 ax[4];
         if constexpr (aux) {
@@ -435,10 +442,12 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
             for (int e = 0; e < 16; ++e) v[e] += (float)ax[e >> 2][e & 3];
           }
         }
-        const int m = tm0 + 64 * wr + rowh + 32 * i + l31;
+        // (the row address from two 32-bit per-lane values and scalars, band by band: a 64-bit per-lane pointer kept across the bands is what the
+        // allocator spills first, and its reloads would queue behind the stores already issued)
+        const int m = mrow + rowh + 32 * i;
         long roff = (long)m * ldo;
-        if (orw) { const int mh = m / orw; roff = (long)mh * ldo_hi + (long)(m - mh * orw) * ldo; }
-        f16* orow = outb + roff + 128 * cs;
+        if (orw) { const int mh = m / orw; roff = (long)mh * ldo_hi + (long)(m - mh * orw) * ldo; }  // two-level row pitch (one phase of an upsampling conv)
+        f16* orow = outb + (roff + (colb + 128 * cs));
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {  // lanes l / l + 32 trade channel groups: each owns 8 consecutive channels = one 16-byte store
           f16x4 ha, hb2;
@@ -456,8 +465,14 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     f16x4 bv0[4], bv1[4];
     load_bias(0, bv0);
     load_bias(1, bv1);
-    // (after a drained wait the bias vectors are USED -- an empty asm -- on every path the compiler sees: a load it believes pending at the end of the
-    // epilogue becomes a wait in front of the next K loop's first reuse of that register, and that wait sits out this tile's stores at run time)
+    // (after a drained wait the bias vectors are USED on every path the compiler sees: a load it believes pending at the end of the epilogue becomes
+    // a wait in front of the next K loop's first reuse of that register, and that wait sits out this tile's stores at run time.)  One f16 -> f32
+    // conversion per column set, not per band: the four bands of a set share it.
+    float bf[16];
+    auto bias_f32 = [&](const f16x4 (&bv)[4]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bf[e] = (float)bv[e >> 2][e & 3];
+    };
     auto touch_bias = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(bv0[g]), "v"(bv1[g]));
@@ -469,10 +484,12 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       PPP_T(t_d1);
       PPP_ACC(7, t_d0, t_d1);
       touch_bias();
-      convert_store(Q0{}, std::false_type{}, bv0, none);
-      convert_store(Q3{}, std::false_type{}, bv0, none);
-      convert_store(Q1{}, std::false_type{}, bv1, none);
-      convert_store(Q2{}, std::false_type{}, bv1, none);
+      bias_f32(bv0);
+      convert_store(Q0{}, std::false_type{}, bf, none);
+      convert_store(Q3{}, std::false_type{}, bf, none);
+      bias_f32(bv1);
+      convert_store(Q1{}, std::false_type{}, bf, none);
+      convert_store(Q2{}, std::false_type{}, bf, none);
     } else {
       uint4 ax0[2][2], ax1[2][2], ax2[2][2], ax3[2][2];  // 64 registers beside the accumulators: the whole tile's operand in ONE round trip
       load_aux(Q0{}, ax0);
@@ -481,10 +498,12 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       load_aux(Q2{}, ax2);
       PPP_DRAIN();
       touch_bias();
-      convert_store(Q0{}, std::true_type{}, bv0, ax0);
-      convert_store(Q3{}, std::true_type{}, bv0, ax3);
-      convert_store(Q1{}, std::true_type{}, bv1, ax1);
-      convert_store(Q2{}, std::true_type{}, bv1, ax2);
+      bias_f32(bv0);
+      convert_store(Q0{}, std::true_type{}, bf, ax0);
+      convert_store(Q3{}, std::true_type{}, bf, ax3);
+      bias_f32(bv1);
+      convert_store(Q1{}, std::true_type{}, bf, ax1);
+      convert_store(Q2{}, std::true_type{}, bf, ax2);
     }
   };
 
@@ -667,6 +686,16 @@ int32_t gn_ppp_pool_init(int device) {
 }
 
 // rounds / tail split / skew of a problem of `tiles` 256 x 256 tiles and nk K iterations on G workgroups; -> hand-off slabs the launch may use
+static GemmParams::FastDiv fast_div(unsigned d) {
+  GemmParams::FastDiv f;
+  if (d == 0) d = 1;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.mul = (unsigned)((((1ull << 32) * ((1ull << l) - d)) / d) + 1);
+  f.shift = l;
+  return f;
+}
+
 int gn_ppp_plan(void* params, int tiles, int G) {
   GemmParams& p = *static_cast<GemmParams*>(params);
   const int nk = p.K / BK;
@@ -674,12 +703,32 @@ int gn_ppp_plan(void* params, int tiles, int G) {
   p.ppNz = p.up_ph ? 4 : 1;
   p.ppR = tiles / G;
   p.ppTail = tiles - p.ppR * G;
-  int s = p.ppTail > 0 ? G / p.ppTail : 1;
-  if (s > 8) s = 8;
-  while (s > 1 && nk / s < 2) --s;  // every part walks at least two K iterations
+  // The tiles of the last partial round: split s ways along K where that pays.  A K iteration of a tile is ~1.8 us, a tile boundary ~9 us and a
+  // hand-off (256 KB of partial sums out, drained, back in through the owner's epilogue) ~14 us (profiles/r06_ppp_*): a 10-iteration tile gains nothing.
+  int s = 1;
+  if (p.ppTail > 0) {
+    static const int s_env = [] { const char* e = getenv("GN_PPP_TAIL_SPLIT"); return e ? atoi(e) : -1; }();  // A/B switch: force the split (1 = never)
+    int smax = G / p.ppTail;
+    if (smax > 8) smax = 8;
+    while (smax > 1 && nk / smax < 2) --smax;  // every part walks at least two K iterations
+    double best = 1.8 * nk;
+    for (int c = 2; c <= smax; ++c) {
+      const double cost = 1.8 * ((nk + c - 1) / c) + 14.0;
+      if (cost < best) { best = cost; s = c; }
+    }
+    if (s_env >= 1) s = s_env < smax ? s_env : smax;
+    if (s < 1) s = 1;
+  }
   p.ppS = s;
-  static const int skew_env = [] { const char* e = getenv("GN_PPP_SKEW"); return e ? atoi(e) : 1; }();  // A/B switch (0: every workgroup starts at K = 0)
+  // SKEW (workgroup c enters its first tile at K iteration c * nk / G): measured NOT to pay -- with the next tile's ring requested ahead of the
+  // epilogue and no wait behind the stores, the lock-step store bursts drain under the next K loop, and the skew's two hand-offs per workgroup cost
+  // more than the desynchronisation wins (profiles/r06_ppp_ksweep*.txt: 67 / 155 / 505 us without against 79 / 164 / 548 with, K = 256 / 1024 / 4096 at
+  // 1024 tiles).  GN_PPP_SKEW=1 turns it on (tests run both).
+  static const int skew_env = [] { const char* e = getenv("GN_PPP_SKEW"); return e ? atoi(e) : 0; }();
   p.ppSkew = (skew_env && nk >= 4) ? 1 : 0;
+  p.dG = fast_div((unsigned)G); p.dS = fast_div((unsigned)s);
+  p.dTm = fast_div((unsigned)p.tiles_m); p.dTn = fast_div((unsigned)p.tiles_n); p.dTmn = fast_div((unsigned)(p.tiles_m * p.tiles_n));
+  p.dHw = fast_div((unsigned)(p.Ho * p.Wo)); p.dWo = fast_div((unsigned)p.Wo); p.dCin = fast_div((unsigned)p.C1); p.dKW = fast_div((unsigned)p.KW);
   return 256 + p.ppTail * (s > 1 ? s - 1 : 0);
 }
 

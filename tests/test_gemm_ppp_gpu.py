@@ -4,8 +4,9 @@
   * against torch fp32 on the same f16 inputs at the kernel bar (1e-3), every epilogue the kernel carries (bias, SiLU, residual before / after the
     activation, time shift, scale), dense and conv (3x3, the four-phase upsampling conv), tile counts that exercise every segment kind: exactly one
     round (skew hand-offs only), 1.25 and 2.5 rounds (tail tiles split 4 and 2 ways along K), 3 rounds + a tail;
-  * against tile 15 (gemm_pp.hip, one launch round per 256 tiles): a tile whose K range one workgroup walks is BIT-identical, a shared tile differs by
-    the rounding of one or a few f32 partial sums (<= 2e-4 relative on the tensor); with the skew off and no tail every tile is bit-identical;
+  * against tile 15 (gemm_pp.hip, one launch round per 256 tiles): a tile whose K range one workgroup walks is BIT-identical (every tile of the full
+    rounds), a tile of the last partial round that is split along K differs by the rounding of a few f32 partial sums (<= 2e-4 relative on the
+    tensor); the skewed walk (GN_PPP_SKEW=1, off by default) in a subprocess;
   * run to run bit-identical (fixed summation order of the hand-offs), no bounded wait ever gives up (gn_ppp_timeouts), flags self-clean (the second
     run reuses nothing stale: a recorded program replays the same flag region)."""
 import pytest
@@ -35,9 +36,9 @@ def _ncu():
 
 
 @pytest.mark.parametrize("M,N,K,act,res,res_first", [
-    (16384, 1024, 640, ACT_NONE, False, False),    # 256 tiles: one round, every tile but the first shared by two workgroups (skew)
-    (20480, 1024, 1280, ACT_SILU, False, False),   # 320 tiles: 1.25 rounds, the 64 tail tiles split 4 ways
-    (40960, 1024, 640, ACT_NONE, True, False),     # 640 tiles: 2.5 rounds, tail split 2 ways, residual after the (absent) activation
+    (16384, 1024, 640, ACT_NONE, False, False),    # 256 tiles: exactly one round
+    (20480, 1024, 4096, ACT_SILU, False, False),   # 320 tiles: 1.25 rounds, the 64 tail tiles split along K (the planner's cost model splits long K only)
+    (40960, 1024, 2048, ACT_NONE, True, False),    # 640 tiles: 2.5 rounds, tail split 2 ways, residual after the (absent) activation
     (8192, 2048, 320, ACT_SILU, True, True),       # 256 tiles, K = 5 tiles only, residual inside the activation
     (65536, 512, 1152, ACT_NONE, False, False),    # 512 tiles: two full rounds, no tail
     (28160, 2048, 256, ACT_SILU, True, False)])    # 880 tiles: 3 rounds + 112 tail tiles (2 ways), K = 4 tiles (the minimum)
@@ -71,31 +72,34 @@ def test_dense_vs_torch_and_tile15(M, N, K, act, res, res_first):
     assert_close(y25, ref, 1e-3, "tile 25 vs torch fp32")
     assert rel_l2(y25.float(), y15.float()) < 2e-4, rel_l2(y25.float(), y15.float())
     assert int(E.lib.gn_ppp_timeouts()) == t0, "a bounded hand-off wait gave up"
-    # rows of tiles that ONE workgroup computes over the whole K range are bit-identical to tile 15: with the skew on that is every tile of the
-    # rounds >= 1 (round 0's tiles are all shared, the tail's too); checked on the second round where there is one
+    # the tiles of the full rounds are computed by ONE workgroup over the whole K range: bit-identical to tile 15 (row-major tile order: the first
+    # R * 256 tiles are the first R * 256 / tiles_n row bands); only the tail's tiles, where they are split along K, differ in rounding
     tiles_n = N // 256
-    if (M // 256) * tiles_n >= 512:
-        lo = 256 // tiles_n * 256  # first row of round 1 (row-major tile order inside an XCD run is a permutation of the round's tiles)
-        hi = 2 * lo
-        assert torch.equal(y25[lo:hi], y15[lo:hi]), "unshared tiles must be bit-identical to tile 15"
+    full = ((M // 256) * tiles_n // 256) * 256 // tiles_n * 256
+    assert torch.equal(y25[:full], y15[:full]), "unshared tiles must be bit-identical to tile 15"
 
 
-def test_skew_off_is_bit_identical_to_tile15(monkeypatch):
-    """GN_PPP_SKEW=0 (read once per process by the library): covered through a problem without a tail in a subprocess."""
+def test_skewed_walk_in_a_subprocess():
+    """GN_PPP_SKEW=1 (read once per process by the library; off by default because it measured slower): workgroup c enters its first tile at K
+    iteration c * nk / G and hands the partial sums to workgroup c - 1 -- every round-0 tile goes through a hand-off.  Same bars."""
     import os
     import subprocess
     import sys
     code = (
         "import torch, sys; sys.path.insert(0, 'tests');\n"
-        "from genima_amd.engine import Engine; from util import randn_h\n"
+        "from genima_amd.engine import Engine; from util import randn_h, rel_l2\n"
         "E = Engine('cuda:0'); E.autotune = False\n"
-        "x, w, b = randn_h(32768, 640, seed=1), randn_h(512, 640, seed=2, scale=0.04), randn_h(512, seed=3)\n"
-        "ys = []\n"
-        "for t in (25, 15):\n"
-        "    E.lib.gn_set_gemm_tile_override(t - 1); ys.append(E.linear(x, w, b)); E.synchronize()\n"
-        "assert torch.equal(ys[0], ys[1]); assert int(E.lib.gn_ppp_timeouts()) == 0; print('OK')\n")
+        "for (M, N, K) in ((32768, 512, 640), (20480, 1024, 1280), (40960, 1024, 2048)):\n"
+        "    x, w, b = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5), randn_h(N, seed=3)\n"
+        "    ys = []\n"
+        "    for t in (25, 25, 15):\n"
+        "        E.lib.gn_set_gemm_tile_override(t - 1); ys.append(E.linear(x, w, b)); E.synchronize()\n"
+        "    ref = x.float() @ w.float().t() + b.float()\n"
+        "    assert torch.equal(ys[0], ys[1]); assert rel_l2(ys[0].float(), ys[2].float()) < 2e-4; assert rel_l2(ys[0].float(), ref) < 1e-3\n"
+        "    assert not torch.equal(ys[0], ys[2]), 'the skewed walk shares every round-0 tile: some rounding must differ'\n"
+        "assert int(E.lib.gn_ppp_timeouts()) == 0; print('OK')\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GN_PPP_SKEW="0"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, GN_PPP_SKEW="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stderr[-2000:]
 
 
