@@ -53,7 +53,7 @@ struct GemmParams {
   // persistent skewed ping-pong kernel (gemm_ppp.hip, tile 25): the grid is ppG workgroups (one per CU) that walk the tile list; `ws` holds the f32
   // hand-off slabs of the tiles whose K range two (or more) workgroups share, ppflags their ready words (zero between launches: the consumer resets them)
   struct FastDiv { unsigned mul, shift; };  // n / d for 32-bit n as (umulhi(n, mul) + n) >> shift (Granlund - Montgomery; gn_ppp_plan fills them)
-  FastDiv dG, dS, dTm, dTn, dTmn, dHw, dWo, dCin, dKW;
+  FastDiv dG, dS, dTm, dTn, dTmn, dHw, dWo, dCin, dKW, dOrw;
   unsigned* ppflags;
   unsigned* pptmo;                       // counts bounded hand-off waits that gave up (gn_ppp_timeouts)
   int ppG, ppR, ppTail, ppS, ppNz, ppSkew;  // workgroups, full rounds, tiles of the last partial round, workgroups per such tile, blockIdx.z extent folded in, skew on

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     f16* outb = q->out;
     const long ldo = q->ldo, ldo_hi = q->ldo_hi;
     const int orw = q->orw;
+    const unsigned orw_mul = q->dOrw.mul, orw_shift = q->dOrw.shift;
     if (q->up_ph) outb += (long)(tz >> 1) * (ldo_hi >> 1) + (long)(tz & 1) * (ldo >> 1);
     const int mrow = tm0 + 64 * wr + l31, colb = tn0 + 32 * wc + 8 * hi;
     const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc((void*)q->ws, 0, (int)0x7FFFFFF0, 0x00020000);
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
         // allocator spills first, and its reloads would queue behind the stores already issued)
         const int m = mrow + rowh + 32 * i;
         long roff = (long)m * ldo;
-        if (orw) { const int mh = m / orw; roff = (long)mh * ldo_hi + (long)(m - mh * orw) * ldo; }  // two-level row pitch (one phase of an upsampling conv)
+        if (orw) { const int mh = fdiv(m, orw_mul, orw_shift); roff = (long)mh * ldo_hi + (long)(m - mh * orw) * ldo; }  // two-level row pitch (one phase of an upsampling conv)
         f16* orow = outb + (roff + (colb + 128 * cs));
 #pragma unroll
         for (int g = 0; g < 4; g += 2) {  // lanes l / l + 32 trade channel groups: each owns 8 consecutive channels = one 16-byte store
@@ -704,7 +705,7 @@ int gn_ppp_plan(void* params, int tiles, int G) {
   p.ppR = tiles / G;
   p.ppTail = tiles - p.ppR * G;
   // The tiles of the last partial round: split s ways along K where that pays.  A K iteration of a tile is ~1.8 us, a tile boundary ~9 us and a
-  // hand-off (256 KB of partial sums out, drained, back in through the owner's epilogue) ~14 us (profiles/r06_ppp_*): a 10-iteration tile gains nothing.
+  // hand-off (256 KB of partial sums out, drained, back in through the owner's epilogue) ~22 us (profiles/r06_ppp_*): a 16-iteration tile gains nothing.
   int s = 1;
   if (p.ppTail > 0) {
     static const int s_env = [] { const char* e = getenv("GN_PPP_TAIL_SPLIT"); return e ? atoi(e) : -1; }();  // A/B switch: force the split (1 = never)
@@ -713,7 +714,7 @@ int gn_ppp_plan(void* params, int tiles, int G) {
     while (smax > 1 && nk / smax < 2) --smax;  // every part walks at least two K iterations
     double best = 1.8 * nk;
     for (int c = 2; c <= smax; ++c) {
-      const double cost = 1.8 * ((nk + c - 1) / c) + 14.0;
+      const double cost = 1.8 * ((nk + c - 1) / c) + 22.0;
       if (cost < best) { best = cost; s = c; }
     }
     if (s_env >= 1) s = s_env < smax ? s_env : smax;
@@ -728,6 +729,7 @@ int gn_ppp_plan(void* params, int tiles, int G) {
   p.ppSkew = (skew_env && nk >= 4) ? 1 : 0;
   p.dG = fast_div((unsigned)G); p.dS = fast_div((unsigned)s);
   p.dTm = fast_div((unsigned)p.tiles_m); p.dTn = fast_div((unsigned)p.tiles_n); p.dTmn = fast_div((unsigned)(p.tiles_m * p.tiles_n));
+  p.dOrw = fast_div((unsigned)p.orw);
   p.dHw = fast_div((unsigned)(p.Ho * p.Wo)); p.dWo = fast_div((unsigned)p.Wo); p.dCin = fast_div((unsigned)p.C1); p.dKW = fast_div((unsigned)p.KW);
   return 256 + p.ppTail * (s > 1 ? s - 1 : 0);
 }
