@@ -824,7 +824,7 @@ constexpr Cfg kCfg[] = {{256, 128, 1.00, true, false}, {128, 128, 1.00, true, fa
                         {128, 320, 0.0, false, true},
                         // persistent skewed ping-pong 256x256 (gemm_ppp.hip, round 6): one workgroup per CU walks the tile list; the next tile's ring is
                         // requested before the finished tile's epilogue, tile boundaries are skewed over the chip, the last partial round is split along K
-                        {256, 256, 0.0, false, true}};
+                        {256, 256, 0.0, true, true}};
 constexpr int kNumCfg = 25;
 constexpr int kCfgPPP = 24;
 constexpr int kCfgS3End = 22;  // one past the last 3-stage configuration
@@ -852,7 +852,14 @@ int ppp_workgroups() {
 int64_t ppp_tiles(const gn_gemm_desc* d) { return cdiv64(d->M, 256) * cdiv64(d->N, 256) * (d->up_phases ? 4 : 1); }
 // the persistent skewed ping-pong kernel's restrictions on top of pp_eligible (gemm_ppp.hip header)
 bool ppp_eligible(const gn_gemm_desc* d) {
-  if (!pp_eligible(d) || d->out_mode != GN_OUT_ROWMAJOR || d->out2 || d->ln_c1 || d->sink.stats || d->norm_in.stats || d->norm_out.y) return false;
+  const bool ff = d->act == GN_ACT_GEGLU || d->ln_c1 != nullptr;
+  if (ff) {  // the feed-forward variant: LayerNorm fold AND GEGLU together (diffusers FeedForward.net[0] behind BasicTransformerBlock.norm3), dense, c2 in bias
+    if (!(d->act == GN_ACT_GEGLU && d->ln_c1 && d->bias) || d->conv || d->batch > 1 || d->fp8 || d->K % 64 != 0 || d->residual || d->shift || d->out_scale != 1.0f) return false;
+    if (((uintptr_t)d->ln_c1 & 15) != 0 || ((uintptr_t)d->bias & 7) != 0 || d->ln_eps <= 0.0f) return false;
+  } else if (!pp_eligible(d)) {
+    return false;
+  }
+  if (d->out_mode != GN_OUT_ROWMAJOR || d->out2 || d->sink.stats || d->norm_in.stats || d->norm_out.y) return false;
   if (d->splitk > 1 || (d->shift && d->residual) || d->k_append || d->a2) return false;
   // whole tiles only: no row mask in the loaders, the R part of an address is the buffer instruction's scalar offset
   if (d->M % 256 != 0 || d->N % 256 != 0 || d->K < 4 * 64) return false;
@@ -931,7 +938,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
   if (d->tile >= 1 && d->tile <= kNumCfg) best = d->tile - 1;
   if (geglu && !kCfg[best].geglu) best = 1;
   if (d->ln_c1) {  // LayerNorm fold: the LDS-DMA kernels (two-stage and ring) carry it
-    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22, 23, 6};
+    static const int to_dma[kNumCfg] = {7, 8, 9, 10, 11, 8, 6, 7, 8, 9, 10, 11, 12, 13, 6, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24};
     best = to_dma[best];
   }
   if (d->k_append && !kCfg[best].dma) {  // the appended segment lives in the LDS-DMA loaders
@@ -949,7 +956,7 @@ Plan plan_gemm(const gn_gemm_desc* d) {
     auto lds_bytes = [&](int c) { return (int64_t)3 * (kCfg[c].bm + kCfg[c].bn) * 128 + (rps >= kCfg[c].bm ? 1 : kCfg[c].bm / (rps > 0 ? rps : 1)) * ct * 8; };
     if (lds_bytes(best) > 160 * 1024) best = 17;
   }
-  if (best == kCfgPPP && !ppp_eligible(d)) best = kCfgPP;
+  if (best == kCfgPPP && !ppp_eligible(d)) best = (geglu || d->ln_c1) ? 6 : kCfgPP;
   if (best == kCfgPP && !pp_eligible(d)) best = 6;
   if (kCfg[best].dma && !dma_eligible(d)) {
     static const int fallback[kNumCfg] = {0, 1, 2, 3, 4, 5, 0, 0, 1, 2, 3, 4, 1, 0, 0, 1, 2, 3, 4, 1, 2, 2, 1, 1, 0};

@@ -76,9 +76,15 @@ __device__ __forceinline__ int fdiv(int n, unsigned mul, unsigned shift) {
 }
 #define PPP_DIV(n, fd) fdiv((n), q->fd.mul, q->fd.shift)
 
-template <bool CONV>
+// FF (dense only): the transformer's feed-forward projection -- LayerNorm folded into the Linear (gn_gemm_desc.ln_c1: the row statistics come from
+// the A fragments of the K loop) with the GEGLU epilogue (W rows packed in 32-row [hidden | gate] blocks).  The loader permutes the W rows of a
+// tile so that W half 0 holds its four hidden blocks and half 1 its four gate blocks: wave (., wc) then owns hidden block wc in the W0 quadrants
+// and gate block wc in the W1 quadrants of the same rows, and the GEGLU product is register-local.
+template <bool CONV, bool FF>
 __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PP_STAGE];
+  static_assert(!(CONV && FF), "the feed-forward variant is a dense problem");
+  constexpr int kStatsBytes = FF ? 4 * 256 * 8 : 0;  // FF: (sum, sum of squares) of the 256 rows from each of the 4 waves that share them
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * PP_STAGE + kStatsBytes];
 #ifdef GN_PPP_PROFILE
   unsigned prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   PPP_T(t_start);
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     tile_origin(s.tile, m0, n0, z);
     kbeg = s.k0 * BK;
     kend = s.k1 * BK;
-    woffk = (unsigned)((long)(n0 + r0) * q->ldw * 2) + (unsigned)kl2;
+    // FF: LDS row 64 i + r0 of W half h is global row n0 + 128 i + 32 h + 64 (r0 / 32) + r0 % 32 (the hidden block of pair 2 i + r0 / 32 for h = 0, its gate block for h = 1)
+    woffk = (unsigned)((long)(n0 + (FF ? 64 * (r0 >> 5) + (r0 & 31) : r0)) * q->ldw * 2) + (unsigned)kl2;
     if (q->up_ph)  // phase z = 2 dy + dx of an upsampling conv (gemm_common.h batch_offset): its weights here, its padding below, its output offset in the epilogue
       rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)(q->w + (long)z * q->w_bs), 0, (int)q->w_bytes, 0x00020000);
     if constexpr (CONV) {
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     const unsigned voff = (woffk + (unsigned)k0 * 2u) | (k0 < kend ? 0u : kOOB);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + i * 8192), 16, voff, (128 * h + 64 * i) * (int)p.ldw * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(dst + i * 8192), 16, voff, (FF ? 32 * h + 128 * i : 128 * h + 64 * i) * (int)p.ldw * 2, 0, 0);
   };
   // the whole LDS ring of a segment: all of K tile 0, then A0 / W0 of tile 1 (the order the steady-state vmcnt counts assume)
   auto prologue = [&]() __attribute__((always_inline)) {
@@ -275,6 +282,31 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
   auto rd = [&](const unsigned char* ptr) __attribute__((always_inline)) -> f16x8 { return *reinterpret_cast<const f16x8*>(ptr); };
   auto mma = [&](const f16x8& w, const f16x8& a, f32x16& acc1) __attribute__((always_inline)) { acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w, a, acc1, 0, 0, 0); };
   auto bar = [&]() __attribute__((always_inline)) { __builtin_amdgcn_s_barrier(); };
+
+  // FF: this wave's share of the rows' LayerNorm sums, [A half][row band]: the four waves of a row band take one 16-wide K step of every K tile each
+  float ls1[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}}, ls2[2][2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+  auto ln_step = [&](int hA, const f16x8 (&fa)[2][4]) __attribute__((always_inline)) {
+    if constexpr (FF) {
+      const f16x2 ones = {(f16)1.0f, (f16)1.0f};
+      static_for<4>::run([&](auto KK) {
+        constexpr int kk = decltype(KK)::value;
+        if ((wave & 3) == kk) {  // wave-uniform
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) {
+            const f16x8 f = fa[mt][kk];
+            const f16x2 h0 = __builtin_shufflevector(f, f, 0, 1), h1 = __builtin_shufflevector(f, f, 2, 3);
+            const f16x2 h2 = __builtin_shufflevector(f, f, 4, 5), h3 = __builtin_shufflevector(f, f, 6, 7);
+            float a = ls1[hA][mt], b = ls2[hA][mt];
+            a = __builtin_amdgcn_fdot2(h0, ones, a, false); b = __builtin_amdgcn_fdot2(h0, h0, b, false);
+            a = __builtin_amdgcn_fdot2(h1, ones, a, false); b = __builtin_amdgcn_fdot2(h1, h1, b, false);
+            a = __builtin_amdgcn_fdot2(h2, ones, a, false); b = __builtin_amdgcn_fdot2(h2, h2, b, false);
+            a = __builtin_amdgcn_fdot2(h3, ones, a, false); b = __builtin_amdgcn_fdot2(h3, h3, b, false);
+            ls1[hA][mt] = a; ls2[hA][mt] = b;
+          }
+        }
+      });
+    }
+  };
 
   f32x16 acc[4][1][2];  // [quadrant][TN = 1][TM = 2]; quadrants (A0,W0) (A0,W1) (A1,W1) (A1,W0)
   auto zero_acc = [&]() __attribute__((always_inline)) {
@@ -508,6 +540,88 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     }
   };
 
+  // ---- FF epilogue: finish the rows' LayerNorm statistics, then  out = (rstd (h - mean c1h) + bh) * gelu(rstd (g - mean c1g) + bg)  ------------------
+  // h / g = the hidden / gate accumulators of a row band (quadrants (A, W0) / (A, W1)), c1 = the column sums of the gamma-scaled weight, b = c2
+  // (gn_gemm_desc.ln_c1; gemm_common.h ln_fold_apply + the GEGLU branch of gemm_epilogue are the launches this replaces).  Loads (c1, bias) first,
+  // one drained wait = the next segment's ring, then band by band compute and store: 8 x 16-byte stores per wave (the output is N / 2 wide).
+  auto finish_tile_ff = [&](int tm0, int tn0) __attribute__((always_inline)) {
+    if constexpr (FF) {
+      KArgs* q = ppp_kargs();
+      int lane = lane_, wave = wave_;
+      asm volatile("" : "+v"(lane), "+s"(wave));
+      const int l31 = lane & 31, hi = lane >> 5, wr = wave >> 2, wc = wave & 3;
+      // (1) the statistics: the two lane halves hold the two 8-element halves of every K step; the four waves of a row band one K step in four each
+      float* st = reinterpret_cast<float*>(smem + 2 * PP_STAGE);
+#pragma unroll
+      for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const float a = ls1[hA][mt] + __shfl_xor(ls1[hA][mt], 32), b = ls2[hA][mt] + __shfl_xor(ls2[hA][mt], 32);
+          if (hi == 0) *reinterpret_cast<float2*>(st + ((wc * 256) + hA * 128 + wr * 64 + mt * 32 + l31) * 2) = make_float2(a, b);
+          ls1[hA][mt] = 0.0f; ls2[hA][mt] = 0.0f;
+        }
+      // (2) this wave's columns: c1 (f32) and c2 (f16, in `bias`) of hidden block wc and gate block wc of the tile
+      const float* c1 = q->ln_c1 + tn0 + 64 * wc + 4 * hi;
+      const f16* c2 = q->bias + tn0 + 64 * wc + 4 * hi;
+      f32x4 c1h[4], c1g[4];
+      f16x4 bh[4], bg[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        c1h[g] = *reinterpret_cast<const f32x4*>(c1 + 8 * g);
+        c1g[g] = *reinterpret_cast<const f32x4*>(c1 + 32 + 8 * g);
+        bh[g] = *reinterpret_cast<const f16x4*>(c2 + 8 * g);
+        bg[g] = *reinterpret_cast<const f16x4*>(c2 + 32 + 8 * g);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave's partial sums are in LDS
+      float nmr[2][2], rstd[2][2];   // -rstd * mean, rstd of this lane's rows
+      const float invk = 1.0f / (float)q->K, eps = q->ln_eps;
+#pragma unroll
+      for (int hA = 0; hA < 2; ++hA)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float a = 0.0f, b = 0.0f;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {  // fixed order: every wave of a row band computes the same bits
+            const float2 v = *reinterpret_cast<const float2*>(st + ((w * 256) + hA * 128 + wr * 64 + mt * 32 + l31) * 2);
+            a += v.x; b += v.y;
+          }
+          const float mean = a * invk;
+          const float var = fmaxf(b * invk - mean * mean, 0.0f);
+          rstd[hA][mt] = __frsqrt_rn(var + eps);
+          nmr[hA][mt] = -rstd[hA][mt] * mean;
+        }
+      PPP_DRAIN();  // c1 / c2 AND the next segment's ring have landed; nothing of this tile is stored yet
+#pragma unroll
+      for (int g = 0; g < 4; ++g) asm volatile("" ::"v"(c1h[g]), "v"(c1g[g]), "v"(bh[g]), "v"(bg[g]));
+      f16* outp = q->out + (tn0 >> 1) + 32 * wc + 8 * hi;
+      const long ldo = q->ldo;
+      const int mrow = tm0 + 64 * wr + l31;
+      static_for<4>::run([&](auto U) {
+        constexpr int u = decltype(U)::value, hA = u >> 1, mt = u & 1;
+        constexpr int qh = hA == 0 ? 0 : 3, qg = hA == 0 ? 1 : 2;
+        const float rs = rstd[hA][mt], nm = nmr[hA][mt];
+        f16x4 o[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float hv = rs * acc[qh][0][mt][4 * g + e] + nm * c1h[g][e] + (float)bh[g][e];
+            const float gv = rs * acc[qg][0][mt][4 * g + e] + nm * c1g[g][e] + (float)bg[g][e];
+            o[g][e] = (f16)(hv * gelu_fast(gv));
+          }
+        f16* orow = outp + (long)(mrow + 128 * hA + 32 * mt) * ldo;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const uint2 ua = *reinterpret_cast<const uint2*>(&o[g]), ub = *reinterpret_cast<const uint2*>(&o[g + 1]);
+          const auto r0 = __builtin_amdgcn_permlane32_swap(ua.x, ub.x, false, false);
+          const auto r1 = __builtin_amdgcn_permlane32_swap(ua.y, ub.y, false, false);
+          *reinterpret_cast<uint4*>(orow + 8 * g) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      });
+    }
+  };
+
   // ================================================================ the walk ==================================================================
   int nks;
   {
@@ -543,6 +657,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) fa[mt][kk] = rd(Ab + a_rd[kk] + mt * 4096);
+      ln_step(0, fa);
       stage_w(1, b ^ 1, kt + BK);
 #ifdef GN_PPP_PROFILE
       if (t == 1) { PPP_T(tw0); asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); PPP_T(tw1); PPP_ACC(4, tw0, tw1); }
@@ -584,6 +699,7 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) fa[mt][kk] = rd(Ab + PP_HALF + a_rd[kk] + mt * 4096);
+      ln_step(1, fa);
       stage_a(0, b, kt + 2 * BK);
       __builtin_amdgcn_sched_barrier(0);
       bar();
@@ -629,7 +745,9 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     // a shared tile's partial sums go out first (once or twice per workgroup and launch): the accumulators are dead before the next segment's
     // loader state and ring come in.  The OWNER of a shared tile adds the other parts' slabs inside its epilogue (the accumulators are only READ there:
     // as values modified on one path they would need a second copy of themselves at the join, i.e. scratch)
-    if (role == ROLE_PRODUCER) publish(done.slot);
+    if constexpr (!FF) {
+      if (role == ROLE_PRODUCER) publish(done.slot);
+    }
     __builtin_amdgcn_sched_barrier(0);
     const bool more = si + 1 < seg_count();
     int nks_next = 0;
@@ -645,8 +763,12 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
     if (role == ROLE_PRODUCER) {
       PPP_DRAIN();  // the ring of the next segment
     } else {
-      if (role == ROLE_OWNER) wait_parts(done.slot, done.nslot);
-      finish_tile(tm0, tn0, tz, done.slot, role == ROLE_OWNER ? done.nslot : 0);
+      if constexpr (FF) {
+        finish_tile_ff(tm0, tn0);  // (the planner neither skews nor splits these problems: a tile's statistics want its whole K range)
+      } else {
+        if (role == ROLE_OWNER) wait_parts(done.slot, done.nslot);
+        finish_tile(tm0, tn0, tz, done.slot, role == ROLE_OWNER ? done.nslot : 0);
+      }
     }
     PPP_T(t_f1);
     PPP_ACC(role == ROLE_FULL ? 2 : 5, t_b1, t_f1);
@@ -720,13 +842,14 @@ int gn_ppp_plan(void* params, int tiles, int G) {
     if (s_env >= 1) s = s_env < smax ? s_env : smax;
     if (s < 1) s = 1;
   }
+  if (p.ln_c1) s = 1;  // the feed-forward variant takes a tile's LayerNorm statistics from its whole K range
   p.ppS = s;
   // SKEW (workgroup c enters its first tile at K iteration c * nk / G): measured NOT to pay -- with the next tile's ring requested ahead of the
   // epilogue and no wait behind the stores, the lock-step store bursts drain under the next K loop, and the skew's two hand-offs per workgroup cost
   // more than the desynchronisation wins (profiles/r06_ppp_ksweep*.txt: 67 / 155 / 505 us without against 79 / 164 / 548 with, K = 256 / 1024 / 4096 at
   // 1024 tiles).  GN_PPP_SKEW=1 turns it on (tests run both).
   static const int skew_env = [] { const char* e = getenv("GN_PPP_SKEW"); return e ? atoi(e) : 0; }();
-  p.ppSkew = (skew_env && nk >= 4) ? 1 : 0;
+  p.ppSkew = (skew_env && nk >= 4 && !p.ln_c1) ? 1 : 0;
   p.dG = fast_div((unsigned)G); p.dS = fast_div((unsigned)s);
   p.dTm = fast_div((unsigned)p.tiles_m); p.dTn = fast_div((unsigned)p.tiles_n); p.dTmn = fast_div((unsigned)(p.tiles_m * p.tiles_n));
   p.dOrw = fast_div((unsigned)p.orw);
@@ -743,8 +866,9 @@ void gn_launch_gemm_ppp(const void* params, bool conv, hipStream_t st) {
   p.ppflags = g_pool[dev] + PPP_POOL_HEAD + (size_t)region * PPP_REGION;
   p.pptmo = g_pool[dev];
   const dim3 grid(p.ppG);
-  if (conv) hipLaunchKernelGGL((gemm_ppp_kernel<true>), grid, dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((gemm_ppp_kernel<false>), grid, dim3(512), 0, st, p);
+  if (conv) hipLaunchKernelGGL((gemm_ppp_kernel<true, false>), grid, dim3(512), 0, st, p);
+  else if (p.ln_c1) hipLaunchKernelGGL((gemm_ppp_kernel<false, true>), grid, dim3(512), 0, st, p);  // LayerNorm fold + GEGLU (the planner admits them together only)
+  else hipLaunchKernelGGL((gemm_ppp_kernel<false, false>), grid, dim3(512), 0, st, p);
 }
 
 // profiling builds: the per-workgroup cycle sums of the LAST tile-25 launch (8 words per workgroup: K loops, boundary up to the ring request,

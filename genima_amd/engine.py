@@ -314,7 +314,9 @@ class Engine:
     def _ppp_candidate(d: GemmDesc) -> bool:
         """Is the persistent skewed ping-pong tile (25, csrc/gemm_ppp.hip) worth racing?  (The library decides eligibility; this only keeps shapes it
         would map back onto tile 15 out of the race.)"""
-        if d.M % 256 or d.N % 256 or d.K % 64 or d.K < 256 or d.act == ACT_GEGLU or d.out_mode != OUT_ROWMAJOR or d.out2 or d.ln_c1 or d.fp8 or d.k_append or d.a2:
+        if d.M % 256 or d.N % 256 or d.K % 64 or d.K < 256 or d.out_mode != OUT_ROWMAJOR or d.out2 or d.fp8 or d.k_append or d.a2:
+            return False
+        if (d.act == ACT_GEGLU) != bool(d.ln_c1):  # the feed-forward variant takes the LayerNorm fold and GEGLU together
             return False
         if d.batch > 1 and not d.up_phases:
             return False
@@ -332,16 +334,16 @@ class Engine:
         challengers = [int(c) for c in os.environ.get("GN_RETUNE", "").split(",") if c.strip()]  # e.g. GN_RETUNE=15: race new tiles
         if key in table and not (challengers and key not in self._retuned):                       # against each shape's incumbent
             return table[key]
-        cands = (1, 2, 5, 6, 7, 8, 9, 12, 16, 19) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
+        cands = (1, 2, 5, 6, 7, 8, 9, 12, 16, 19, 25) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
         if key in table:
             self._retuned.add(key)
-            cands = [table[key]] + [c for c in challengers if c != table[key] % 100 and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19))]
+            cands = [table[key]] + [c for c in challengers if c != table[key] % 100 and (d.act != ACT_GEGLU or c in (1, 2, 5, 6, 7, 8, 9, 12, 16, 19, 25))]
         if not self._ppp_candidate(d):  # tile 25 needs whole 256 x 256 tiles, at least one per CU (the library would run tile 15 instead: no second race of it)
             cands = [c for c in cands if c % 100 != 25]
         if d.fp8:  # the fp8 kernel exists for the six LDS-DMA block tiles 256x256 .. 256x64
             cands = (7, 8, 9, 12) if d.act == ACT_GEGLU else range(7, 13)
         if d.ln_c1:  # the LayerNorm fold lives in the LDS-DMA kernels (the library maps the other tiles onto them)
-            cands = [c for c in cands if c % 100 >= 7 and c % 100 not in (15, 25)]
+            cands = [c for c in cands if c % 100 >= 7 and c % 100 != 15]
         if d.k_append:  # so does the appended 1x1 segment
             cands = [c for c in cands if c % 100 >= 7]
         if d.norm_in.stats:  # the normalising A path lives in the ring kernels; a row tile spans at most four samples

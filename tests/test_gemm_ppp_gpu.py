@@ -184,3 +184,38 @@ def test_ineligible_problems_fall_back_to_tile15():
         x, w, b = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=0.04), randn_h(N, seed=3)
         y = _with_tile(E, 25, lambda: E.linear(x, w, b))
         assert_close(y, x.float() @ w.float().t() + b.float(), 1e-3)
+
+
+@pytest.mark.parametrize("M,Nh,K", [
+    (8192, 2560, 640),     # the 32 x 32 latent level's feed-forward projection at B = 8: 32 x 20 = 640 tiles, 2.5 rounds
+    (2048, 5120, 1280),    # the 16 x 16 level: 8 x 40 = 320 tiles
+    (32768, 1280, 320)])   # 128 x 10 = 1280 tiles, five rounds, K = 5 tiles
+def test_feed_forward_variant_layernorm_fold_and_geglu(M, Nh, K):
+    """BasicTransformerBlock.norm3 -> FeedForward.net[0] (GEGLU) as ONE persistent launch: the rows' LayerNorm statistics from the K loop's A fragments,
+    hidden * gelu(gate) in the epilogue (W rows permuted in the loader so that a wave owns a hidden block and its gate block).  Against torch fp32
+    layer_norm + linear + GEGLU at the kernel bar, against the tile the table names today (9: 128 x 128 LDS-DMA) within 3e-4 (the statistics are
+    summed in another order), bit-reproducible; rows with a large mean so that the mean * c1 cancellation is exercised."""
+    if _ncu() != 256:
+        pytest.skip("tile counts are written for 256 CUs")
+    from genima_amd.packing import pack_geglu
+    E = Engine("cuda:0")
+    E.autotune = False
+    x = (randn_h(M, K, seed=31).float() + randn_h(M, 1, seed=32).float() * 3.0).half()
+    w, b = randn_h(2 * Nh, K, seed=33, scale=K ** -0.5), randn_h(2 * Nh, seed=34, scale=0.3)
+    gamma, beta = (1.0 + 0.3 * randn_h(K, seed=35).float()).half(), randn_h(K, seed=36, scale=0.2)
+    ln = F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)
+    full = ln @ w.float().t() + b.float()
+    want = full[:, :Nh] * F.gelu(full[:, Nh:])
+    wp, bp = pack_geglu(w.float().cpu(), b.float().cpu())
+    wp, bp = wp.cuda(), bp.cuda()
+    wg = (wp.float() * gamma.float()[None, :]).half().contiguous()
+    c1 = wg.float().sum(dim=1).contiguous()
+    c2 = (wp.float() @ beta.float() + bp.float()).half()
+    run = lambda: E.linear(x, wg, c2, ln_c1=c1, act=5)
+    y25 = _with_tile(E, 25, run)
+    y25b = _with_tile(E, 25, run)
+    y9 = _with_tile(E, 9, run)
+    assert torch.equal(y25, y25b)
+    assert_close(y25, want, 1e-3, "feed-forward variant vs torch fp32")
+    assert rel_l2(y25.float(), y9.float()) < 3e-4, rel_l2(y25.float(), y9.float())
+    assert int(E.lib.gn_ppp_timeouts()) == 0

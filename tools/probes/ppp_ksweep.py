@@ -33,5 +33,16 @@ for tile in (15, 25):
         tf = 2.0 * M * N * row[-1][0] / row[-1][1] / 1e6
         print(f"  M={M} N={N}: {tiles} tiles = {rounds:.2f} rounds | " + "  ".join(f"K={k} {u:.1f}" for k, u in row) +
               f" | {slope:.2f} us per 64-wide K tile, intercept {icpt:.1f} us = {icpt / max(rounds, 1):.1f} us per round; {tf:.0f} TF/s at K={row[-1][0]}", flush=True)
+# the feed-forward projections of the B = 8 call (LayerNorm fold + GEGLU): the table's tile, tile 9 and tile 25
+from genima_amd.packing import pack_geglu
+from genima_amd.engine import _tune_table
+for (M, Nh, K) in ((8192, 2560, 640), (2048, 5120, 1280)):
+    x = h(M, K); w = h(2 * Nh, K, sc=K ** -0.5); b = h(2 * Nh); c1 = w.float().sum(1).contiguous()
+    row = []
+    for tile in (0, 9, 25):
+        if tile: E.lib.gn_set_gemm_tile_override(tile - 1); E.no_table = True
+        else: E.lib.gn_set_gemm_tile_override(-1); E.no_table = False
+        row.append((tile, t(lambda: E.linear(x, w, b, ln_c1=c1, act=5))))
+    print(f"FF {M}x{2 * Nh}x{K}: " + "  ".join(f"tile {tl if tl else 'table'} {u:.1f} us ({2.0 * M * 2 * Nh * K / u / 1e6:.0f} TF/s)" for tl, u in row), flush=True)
 E.lib.gn_set_gemm_tile_override(-1)
 print("timeouts", int(E.lib.gn_ppp_timeouts()))
