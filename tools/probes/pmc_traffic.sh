@@ -11,7 +11,7 @@ python - <<'PY'
 import csv, glob, hashlib, json, os
 O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/pmc_traffic"
 STEPS, MARKER = 3, "image_f16_to_u8_kernel"  # the marker kernel closes a pipeline call: exactly one launch per call
-fams = [("gemm", ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_s3_kernel", "gemm_kernel", "gemm_fp8_kernel", "splitk_reduce", "tblock_kernel", "conv3x3_gn_")),
+fams = [("gemm", ("gemm_dma_kernel", "gemm_pp_kernel", "gemm_ppp_kernel", "gemm_s3_kernel", "gemm_kernel", "gemm_fp8_kernel", "splitk_reduce", "tblock_kernel", "conv3x3_gn_")),
         ("attn", ("attn_fwd",)), ("layernorm", ("layernorm_kernel",)), ("gn_stats", ("gn_stats_kernel",)), ("gn_apply", ("gn_apply_kernel",)),
         ("gn_fused", ("gn_fused_kernel",)), ("gn_finalize", ("gn_finalize_kernel",))]
 out = {}
