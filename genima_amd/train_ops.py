@@ -4,6 +4,8 @@ Used by genima_amd/training.py (the ControlNet fine-tune step).  Like engine.py:
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional
 
@@ -53,7 +55,7 @@ def _tuned_tile(E: Engine, d: GemmDesc, out: torch.Tensor) -> int:
     from .engine import _tune_table
     key = E._tune_key(d)
     hit = _tune_table().get(key)
-    if hit is not None:
+    if hit is not None and not (os.environ.get("GN_RETUNE") and key not in E._retuned):  # (GN_RETUNE: re-race the named tiles against the incumbent, once)
         return hit
     scratch = torch.empty_like(out)
     real_out, real_acc = d.out, d.accumulate
