@@ -25,14 +25,17 @@ Tensor = torch.Tensor
 
 def train_forward_backward(unet_sd: Dict[str, Tensor], cn_sd: Dict[str, Tensor], unet_cfg, cn_cfg, latents: Tensor, noise: Tensor,
                            t: Tensor, sqrt_ac: Tensor, sqrt_1mac: Tensor, ctx: Tensor, cond: Tensor,
-                           q: Callable = O._id, added=None) -> Tuple[Tensor, Dict[str, Tensor], Tensor]:
+                           q: Callable = O._id, added=None, prediction_type: str = "epsilon") -> Tuple[Tensor, Dict[str, Tensor], Tensor]:
     """NCHW fp32 inputs.  -> (loss, {name: d loss / d controlnet parameter}, model_pred).
     ``added`` = (text_embeds, time_ids): the SDXL step (diffusion/train_controlnet_sdxl_genima.py:1448-1471) passes them to both nets."""
     params = {k: v.detach().clone().requires_grad_(True) for k, v in cn_sd.items()}
     noisy = q(sqrt_ac.view(-1, 1, 1, 1) * latents + sqrt_1mac.view(-1, 1, 1, 1) * noise)
     down, mid = O.controlnet_forward(params, cn_cfg, noisy, t, ctx, cond, q=q, added=added)
     pred = O.unet_forward(unet_sd, unet_cfg, noisy, t, ctx, down, mid, q=q, added=added)
-    loss = F.mse_loss(pred.float(), noise.float(), reduction="mean")
+    target = noise
+    if prediction_type == "v_prediction":  # noise_scheduler.get_velocity (diffusion/train_controlnet_genima.py:1393-1394)
+        target = q(sqrt_ac.view(-1, 1, 1, 1) * noise - sqrt_1mac.view(-1, 1, 1, 1) * latents)
+    loss = F.mse_loss(pred.float(), target.float(), reduction="mean")
     loss.backward()
     grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in params.items()}
     return loss.detach(), grads, pred.detach()

@@ -157,3 +157,32 @@ def test_overlapped_step_equals_the_serial_step(monkeypatch):
     assert s0[0] < 2.0 ** 30 and o0 >= 1, f"the test wants skipped (overflowed) AND applied steps: scales {s0}, applied {o0}"
     assert l0 == l1 and s0 == s1_ and o0 == o1
     assert torch.equal(m0, m1)
+
+
+def test_v_prediction_target():
+    """prediction_type = "v_prediction" (diffusion/train_controlnet_genima.py:1393-1394: target = noise_scheduler.get_velocity(latents, noise, t)):
+    the step's loss and flat gradient against the oracle's autograd with the velocity target; an unknown type is refused as the reference does."""
+    ucfg, ccfg, usd, csd, lat, noise, ctx, cond, t, sa, s1 = _setup()
+    E = Engine("cuda:0")
+    S = 4096.0
+    tr = ControlNetTrainer(E, ucfg, ccfg, pack_state_dict(usd, "cuda"), csd, lr=1e-4, loss_scale=S)
+    tr.prediction_type = "v_prediction"
+    dev = lambda x: x.cuda()  # noqa: E731
+    args = (dev(nchw_to_nhwc(lat, 8).half()), dev(nchw_to_nhwc(noise, 8).half()), dev(t.float()), dev(sa), dev(s1), dev(ctx.half()),
+            dev(nchw_to_nhwc(cond, 8).half()))
+    loss = float(tr.forward_backward(*args).cpu())
+    layout = list(tr.cn.layout)
+    g_hip = {n: (tr.cn.G[n].float() / S).cpu() for n in layout}
+    l32, g32, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond, prediction_type="v_prediction")
+    l_eps, _, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond)
+    assert abs(float(l32) - float(l_eps)) > 1e-2 * float(l_eps), "the two targets must give different losses for the test to mean anything"
+    assert abs(loss - float(l32)) <= 2e-3 * float(l32), (loss, float(l32))
+    P32 = pack_state_dict(g32, "cpu", dtype=torch.float32)
+    e = rel_l2(_flat(g_hip, layout), _flat(P32, layout))
+    print(f"v_prediction: loss hip {loss:.6f} oracle {float(l32):.6f} (epsilon target: {float(l_eps):.6f}); flat gradient rel-L2 {e:.2e}")
+    assert e <= 1e-2
+
+    class _Sched:
+        config = {"prediction_type": "sample", "num_train_timesteps": 1000}
+    with pytest.raises(ValueError):
+        tr.attach_frozen(None, None, None, None, _Sched())
