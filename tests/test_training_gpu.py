@@ -174,13 +174,15 @@ def test_v_prediction_target():
     layout = list(tr.cn.layout)
     g_hip = {n: (tr.cn.G[n].float() / S).cpu() for n in layout}
     l32, g32, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond, prediction_type="v_prediction")
-    l_eps, _, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond)
-    assert abs(float(l32) - float(l_eps)) > 1e-2 * float(l_eps), "the two targets must give different losses for the test to mean anything"
+    l_eps, g_eps, _ = OT.train_forward_backward(usd, csd, ucfg, ccfg, lat, noise, t.float(), sa, s1, ctx, cond)
     assert abs(loss - float(l32)) <= 2e-3 * float(l32), (loss, float(l32))
-    P32 = pack_state_dict(g32, "cpu", dtype=torch.float32)
+    P32, Peps = pack_state_dict(g32, "cpu", dtype=torch.float32), pack_state_dict(g_eps, "cpu", dtype=torch.float32)
     e = rel_l2(_flat(g_hip, layout), _flat(P32, layout))
-    print(f"v_prediction: loss hip {loss:.6f} oracle {float(l32):.6f} (epsilon target: {float(l_eps):.6f}); flat gradient rel-L2 {e:.2e}")
-    assert e <= 1e-2
+    e_other = rel_l2(_flat(Peps, layout), _flat(P32, layout))
+    print(f"v_prediction: loss hip {loss:.6f} oracle {float(l32):.6f} (epsilon target: {float(l_eps):.6f}); flat gradient rel-L2 {e:.2e} "
+          f"(the epsilon target's gradient is {e_other:.2e} away)")
+    # (random-init networks predict something uncorrelated with either target, so the two LOSSES are nearly equal; the gradients are not)
+    assert e <= 1e-2 and e_other > 10 * e
 
     class _Sched:
         config = {"prediction_type": "sample", "num_train_timesteps": 1000}
