@@ -27,6 +27,21 @@ __global__ __launch_bounds__(512) void k(uint4* out, int N, int rounds) {
             const int col = 32 * wc + 128 * ((q & 1) ^ (q >> 1)) + 16 * g + 8 * hi;
             *reinterpret_cast<uint4*>(base + row * N * 2 + col * 2) = v;
           }
+    } else if (PAT == 2 || PAT == 3) {
+      // round 6: SEG-byte row segments per instruction (PAT 2: 64 B = a wave's own 32 columns after a transpose through LDS, 16 rows per
+      // instruction; PAT 3: 128 B = a whole cache line, 8 rows per instruction): wave (wr, wc) still owns the columns 32 wc + 128 qn of rows 64 wr + 128 qm ..
+      constexpr int LPR = PAT == 2 ? 4 : 8, RPI = 64 / LPR;   // lanes per row, rows per instruction
+      const int wr = wave >> 2, wc = wave & 3;
+      // the wave's 4 quadrants x 64 rows x 64 bytes = 16 KB, as 16 instructions of 1 KB
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int idx = s * RPI + lane / LPR;            // 0 .. 16 * RPI - 1: (quadrant-row index) over 256 row-segments of 64 B (PAT 2) / 128 of 128 B (PAT 3)
+        const int piece = lane % LPR;
+        long row; int colb;
+        if (PAT == 2) { const int q = idx >> 6, r = idx & 63; row = 64 * wr + 128 * (q >> 1) + r; colb = (32 * wc + 128 * ((q & 1) ^ (q >> 1))) * 2 + piece * 16; }
+        else { const int q = idx >> 5, r = idx & 31; row = 64 * wr + 128 * (q >> 1) + 2 * r + (piece >> 2) * 0 + 0; row += (idx & 0) ; colb = (64 * (wc >> 1) + 128 * ((q & 1) ^ (q >> 1))) * 2 + piece * 16; row = 64 * wr + 128 * (q >> 1) + 32 * (wc & 1) + r; }
+        *reinterpret_cast<uint4*>(base + row * N * 2 + colb) = v;
+      }
     } else {
       // 256 rows x 512 bytes: instruction s of wave w writes rows 2 (16 w + s) .. + 1, lane = (row & 1) * 32 + 16-byte piece
 #pragma unroll
@@ -60,6 +75,8 @@ int main() {
   for (int rounds : {1, 4, 16}) {
     run<0>("A: MFMA-fragment stores (32 rows x 32 B)", out, N, rounds);
     run<1>("B: whole rows (2 rows x 512 B)", out, N, rounds);
+    run<2>("C: 64-byte row segments (16 rows x 64 B)", out, N, rounds);
+    run<3>("D: 128-byte row segments (8 rows x 128 B)", out, N, rounds);
   }
   return 0;
 }
