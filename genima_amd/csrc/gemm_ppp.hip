@@ -792,7 +792,6 @@ __global__ __launch_bounds__(512) void gemm_ppp_kernel(const GemmParams p) {
 
 // ---- the flag pool: zero-initialised once per device, self-cleaning afterwards ----------------------------------------------------------------------
 unsigned* g_pool[64] = {};
-std::atomic<unsigned> g_next_region{0};
 
 }  // namespace
 
@@ -862,7 +861,29 @@ void gn_launch_gemm_ppp(const void* params, bool conv, hipStream_t st) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !g_pool[dev]) { (void)gn_ppp_pool_init(dev); }
-  const unsigned region = g_next_region.fetch_add(1) % PPP_REGIONS;
+  // Flag regions.  Only launches that hand partial sums over use their region (a K-split tail, the skewed walk).  A launch being CAPTURED bakes its
+  // region into the graph, which may be replayed at any later time beside anything else: it takes a region of the lower half of the pool for good
+  // (never recycled; once those 512 are gone a captured launch runs without hand-offs: its tail unsplit, correct and slower).  Eager launches rotate
+  // through the upper half: two of them could only collide with 512 flag-using launches in flight between them.
+  static std::atomic<unsigned> next_captured{0}, next_eager{0};
+  unsigned region = 0;
+  const bool needs_flags = p.ppSkew || (p.ppTail > 0 && p.ppS > 1);
+  if (needs_flags) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
+    if (capturing) {
+      const unsigned r = next_captured.fetch_add(1);
+      if (r < PPP_REGIONS / 2) {
+        region = r;
+      } else {  // pool exhausted: no hand-offs in this launch (every tile by one workgroup; the workspace named for the split plan is simply not used)
+        p.ppSkew = 0;
+        p.ppS = 1;
+        p.dS.mul = 1; p.dS.shift = 0;
+      }
+    } else {
+      region = PPP_REGIONS / 2 + next_eager.fetch_add(1) % (PPP_REGIONS / 2);
+    }
+  }
   p.ppflags = g_pool[dev] + PPP_POOL_HEAD + (size_t)region * PPP_REGION;
   p.pptmo = g_pool[dev];
   const dim3 grid(p.ppG);

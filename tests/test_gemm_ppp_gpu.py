@@ -219,3 +219,36 @@ def test_feed_forward_variant_layernorm_fold_and_geglu(M, Nh, K):
     assert_close(y25, want, 1e-3, "feed-forward variant vs torch fp32")
     assert rel_l2(y25.float(), y9.float()) < 3e-4, rel_l2(y25.float(), y9.float())
     assert int(E.lib.gn_ppp_timeouts()) == 0
+
+
+def test_split_tail_inside_a_captured_graph():
+    """A tile-25 launch whose last partial round is split along K (hand-off flags in use) captured into a hipGraph and replayed: the region it took at capture
+    time stays its own (captured launches draw from a never-recycled half of the pool), the flags come back clean after every replay, and eager launches
+    of the same problem in between (rotating through the other half) do not disturb it."""
+    if _ncu() != 256:
+        pytest.skip("tile counts are written for 256 CUs")
+    M, N, K = 20480, 1024, 4096   # 320 tiles: 64 tail tiles, split along K
+    x, w, b = randn_h(M, K, seed=1), randn_h(N, K, seed=2, scale=K ** -0.5), randn_h(N, seed=3)
+    E = Engine("cuda:0")
+    E.autotune = False
+    y_eager = _with_tile(E, 25, lambda: E.linear(x, w, b))
+    side = torch.cuda.Stream()
+    R = Engine("cuda:0", record=True)
+    R.autotune = False
+    R.lib.gn_set_gemm_tile_override(24)
+    try:
+        yr = R.linear(x, w, b, name="y")
+        R.use_stream(side)
+        with torch.cuda.stream(side):
+            R.run(); side.synchronize()
+            R.capture()
+            for _ in range(3):
+                yr.zero_()
+                R.launch(); side.synchronize()
+                assert torch.equal(yr, y_eager)
+                y2 = E.linear(x, w, b)   # (the override is process-wide: this is tile 25 too, eager, on the default stream)
+                E.synchronize()
+                assert torch.equal(y2, y_eager)
+    finally:
+        R.lib.gn_set_gemm_tile_override(-1)
+    assert int(R.lib.gn_ppp_timeouts()) == 0
