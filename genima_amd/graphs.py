@@ -14,6 +14,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from ._lib import ACT_GEGLU, ACT_GELU, ACT_NONE, ACT_QUICK_GELU, ACT_RELU, ACT_SILU, ACT_TANH3
@@ -129,6 +131,18 @@ def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[
     B, L, _ = ctx.shape
     kv = {}
     sites = [name[: -len(".to_k.weight")] for name in W if name.endswith(".attn2.to_k.weight")]
+    offs = (W.get("__meta__") or {}).get("cross_kv") if hasattr(W, "get") else None
+    if (offs and "cross_kv_all.weight" in W and getattr(E, "kv_all", os.environ.get("GN_KV_ALL", "1") != "0") and not E._fp8_weights
+            and all(q in offs and offs[q][1] % 64 == 0 for q in sites)):
+        # ONE launch for the whole network: [B, L, sum 2 C] = ctx @ [to_k ; to_v ; to_k ; ...]^T (packing `cross_kv_all`); a layer's K and V are column
+        # slices of it (row stride = the full width), V row-major: the attention kernel transposes it out of its LDS tile (gn_attn_desc.v_rowmajor,
+        # head dim 64 -- every SD / SDXL head), bit-identical to the V^T path at 77 keys
+        with E.scope(tag):
+            allkv = E.linear(ctx, W["cross_kv_all.weight"], name="kv_all")
+        for q in sites:
+            o, c = offs[q]
+            kv[q] = (allkv[:, :, o:o + c], allkv[:, :, o + c:o + 2 * c], True)
+        return kv
     pad = _rup(L, 64)
     with E.zero_pool(sum(B * W[p + ".to_v.weight"].shape[0] * pad + 64 for p in sites) if pad != L else 0):  # (eager engines: one fill for all V^T)
         for p in sites:
@@ -137,6 +151,15 @@ def emit_cross_kv(E: Engine, W, ctx: torch.Tensor, tag: str) -> Dict[str, Tuple[
                 vt = E.linear(ctx, W[p + ".to_v.weight"], transposed_out=True, rows_per_batch=L, pad_cols=pad, name="vt")
             kv[p] = (k, vt)
     return kv
+
+
+def _cross_attention(E: Engine, q, kvp, heads: int):
+    """attn2 against the hoisted prompt projections: (K, V^T) of emit_cross_kv's per-layer launches, or (K, V, True) = column slices of its one
+    combined launch (V row-major)."""
+    ck, cv = kvp[0], kvp[1]
+    if len(kvp) > 2 and kvp[2]:
+        return E.attention(q, ck, cv, heads, Nk=ck.shape[1], v_rowmajor=True, name="ca")
+    return E.attention(q, ck, cv, heads, Nk=ck.shape[1], name="ca")
 
 
 def _ln_fold(E: Engine, W, lin: str):
@@ -173,8 +196,7 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     _, qk, vt = front
                     a = E.attention(qk[:, :, :Cc], qk[:, :, Cc:], vt, heads, name="sa")
                     h1, q = E.tblock_mid(a, h, W[b + ".tblock_mid.tape"], name="mid")
-                    ck, cvt = kv[b + ".attn2"]
-                    a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                    a = _cross_attention(E, q, kv[b + ".attn2"], heads)
                     out = E.tblock_tail(a, h1, x.view(B, N, Cc), W[b + ".tblock_tail.tape"], name="tail")
                     return out.view(B, H, Wd, Cc)
                 # LayerNorm folded into the consuming Linear where the packed dict carries the folded weights (packing.fold_layernorms):
@@ -206,8 +228,7 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                     # attn1.to_out .. attn2.to_q and attn2.to_out .. proj_out as TWO launches that keep their rows of the residual stream in
                     # LDS and stream the weights from a tape (csrc/tblock.hip) instead of six gn_gemm launches
                     h1, q = E.tblock_mid(a, h, W[b + ".tblock_mid.tape"], name="mid")
-                    ck, cvt = kv[b + ".attn2"]
-                    a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                    a = _cross_attention(E, q, kv[b + ".attn2"], heads)
                     out = E.tblock_tail(a, h1, x.view(B, N, Cc), W[b + ".tblock_tail.tape"], name="tail")
                     return out.view(B, H, Wd, Cc)
                 h = E.linear(a, W[b + ".attn1.to_out.0.weight"], W[b + ".attn1.to_out.0.bias"], residual=h, name="sao")
@@ -217,8 +238,7 @@ def emit_transformer(E: Engine, W, p: str, x, kv, heads: int, groups: int):
                 else:
                     n = E.layernorm(h, W[b + ".norm2.weight"], W[b + ".norm2.bias"], name="ln2")
                     q = E.linear(n, W[b + ".attn2.to_q.weight"], name="cq")
-                ck, cvt = kv[b + ".attn2"]
-                a = E.attention(q, ck, cvt, heads, Nk=ck.shape[1], name="ca")
+                a = _cross_attention(E, q, kv[b + ".attn2"], heads)
                 h = E.linear(a, W[b + ".attn2.to_out.0.weight"], W[b + ".attn2.to_out.0.bias"], residual=h, name="cao")
                 fold = _ln_fold(E, W, b + ".ff.net.0.proj")
                 if fold:

@@ -407,6 +407,18 @@ def pack_state_dict(sd: Dict[str, torch.Tensor], device, dtype=torch.float16, up
         fold_layernorms(out, hip)
         add_tblock_tapes(out, hip)
     meta = {}
+    # every cross-attention layer's to_k | to_v stacked along N: the prompt's K / V projections of a whole network as ONE launch (graphs.emit_cross_kv;
+    # 14 + 32 launches of M = 77 B rows otherwise).  Inference dicts; sites in dict order, (offset, C) per site in the meta.
+    if dtype == torch.float16:
+        sites = [n[: -len(".to_k.weight")] for n in out if n.endswith(".attn2.to_k.weight") and n[: -len("to_k.weight")] + "to_v.weight" in out]
+        if sites and len({out[q + ".to_k.weight"].shape[1] for q in sites}) == 1:
+            offs, o = OrderedDict(), 0
+            for q in sites:
+                c = out[q + ".to_k.weight"].shape[0]
+                offs[q] = (o, c)
+                o += 2 * c
+            out["cross_kv_all.weight"] = torch.cat([t.to(out[sites[0] + ".to_k.weight"].device) for q in sites for t in (out[q + ".to_k.weight"], out[q + ".to_v.weight"])], dim=0).contiguous()
+            meta["cross_kv"] = offs
     if temb_w:
         out["time_emb_proj_all.weight"] = torch.cat(temb_w, dim=0).to(dtype).contiguous()
         out["time_emb_proj_all.bias"] = torch.cat(temb_b, dim=0).to(dtype).contiguous()
