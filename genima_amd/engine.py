@@ -153,6 +153,9 @@ class Engine:
         # one workgroup per (sample, group) slab gathers the partial slabs: it needs the slabs to fill the chip (B = 8: 256 workgroups; at B = 1 the
         # 32 of them lose to the parallel reduce + GroupNorm pair: 1024 x 640 x 5760 49 vs 29 + 12 us, profiles/r05_v7_reduce_gn_ops_*)
         self.gn_reduce_fuse_min_slabs = int(os.environ.get("GN_REDUCE_FUSE_MIN_SLABS", "128"))
+        # ... except at the deepest latent levels (rows per sample <= this): there a slab is a few KB, the gather is short, and the GroupNorm launch it
+        # replaces is pure latency (7 - 8 us each at B = 1: 185 launches of the tiled call at the 8 x 8 / 16 x 16 levels)
+        self.gn_reduce_fuse_small_hw = int(os.environ.get("GN_REDUCE_FUSE_SMALL_HW", "0"))
         self._writer: Dict[int, _Writer] = {}
         self._stats_arena = None
         self._stats_used = 0
@@ -977,7 +980,7 @@ class Engine:
     def _norm_out(self, x, gamma, beta, groups, eps, act, out, B, HW, Cc) -> bool:
         """Recorded programs: move this GroupNorm (+ activation) into the split-K reduce of the gn_gemm that wrote x (gn_gemm_desc.norm_out).
         -> done?  (No: x was not written by a K-split launch of this program, is also being normalised elsewhere, or the slab does not fit.)"""
-        if not (self.record and self.gn_reduce_fuse) or B * groups < self.gn_reduce_fuse_min_slabs:
+        if not (self.record and self.gn_reduce_fuse) or (B * groups < self.gn_reduce_fuse_min_slabs and HW > self.gn_reduce_fuse_small_hw):
             return False
         w = self._writer.get(x.data_ptr())
         if w is None or not w.gemm or w.sunk or w.rdiv != 1 or w.numel != x.numel() or not x.is_contiguous() or not out.is_contiguous():
