@@ -155,7 +155,7 @@ class Engine:
         self.gn_reduce_fuse_min_slabs = int(os.environ.get("GN_REDUCE_FUSE_MIN_SLABS", "128"))
         # ... except at the deepest latent levels (rows per sample <= this): there a slab is a few KB, the gather is short, and the GroupNorm launch it
         # replaces is pure latency (7 - 8 us each at B = 1: 185 launches of the tiled call at the 8 x 8 / 16 x 16 levels)
-        self.gn_reduce_fuse_small_hw = int(os.environ.get("GN_REDUCE_FUSE_SMALL_HW", "0"))
+        self.gn_reduce_fuse_small_hw = int(os.environ.get("GN_REDUCE_FUSE_SMALL_HW", "64"))  # measured: profiles/r06_v4_gn_small_hw_ab.txt (single view 19.8 -> 19.3 ms, tiled B = 1 30.5 -> 30.2; 256 / 1024 lose on the tiled call)
         self._writer: Dict[int, _Writer] = {}
         self._stats_arena = None
         self._stats_used = 0
