@@ -93,6 +93,10 @@ def pmc_traffic_stamp():
             st = json.load(f).get("stamp", {})
         with open(os.path.join(ROOT, "genima_amd", "libgenima_hip.so"), "rb") as f:
             st["same_library_as_this_run"] = hashlib.sha256(f.read()).hexdigest()[:16] == st.get("lib_sha16")
+        # a rebuilt .so differs byte-wise from box to box; the hash of csrc/ + compile flags names the code itself
+        from genima_amd.build import source_sha16
+
+        st["same_sources_as_this_run"] = source_sha16() == st.get("src_sha16")
         return st
     except OSError:
         return None

@@ -38,6 +38,19 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def source_sha16() -> str:
+    """Hash of every file under csrc/ plus the compile flags: names the library's CODE independently of where / when it was built (a
+    rebuilt .so differs byte-wise from box to box; bench.py matches committed PMC traffic files to the running code through this)."""
+    import hashlib
+
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for n in sorted(os.listdir(CSRC)):
+        if n.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, n), "rb") as f:
+                h.update(n.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")

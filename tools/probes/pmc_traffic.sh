@@ -44,6 +44,7 @@ g = out["FETCH_SIZE"]["gemm"], out["WRITE_SIZE"]["gemm"]
 assert g[0]["launches"] == g[1]["launches"], (g[0]["launches"], g[1]["launches"])
 out["stamp"] = {"commit": os.environ.get("GIT_COMMIT", "unknown"),
                 "lib_sha16": hashlib.sha256(open(root + "/genima_amd/libgenima_hip.so", "rb").read()).hexdigest()[:16],
+                "src_sha16": __import__("genima_amd.build", fromlist=["source_sha16"]).source_sha16(),
                 "calls": STEPS, "gemm_launches_per_call": g[0]["launches"] / STEPS, "gemm_ops_per_call": g[0]["ops"] / STEPS,
                 "command": "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-act --no-train --no-single-view; dispatches of the 3 timed calls (cut at image_f16_to_u8_kernel)"}
 json.dump(out, open(O + "/traffic.json", "w"), indent=1)
