@@ -105,6 +105,7 @@ class Engine:
         self.k_append = os.environ.get("GN_K_APPEND", "1") != "0"
         self.k_append_min_rows = int(os.environ.get("GN_K_APPEND_MIN_ROWS", "0"))
         self.add_multi_on = os.environ.get("GN_ADD_MULTI", "1") != "0"  # graphs: the UNet's skip + ControlNet-residual adds as one launch
+        self.zero_conv_split = os.environ.get("GN_ZERO_CONV_SPLIT", "1") != "0"  # deferred zero convs on both streams while the side stream is free
         self.side_free_max_rows = int(os.environ.get("GN_SIDE_FREE_MAX_ROWS", "4096"))  # decoder shortcuts on the idle side stream up to this many latent rows
         self.tblock = os.environ.get("GN_TBLOCK", "1") != "0"  # graphs: fused transformer-block chains at C = 320 (csrc/tblock.hip; A/B switch)
         # one workgroup per 128 rows streams the chain's whole weight tape: it pays once the rows fill the chip (tools/bench_tblock.py on MI355X:

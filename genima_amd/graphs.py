@@ -309,7 +309,9 @@ def emit_unet(E: Engine, W, cfg, x8: torch.Tensor, t_dev: torch.Tensor, kv, down
             before_residuals()
             E.side_free = x8.shape[0] * x8.shape[1] * x8.shape[2] <= getattr(E, "side_free_max_rows", 4096)  # the caller joined its side stream: free for the decoder at small batch
         # the residual adds only feed the decoder, so they sit after the mid block (same values; lets the encoder + mid overlap the ControlNet)
-        if down_res is not None and mid_res is not None and len(skips) < 16 and getattr(E, "add_multi_on", True):
+        if callable(down_res):  # emit_controlnet(defer_zero_convs=True): the zero convs run HERE with the skip as their residual operand (no add launch)
+            skips, h = down_res(skips, h)
+        elif down_res is not None and mid_res is not None and len(skips) < 16 and getattr(E, "add_multi_on", True):
             outs = E.add_multi(list(zip(skips, down_res)) + [(h, mid_res)], name="res_add")  # thirteen adds, one launch (gn_add_multi)
             skips, h = outs[:-1], outs[-1]
         else:
@@ -344,14 +346,37 @@ def emit_controlnet_cond(E: Engine, W, cfg, cond8: torch.Tensor) -> torch.Tensor
 
 
 def emit_controlnet(E: Engine, W, cfg, x8, t_dev, kv, cond_emb: torch.Tensor, conditioning_scale: float = 1.0, added=None,
-                    shifts: Optional[torch.Tensor] = None):
-    """-> (list of down residuals (12 for SD-2.x, 9 for SDXL), mid residual), NHWC."""
+                    shifts: Optional[torch.Tensor] = None, defer_zero_convs: bool = False):
+    """-> (list of down residuals (12 for SD-2.x, 9 for SDXL), mid residual), NHWC.
+    ``defer_zero_convs``: -> (fn, None) instead; fn(unet_skips, unet_h) -> (skips, h) emits the zero convs (controlnet_down_blocks.* /
+    controlnet_mid_block, 1x1) with the UNet's skip / mid tensor as their residual operand -- diffusers' ``sample + residual`` adds
+    (UNet2DConditionModel.forward: down_block_res_samples + down_block_additional_residuals, mid_block_additional_residual) ride in the zero
+    convs' epilogues -- and, while the side stream is free (a small batch, after the join), deals them over both streams."""
     with E.scope("cn"):
         if shifts is None:
             shifts = emit_time_shifts(E, W, cfg, t_dev, added)
         h = E.conv2d(x8, W["conv_in.weight"], W["conv_in.bias"], residual=cond_emb, name="conv_in")
         h, skips = _emit_encoder(E, W, cfg, h, shifts, kv)
         h = _emit_mid(E, W, cfg, h, shifts, kv)
+        if defer_zero_convs:
+            cn_skips, cn_h = skips, h
+
+            def residuals(un_skips, un_h):
+                jobs = [(f"controlnet_down_blocks.{i}", s, u) for i, (s, u) in enumerate(zip(cn_skips, un_skips))] + [("controlnet_mid_block", cn_h, un_h)]
+                two = bool(getattr(E, "side_free", False)) and E.record and getattr(E, "zero_conv_split", True)
+                order = [j for k, j in enumerate(jobs) if k % 2 == 1] + [j for k, j in enumerate(jobs) if k % 2 == 0] if two else jobs
+                res = {}
+                with E.scope("cn"):
+                    if two:
+                        E.fork()
+                    for k, (p, s, u) in enumerate(order):
+                        if two and k == len(jobs) // 2:
+                            E.main()
+                        res[p] = E.conv2d(s, W[p + ".weight"], W[p + ".bias"], ksize=1, out_scale=conditioning_scale, residual=u, name=p)
+                    if two:
+                        E.join()
+                return [res[p] for p, _, _ in jobs[:-1]], res[jobs[-1][0]]
+            return residuals, None
         outs = []
         for i, s in enumerate(skips):
             p = f"controlnet_down_blocks.{i}"

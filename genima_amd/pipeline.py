@@ -101,6 +101,8 @@ class StableDiffusionControlNetPipeline:
         self._progs = {}
         self.use_graph = False
         self.two_streams = os.environ.get("GN_TWO_STREAMS", "1") != "0"  # ControlNet || UNet encoder inside each denoise step
+        # the ControlNet's zero convs behind the join, the UNet's skip as their residual operand (no add launch), dealt over both streams at small batch
+        self.zero_convs_fused = os.environ.get("GN_ZERO_CONV_FUSED", "1") != "0"
         self._progress = True
 
     # ---- construction ----------------------------------------------------------------------------------------------
@@ -253,7 +255,8 @@ class StableDiffusionControlNetPipeline:
             # joined where the UNet consumes its residuals (fills the CUs the small-M deep-level kernels leave idle)
             if self.two_streams:
                 E.fork()
-            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0, added=added, shifts=s_cn)
+            down, mid = graphs.emit_controlnet(E, self.controlnet.W, self.controlnet.config, x8, t_dev, kv_cn, cemb, 1.0, added=added, shifts=s_cn,
+                                               defer_zero_convs=self.zero_convs_fused)
             if self.two_streams:
                 E.main()
             eps = graphs.emit_unet(E, self.unet.W, self.unet.config, x8, t_dev, kv_un, down, mid, added=added,
