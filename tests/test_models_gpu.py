@@ -225,3 +225,41 @@ def test_pipeline_end_to_end(graph):
     # PIL surface + determinism of a second call (same injected latents)
     out2 = pipe(prompt_ids=ids, image=img_u8, num_inference_steps=steps, guidance_scale=0.0, latents=lat.half())
     assert out2[0][0].size == (128, 128) and np.array_equal(np.asarray(out2.images[1]), u8[1])
+
+
+def test_zero_convs_fused_behind_the_join_match_the_add_launch():
+    """The ControlNet's zero convs with the UNet's skip / mid tensor as residual operand (default; dealt over both streams at small batch) against the
+    round-5 route (13 zero convs on the ControlNet's stream + one gn_add_multi launch): same latents within two f16 roundings of the skip tensors,
+    no add launch in the program, every zero conv carries a residual.  Reference: UNet2DConditionModel.forward's
+    down_block_res_samples + down_block_additional_residuals / mid_block_additional_residual, called from `self.pipe(...)`
+    (controller/agent/sd_controlnet_agent.py:67-76)."""
+    from genima_amd.pipeline import StableDiffusionControlNetPipeline
+
+    B, steps = 2, 2
+    img_u8 = torch.from_numpy(weights.counter_bytes(3, "ctrl", B * 128 * 128 * 3).reshape(B, 128, 128, 3))
+    lat = q16(torch.randn(B, 4, 16, 16, generator=torch.Generator().manual_seed(2)))
+    lats, kinds = [], []
+    for fused, split in ((False, True), (True, False), (True, True)):
+        pipe = StableDiffusionControlNetPipeline.from_synthetic(FAM, seed=20)
+        pipe.to("cuda")
+        pipe.zero_convs_fused = fused
+        ids = pipe.encode_ids(["open the box"] * B)
+        prog = None
+        import genima_amd.engine as eng
+        old = eng.Engine.__init__
+
+        def init(self, *a, _old=old, _split=split, **k):
+            _old(self, *a, **k)
+            self.zero_conv_split = _split
+        eng.Engine.__init__ = init
+        try:
+            pipe(prompt_ids=ids, image=img_u8, num_inference_steps=steps, guidance_scale=0.0, latents=lat.half(), output_type="np")
+            prog = pipe.program(B, 128, 128, steps)
+        finally:
+            eng.Engine.__init__ = old
+        lats.append(prog.latents.float().cpu().clone())
+        kinds.append([m["kind"] for m in prog.engine.meta])
+    assert "add_multi" in kinds[0] and "add_multi" not in kinds[1] and "add_multi" not in kinds[2]
+    assert kinds[2].count("stream") > kinds[1].count("stream"), "the split route forks the side stream once more per step"
+    assert torch.equal(lats[1], lats[2]), "dealing the zero convs over two streams changes no value"
+    assert rel_l2(lats[1], lats[0]) < 2e-3, rel_l2(lats[1], lats[0])
