@@ -9,6 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ABI_VERSION = 101  # gn_version() of the library this binding was written against (csrc/api.hip)
 LIB_PATH = os.path.join(HERE, "libgenima_hip.so")
 if os.environ.get("GN_LIB_PATH"):  # same-box A/B of library builds (tools/probes): an explicit path to another libgenima_hip.so
     LIB_PATH = os.environ["GN_LIB_PATH"]

@@ -28,7 +28,7 @@ def test_library_builds_and_exports_header_symbols():
 
 def test_loader_binds_and_reports_version():
     lib = _lib.load()
-    assert lib.gn_version() == 101
+    assert lib.gn_version() == 101 == _lib.ABI_VERSION
     # 8 pointers, 8 int64, 20 int32 + float, batch/batch_inner (+pad to 8), 8 int64 batch strides, accumulate + fp8, 2 scale pointers,
     # out2 + ldo2 + split_n + ln_eps, ln_c1, out_row_width (+pad) + ldo_hi, up_phases (+tail pad)
     base = 8 * 8 + 8 * 8 + 24 * 4 + 8 * 8 + 8 + 2 * 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8  # ... k_append in up_phases' tail pad, a3, C3 (+pad), lda2
@@ -68,3 +68,18 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f"{f} imports the oracle"
+
+
+def test_driver_entry_point_builds():
+    """__graft_entry__.build() is what the driver runs on CPU each round: it must build (a no-op when the library is current), load the library,
+    accept its version and import the package + the oracle modules."""
+    import importlib
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
+    assert callable(entry.smoke)
