@@ -330,14 +330,19 @@ class Engine:
     def apply_plan(d: GemmDesc, plan: int):
         """A tune-table value is ``tile + 100 * splitk`` (splitk 0 = the library's heuristic for that tile)."""
         d.tile, d.splitk = int(plan) % 100, int(plan) // 100
+        cap = int(os.environ.get("GN_PROBE_SPLITK_CAP", "0"))  # probe: 1 = never split K, n = at most n slices where the table names more
+        if cap == 1 or (cap > 1 and d.splitk > cap):
+            d.splitk = cap
 
     def _autotune(self, d: GemmDesc, key: Optional[str] = None) -> int:
         """-> the plan (``tile + 100 * splitk``) of this problem: from the table, or measured now and remembered."""
         key = key or self._tune_key(d)
         table = _tune_table()
         challengers = [int(c) for c in os.environ.get("GN_RETUNE", "").split(",") if c.strip()]  # e.g. GN_RETUNE=15: race new tiles
-        if key in table and not (challengers and key not in self._retuned):                       # against each shape's incumbent
+        sk_chal = [int(c) for c in os.environ.get("GN_RETUNE_SK", "").split(",") if c.strip()]      # e.g. GN_RETUNE_SK=10,12,16: race deeper K splits
+        if key in table and not ((challengers or sk_chal) and key not in self._retuned):          # against each shape's incumbent
             return table[key]
+        resplit = key in table and bool(sk_chal)
         cands = (1, 2, 5, 6, 7, 8, 9, 12, 16, 19, 25) if d.act == ACT_GEGLU else range(1, self.N_TILE_CFGS + 1)
         if key in table:
             self._retuned.add(key)
@@ -391,7 +396,7 @@ class Engine:
             if 15 in cands and 15 not in tiles and d.K >= 2048 and d.K % 64 == 0 and pp_blocks < 128 and not d.norm_in.stats:
                 tiles.append(15)
             for tile in tiles:
-                for sk in (1, 2, 3, 4, 5, 6, 8):
+                for sk in (sk_chal if resplit else (1, 2, 3, 4, 5, 6, 8)):
                     if sk * 512 > d.K or tile + 100 * sk == best or (tile == 15 and tile != tiles[0] and not 128 < pp_blocks * sk <= 256):
                         continue
                     ms = race(tile + 100 * sk)
