@@ -41,10 +41,10 @@ __device__ __forceinline__ int tn_swz(int row) {
   else return ((row >> 1) & 1) << 2;              // 128-byte rows: odd rows already sit on the other half of the banks
 }
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256, gemm_waves_per_simd(2 * (BM + BN) * 128, 4)) void gemm_tn_kernel(const TnParams tp) {
+template <int BM, int BN, bool CONV, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(WM* WN * 64, gemm_waves_per_simd(2 * (BM + BN) * 128, WM* WN)) void gemm_tn_kernel(const TnParams tp) {
   const GemmParams& p = tp.g;
-  constexpr int NW = 4, WM = 2, WN = 2;
+  constexpr int NW = WM * WN;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
   constexpr int CPA = BM / 8, CPB = BN / 8;            // 16-byte chunks per LDS row
   constexpr int RPA = 64 / CPA, RPB = 64 / CPB;        // rows one DMA instruction (64 lanes x 16 B) fills
@@ -270,6 +270,10 @@ TnPlan tn_plan(const gn_wgrad_desc* d) {
   TnPlan pl;
   const bool small = d->tile == 2 || (d->tile == 0 && (d->N < 128 || d->K < 128));
   pl.bm = pl.bn = small ? 64 : 128;
+  // tile 3 (round 6): 128 x 256 on eight waves of 64 x 64 -- one workgroup per CU (96 KB of LDS), a third more multiply-adds per byte moved into LDS than
+  // 128 x 128; for the wide weight gradients (K = 9 C columns of a 3x3 conv, the feed-forward projections)
+  if (d->tile == 3 && d->N >= 128 && d->K >= 256) pl.bn = 256;
+  if (d->tile == 4 && d->N >= 256 && d->K >= 128) pl.bm = 256;  // 256 x 128: the same for tall gradients (N = 640 / 1280 rows are whole tiles)
   const long blocks = ((d->N + pl.bm - 1) / pl.bm) * ((d->K + pl.bn - 1) / pl.bn);
   int sk = d->splitk;
   if (sk <= 0) {  // a handful of output tiles under a reduction over every pixel of the batch: the row split supplies the parallelism
@@ -340,7 +344,13 @@ extern "C" int32_t gn_wgrad(gn_ctx* ctx, const gn_wgrad_desc* d) {
   tp.sums_ws = want_sums ? (float*)d->workspace + (pl.splitk > 1 ? (int64_t)pl.splitk * d->N * d->K : 0) : nullptr;
   p.tiles_m = (int)((d->N + pl.bm - 1) / pl.bm); p.tiles_n = (int)((d->K + pl.bn - 1) / pl.bn);
   const dim3 grid(p.tiles_m * p.tiles_n, pl.splitk, 1);
-  if (pl.bm == 128) {
+  if (pl.bn == 256) {
+    if (d->conv) hipLaunchKernelGGL((gemm_tn_kernel<128, 256, true, 2, 4>), grid, dim3(512), 0, ctx->stream, tp);
+    else hipLaunchKernelGGL((gemm_tn_kernel<128, 256, false, 2, 4>), grid, dim3(512), 0, ctx->stream, tp);
+  } else if (pl.bm == 256) {
+    if (d->conv) hipLaunchKernelGGL((gemm_tn_kernel<256, 128, true, 4, 2>), grid, dim3(512), 0, ctx->stream, tp);
+    else hipLaunchKernelGGL((gemm_tn_kernel<256, 128, false, 4, 2>), grid, dim3(512), 0, ctx->stream, tp);
+  } else if (pl.bm == 128) {
     if (d->conv) hipLaunchKernelGGL((gemm_tn_kernel<128, 128, true>), grid, dim3(256), 0, ctx->stream, tp);
     else hipLaunchKernelGGL((gemm_tn_kernel<128, 128, false>), grid, dim3(256), 0, ctx->stream, tp);
   } else {

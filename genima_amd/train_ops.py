@@ -111,8 +111,10 @@ def wgrad(E: Engine, dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, *, ksi
         from .engine import _tune_table
         key = f"wg|{int(d.conv)}|{R}|{N}|{int(d.K)}|{int(d.C)}|{int(d.KH)}|{int(d.stride)}"
         plan = _tune_table().get(key)
-        if plan is None and E.autotune:
-            plan = _tune_wgrad(E, d, dw, key)
+        retune = os.environ.get("GN_RETUNE_WGRAD")  # e.g. GN_RETUNE_WGRAD=3,4: race the named tiles against the incumbent, once per shape
+        if E.autotune and (plan is None or (retune and key not in E._retuned)):
+            E._retuned.add(key)
+            plan = _tune_wgrad(E, d, dw, key, incumbent=plan, tiles=[int(t) for t in retune.split(",")] if (retune and plan is not None) else None)
         if plan:
             d.tile, d.splitk = plan % 100, plan // 100
     _run_wgrad(E, d)
@@ -125,8 +127,8 @@ def _run_wgrad(E: Engine, d: WgradDesc):
     check(E.lib.gn_wgrad(E._ctx, C.byref(d)), "gn_wgrad")
 
 
-def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str) -> int:
-    """Race the two tiles and a few row splits of gn_wgrad on this shape (into a scratch copy of dw) and remember the winner in the
+def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str, incumbent=None, tiles=None) -> int:
+    """Race the tiles (or ``tiles`` against ``incumbent``: GN_RETUNE_WGRAD) and a few row splits of gn_wgrad on this shape (into a scratch copy of dw) and remember the winner in the
     GEMM tune table (value = tile + 100 * row split, split 0 = the library's heuristic)."""
     from . import engine as _eng
     real, real_sums = d.dw, (d.dbias, d.dshift)
@@ -135,21 +137,24 @@ def _tune_wgrad(E: Engine, d: WgradDesc, dw: torch.Tensor, key: str) -> int:
     best, best_ms = 0, float("inf")
     e0, e1 = E.event(), E.event()
     try:
-        for tile in (1, 2):
-            for sk in (0, 64, 32, 16, 8):
-                if sk and sk * 512 > d.R:
-                    continue
-                d.tile, d.splitk = tile, sk
-                _run_wgrad(E, d)
-                ms = float("inf")
-                for _ in range(2):
-                    E.event_record(e0)
-                    for _ in range(3):
-                        _run_wgrad(E, d)
-                    E.event_record(e1)
-                    ms = min(ms, E.event_elapsed_ms(e0, e1))
-                if ms < best_ms:
-                    best, best_ms = tile + 100 * sk, ms
+        plans = [t + 100 * sk for t in (tiles or (1, 2, 3, 4)) for sk in (0, 64, 32, 16, 8)]
+        if incumbent is not None:
+            plans = [int(incumbent)] + [q for q in plans if q != int(incumbent)]
+        for plan in plans:
+            tile, sk = plan % 100, plan // 100
+            if (sk and sk * 512 > d.R) or (tile == 3 and (d.N < 128 or d.K < 256)) or (tile == 4 and (d.N < 256 or d.K < 128)):
+                continue
+            d.tile, d.splitk = tile, sk
+            _run_wgrad(E, d)
+            ms = float("inf")
+            for _ in range(2):
+                E.event_record(e0)
+                for _ in range(3):
+                    _run_wgrad(E, d)
+                E.event_record(e1)
+                ms = min(ms, E.event_elapsed_ms(e0, e1))
+            if ms < (best_ms if incumbent is None or best == 0 else 0.97 * best_ms):  # a challenger must beat the incumbent by 3 %
+                best, best_ms = tile + 100 * sk, ms
     finally:
         d.dw, (d.dbias, d.dshift) = real, real_sums
         E.lib.gn_event_destroy(e0)

@@ -482,7 +482,7 @@ typedef struct gn_wgrad_desc {
   int64_t R, N, K;       /* K = columns of dw (conv: KH*KW*C) */
   int64_t ld_dy, ld_x, ld_dw;
   int32_t conv, B, H, W, C, KH, KW, stride, pad, Ho, Wo;
-  int32_t tile;          /* 0 = heuristic, 1 = 128x128, 2 = 64x64 */
+  int32_t tile;          /* 0 = heuristic, 1 = 128x128, 2 = 64x64, 3 = 128x256, 4 = 256x128 on eight waves (N / K at least a tile; else 128x128) */
   int32_t splitk;        /* 0 = heuristic */
   float* dbias;          /* optional f32 [N] += column sums of dy (the bias gradient), from the fragments the kernel loads anyway */
   float* dshift;         /* optional f32 [shift_groups, N] += column sums per block of R / shift_groups rows (per-sample time-shift gradient) */

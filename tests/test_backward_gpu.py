@@ -327,7 +327,8 @@ def test_transpose_with_column_sums(engine, rows, cols, groups):
     assert torch.equal(xt2, xt)
 
 
-@pytest.mark.parametrize("R,N,K,tile", [(4096, 320, 320, 0), (1000, 136, 72, 0), (8192, 1280, 320, 1), (777 * 8, 64, 640, 2), (32768, 320, 1280, 0)])
+@pytest.mark.parametrize("R,N,K,tile", [(4096, 320, 320, 0), (1000, 136, 72, 0), (8192, 1280, 320, 1), (777 * 8, 64, 640, 2), (32768, 320, 1280, 0),
+                                        (8192, 1280, 320, 3), (32768, 320, 1280, 3), (777 * 8, 136, 264, 3), (8192, 1280, 320, 4), (4096, 320, 328, 4)])  # 128 x 256 / 256 x 128 on eight waves
 def test_wgrad_linear_natural_layout(engine, R, N, K, tile):
     """gn_wgrad (csrc/gemm_tn.hip): dW += dY^T X from row-major dY [R, N] and X [R, K] -- LDS transpose reads instead of transposed copies
     -- against an fp64 torch product of the same f16 inputs; accumulation into existing f32 values; ragged R / N / K tails."""
@@ -371,6 +372,11 @@ def test_wgrad_conv_natural_layout(engine, B, H, C, N, ks, stride):
     dw = torch.zeros(N, ks * ks * C, device="cuda")
     T.wgrad(engine, h(nhwc(dy)), h(nhwc(x)), dw, ksize=ks, stride=stride, pad=ks // 2)
     assert_close(dw, ref, rel=5e-4, what=f"conv wgrad {C}->{N} k{ks} s{stride}")
+    for tile in (3, 4):  # the eight-wave tiles (128 x 256, 256 x 128) where the gradient is at least one tile wide / tall
+        if (tile == 3 and N >= 128 and ks * ks * C >= 256) or (tile == 4 and N >= 256 and ks * ks * C >= 128):
+            dw = torch.zeros(N, ks * ks * C, device="cuda")
+            T.wgrad(engine, h(nhwc(dy)), h(nhwc(x)), dw, ksize=ks, stride=stride, pad=ks // 2, tile=tile)
+            assert_close(dw, ref, rel=5e-4, what=f"conv wgrad {C}->{N} k{ks} s{stride} tile {tile}")
 
 
 def test_transpose2d_multi_matches_single_launches(engine):

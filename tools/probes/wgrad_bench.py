@@ -16,7 +16,7 @@ for (R, N, K) in ((32768, 320, 320), (8192, 640, 640), (2048, 1280, 1280), (3276
         dyt = T.transpose2d(E, dy, R, N); xt = T.transpose2d(E, x, R, K)
         T.gemm(E, dyt, xt, dw, N, K, dyt.shape[1], dyt.shape[1], dyt.shape[1], K, f32_out=True, accumulate=True)
     fl = 2.0 * R * N * K
-    for tile in (1, 2):
+    for tile in (1, 2, 3, 4):
         us = t(lambda: T.wgrad(E, dy, x, dw, tile=tile))
         print(f"linear R={R} N={N} K={K} tile {tile}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s", flush=True)
     us = t(old); print(f"linear R={R} N={N} K={K} old   : {us:8.1f} us {fl/us/1e6:7.1f} TF/s", flush=True)
@@ -27,8 +27,7 @@ for (B, H, C, N) in ((8, 64, 320, 320), (8, 32, 640, 640), (8, 16, 1280, 1280), 
         dyt = T.transpose2d(E, dy.view(R, N), R, N); cols = T.im2col_t(E, x, 3, 1, 1)
         T.gemm(E, dyt, cols, dw, N, 9 * C, R, R, R, 9 * C, f32_out=True, accumulate=True)
     fl = 2.0 * R * N * 9 * C
-    for tile in (1, 2):
-        if tile == 1 and C % 128: continue
+    for tile in (1, 2, 3, 4):
         us = t(lambda: T.wgrad(E, dy, x, dw, ksize=3, stride=1, pad=1, tile=tile))
         print(f"conv B={B} H={H} C={C} N={N} tile {tile}: {us:8.1f} us {fl/us/1e6:7.1f} TF/s", flush=True)
     us = t(old); print(f"conv B={B} H={H} C={C} N={N} old   : {us:8.1f} us {fl/us/1e6:7.1f} TF/s", flush=True)
