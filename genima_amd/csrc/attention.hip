@@ -472,8 +472,10 @@ int32_t gn_launch_attention(gn_ctx* ctx, const gn_attn_desc* d) {
     // measured on MI355X (tools/bench_attn.py, 8 x 5 x 4096^2 / 8 x 10 x 1024^2): 4 waves x 32 rows 220 / 39 us, 4 waves x 64 rows
     // 268 / 52 (occupancy 1), 8 waves x 32 rows 252 / 46; attention_stream.hip 194 / 32 against 218 / 35 on one box (round 3).
     const int ov = attn_variant_override();
-    if (ov == 1) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
-    else if (ov == 2) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
+    // (the block-shape overrides exist for V^T only: a row-major V -- the cross-attention reading the combined K | V projection -- keeps its kernel;
+    //  taking it as V^T read far outside the tensor: tools/probes/cross_attn_variants.py faulted on it)
+    if (ov == 1 && !d->v_rowmajor) launch_attn<64, 4, 2>(p, d->B, ctx->stream);
+    else if (ov == 2 && !d->v_rowmajor) launch_attn<64, 8, 1>(p, d->B, ctx->stream);
     else if (!d->causal && !d->v_rowmajor && d->Nk % 64 == 0 && d->Nk >= 128 &&
              (ov == 5 || (ov < 0 && pwg_min_keys() > 0 && d->Nk >= pwg_min_keys() && (long)((d->Nq + 255) / 256) * d->heads * d->B >= pwg_min_blocks())))
       gn_launch_attention_pwg(p, d->B, ctx->stream);

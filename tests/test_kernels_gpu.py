@@ -335,6 +335,16 @@ def test_attention_rowmajor_v(engine, heads, Nq, Nk, causal):
     else:  # the V^T form of these shapes runs the branch-free kernel (attention_stream.hip): another summation order
         assert_close(o1, o2.float(), rel=1e-3, what="V^T (stream kernel) vs row-major V (generic kernel)")
     assert_attention(o2, q, k, v, heads, causal, what="row-major V")
+    # the block-shape overrides (GN_ATTN_VARIANT 1 / 2: tuning aids) have no row-major-V form: such a problem keeps its kernel (it used to be read as V^T,
+    # far outside the tensor)
+    for var in (1, 2):
+        prev = engine.lib.gn_attention_set_variant(var)
+        try:
+            o3 = engine.attention(q, k, v, heads, Nk=Nk, causal=causal, v_rowmajor=True)
+            engine.synchronize()
+        finally:
+            engine.lib.gn_attention_set_variant(prev)
+        assert torch.equal(o3, o2), f"variant {var} with a row-major V"
 
 
 # ---------------------------------------------------------------------------------------------------- norms
